@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- segmented Mpixels/s of the U-Net inference hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 2-class U-Net, filters (16,32,64,128,256), batch of
+32 synthetic 512x512x1 tiles per GPU, fp32, inputs resident in HBM before the timed
+region.  One "step" = one pass of the hot path over the batch: UNet2D.predict() =
+logits + uint8 argmax mask for every tile.  Multi-GPU: one process per GPU, each rank
+segments its own 32-tile batch (tiles are independent units -> weak scaling, no
+data-path collective); value = pixels all ranks segmented / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the f32 MFMA implicit-GEMM
+convolution; achieved = its algorithmic FLOPs / its HIP-event time inside the timed region)
+and `cpu_baseline` (the torch-CPU oneDNN restatement of the same net on the host cores,
+standing in for the reference's TF-CPU path -- see BASELINE.md section 3).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+TILE = 512
+BATCH = 32
+FILTERS = (16, 32, 64, 128, 256)
+
+
+def mfma_conv_flops(n, h, w, cin, cout, k):
+    return 2.0 * n * h * w * cin * cout * k * k
+
+
+class ConvTimer(object):
+    """Wraps ops.conv2d so every MFMA-path convolution launch is bracketed by HIP events on
+    the stream it is launched on (torch's current stream IS the launch stream)."""
+
+    def __init__(self, ops_mod):
+        self.ops = ops_mod
+        self.orig = ops_mod.conv2d
+        self.records = []        # (start_event, end_event, flops)
+
+    def __enter__(self):
+        def timed(x, w, bias=None, act=None, wscale=1.0, out=None):
+            cin, cout, k = int(w.shape[2]), int(w.shape[3]), int(w.shape[0])
+            on_mfma = (cin % 16 == 0 or cin == 8) and not (k == 1 and cout <= 4)
+            if not on_mfma:
+                return self.orig(x, w, bias, act=act, wscale=wscale, out=out)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = self.orig(x, w, bias, act=act, wscale=wscale, out=out)
+            e.record()
+            n, h, ww = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+            self.records.append((s, e, mfma_conv_flops(n, h, ww, cin, cout, k)))
+            return y
+        self.ops.conv2d = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.conv2d = self.orig
+
+    def summary(self):
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return ms, fl, len(self.records)
+
+
+def cpu_baseline(weights, params, budget_s=20.0):
+    """Bounded CPU sample: time the torch-CPU (oneDNN, fp32, channels_last) restatement on a
+    few tiles of the same workload; never the thing shipped, only the reported baseline."""
+    from oracle.torch_ref import TorchCpuUNet
+    threads = os.cpu_count() or 1
+    net = TorchCpuUNet(weights, params, threads=threads)
+    x1 = np.random.default_rng(1).standard_normal((1, TILE, TILE, 1)).astype(np.float32)
+    net(x1)                                            # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    net(x1)
+    t1 = time.perf_counter() - t0
+    nt = int(max(1, min(8, budget_s / max(t1, 1e-3) / 3)))
+    xb = np.random.default_rng(1).standard_normal((nt, TILE, TILE, 1)).astype(np.float32)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        net(xb)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(nt * TILE * TILE / best / 1e6, 3), "unit": "Mpixels/s", "cores": net.threads,
+            "kind": "port",
+            "sample": "torch-CPU oneDNN fp32 restatement of the same U-Net (oracle/torch_ref.py), "
+                      "%d x 512x512 tiles per pass, best of 3 passes, %d threads; stands in for the "
+                      "reference TF-CPU path (TensorFlow not installable)" % (nt, net.threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from sequitr_amd import ops
+    from sequitr_amd.networks.unet import UNet2D, init_unet_weights
+
+    params = {"shape": (TILE, TILE), "num_inputs": 1, "num_outputs": 2, "filters": FILTERS,
+              "bridge": "eltwise_mul", "device": str(dev)}
+    weights = init_unet_weights(params, seed=0)
+    net = UNet2D(params, "infer")
+    net.load_state_dict(weights)
+    # synthetic tiles, already resident in HBM (seed 1 + rank: every rank its own batch)
+    x = torch.from_numpy(np.random.default_rng(1 + rank).standard_normal(
+        (BATCH, TILE, TILE, 1)).astype(np.float32)).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        net.predict(x)
+    barrier()
+    with ConvTimer(ops) as ct:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            net.predict(x)
+        barrier()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        pix = float(world) * BATCH * TILE * TILE * args.steps
+        conv_ms, conv_flops, nlaunch = ct.summary()
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            "metric": "segmented Mpixels/sec on 512x512 tiles; IoU vs reference",
+            "value": round(pix / dt / 1e6, 3),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "U-Net 2-class inference, batch=32 512x512x1 tiles per GPU, fp32 "
+                                   "(BASELINE.json configs[1]); logits + uint8 argmax mask",
+                       "filters": list(FILTERS), "bridge": "eltwise_mul", "tiles_per_gpu": BATCH,
+                       "parity": "logits and masks bit-exact vs oracle/sq_oracle.c (tests/test_gpu_unet.py)"},
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "conv_mfma_f32_kernel (3x3 implicit GEMM, v_mfma_f32_16x16x4_f32)",
+                "achieved": round(achieved, 3),
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None,
+                "launches_per_step": nlaunch // max(1, args.steps),
+                "kernel_ms_per_step": round(conv_ms / max(1, args.steps), 4),
+                "flops_per_step": conv_flops / max(1, args.steps),
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(weights, params)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+/*
+ * sequitr_hip.h -- C-ABI of libsequitr_hip.so, the MI355X (gfx950) back end of
+ * the sequitr per-tile network hot path.
+ *
+ * The reference has NO FFI: its leaf operators are Python hooks
+ * on the UNet class (sequitr/networks/unet.py:326-343) and module-level
+ * functions in sequitr/networks/gan.py:44-136 that call TensorFlow.  Each entry
+ * point below names the hook / function whose arithmetic it replaces; the
+ * Python side that binds them with ctypes is sequitr_amd/_lib.py +
+ * sequitr_amd/ops.py, and INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, negative = SQ_E*; sq_last_error()
+ *     returns a thread-local message for the last failure on this thread;
+ *   - all tensor pointers are DEVICE pointers (e.g. torch.Tensor.data_ptr());
+ *     the caller owns every byte, kernels never allocate;
+ *   - layout is NHWC, weights HWIO (kh,kw,Cin,Cout), transpose-conv weights in
+ *     TensorFlow's (kh,kw,Cout,Cin);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     launches are asynchronous and graph-capturable (no sync, no malloc);
+ *   - no global mutable state: one host thread per GPU process may call in.
+ *
+ * Numerics contract for the f32 entry points: every
+ * convolution output is one f32 fmaf chain from +0, reduction order
+ * (16-channel chunk, tap, channel), then "+ bias" (one rounding), then the
+ * activation.  oracle/sq_oracle.c restates it; parity is bit-exact.
+ */
+#ifndef SEQUITR_HIP_H
+#define SEQUITR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQ_OK 0
+#define SQ_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
+#define SQ_ELAUNCH (-2)  /* HIP reported a launch error */
+#define SQ_EALIGN (-3)   /* pointer not 16-byte aligned */
+
+/* activations */
+#define SQ_ACT_NONE 0
+#define SQ_ACT_RELU 1    /* UNet._activation, sequitr/networks/unet.py:142 */
+#define SQ_ACT_LEAKY 2   /* k_leaky_relu_alpha, alpha 0.2, sequitr/networks/gan.py:44-46 */
+
+/* bridges, sequitr/networks/unet.py:42,190-200 (up-scaled operand first) */
+#define SQ_BRIDGE_NONE 0
+#define SQ_BRIDGE_ADD 1
+#define SQ_BRIDGE_MUL 2
+#define SQ_BRIDGE_SUB 3
+
+int sq_version(void);
+const char *sq_last_error(void);
+
+/*
+ * conv_layer / conv_layer_1x1 hooks (sequitr/networks/unet.py:326-333) and
+ * weighted_conv2d / to_image / from_image (sequitr/networks/gan.py:61-125).
+ * KxK (K = 1 or 3) SAME stride-1 convolution + bias + activation.
+ *   x (N,H,W,Cin)  w (K,K,Cin,Cout)  bias (Cout) or NULL  y (N,H,W,Cout)
+ * wscale: runtime equalised-LR scale, w' = fl(w*wscale) (gan.py:75-79); 1.0f for the U-Net.
+ * Supported: Cin in {1,2} or Cin % 8 == 0; Cout % 4 == 0, or Cout <= 4 with K == 1.
+ */
+int sq_conv2d_nhwc_fwd_f32(const float *x, const float *w, const float *bias, float *y,
+                           int N, int H, int W, int Cin, int Cout, int K,
+                           float wscale, int act, void *stream);
+
+/*
+ * max_pool_layer / pool_layer hook (sequitr/networks/unet.py:242,340-342):
+ * 2x2 stride-2 VALID max pooling.  x (N,H,W,C) -> y (N,H/2,W/2,C); H,W even, C % 4 == 0.
+ */
+int sq_maxpool2x2_fwd_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
+
+/* tf.layers.average_pooling2d(2,2) in the discriminator (sequitr/networks/gan.py:189-192). */
+int sq_avgpool2x2_fwd_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
+
+/*
+ * conv_transpose_layer hook (sequitr/networks/unet.py:336-338) fused with the
+ * bridge of up_layer (unet.py:312-319): 2x2 stride-2 transpose convolution +
+ * bias, then bridge(upscale, skip).
+ *   x (N,H,W,Cin)  w (2,2,Cout,Cin)  bias (Cout) or NULL
+ *   skip (N,2H,2W,Cout) or NULL when bridge == SQ_BRIDGE_NONE   y (N,2H,2W,Cout)
+ * Cin % 16 == 0, Cout % 16 == 0.
+ */
+int sq_convT2x2s2_nhwc_fwd_f32(const float *x, const float *w, const float *bias,
+                               const float *skip, float *y, int N, int H, int W,
+                               int Cin, int Cout, int bridge, void *stream);
+
+/* UNet.bridge as a stand-alone op (sequitr/networks/unet.py:190-200), y = a (op) b, n elements, n % 4 == 0. */
+int sq_bridge_fwd_f32(const float *a, const float *b, float *y, int64_t n, int bridge, void *stream);
+
+/*
+ * to_image head of UNet.build (sequitr/networks/unet.py:252-253) fused with the
+ * prediction argmax: 1x1 conv Cin -> Cout (Cout <= 4) writes f32 logits and the
+ * uint8 class mask (ties -> lowest index) in one pass.  mask may be NULL.
+ */
+int sq_conv1x1_argmax_fwd_f32(const float *x, const float *w, const float *bias,
+                              float *logits, uint8_t *mask, int N, int H, int W,
+                              int Cin, int Cout, void *stream);
+
+/* argmax over the channel axis of (npix, C) f32 logits -> uint8, ties -> lowest index. */
+int sq_argmax_u8(const float *logits, uint8_t *mask, int64_t npix, int C, void *stream);
+
+/* pixel_norm (sequitr/networks/gan.py:49-51): y = x * rsqrt(mean_c(x^2) + eps). C % 4 == 0. */
+int sq_pixelnorm_fwd_f32(const float *x, float *y, int64_t npix, int C, float eps, void *stream);
+
+/* double_size (sequitr/networks/gan.py:133-136): nearest-neighbour 2x up-sampling. C % 4 == 0. */
+int sq_upsample_nn2x_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
+
+/*
+ * Weighted softmax cross-entropy, forward + backward in one pass (SURVEY.md A.3;
+ * tensor contract sequitr/networks/unet.py:395-401).
+ *   logits (npix,C) f32, onehot (npix,C) u8, weights (npix) f32
+ *   partials: workspace of sq_wsoftmax_ce_partials(npix) doubles (block sums, fixed order)
+ *   loss: 1 double on the device = sum(partials)/npix, written by a second tiny kernel
+ *   dlogits (npix,C) f32 or NULL:  w_p (softmax_c * sum(y) - y_c) * grad_scale / npix
+ */
+int64_t sq_wsoftmax_ce_partials(int64_t npix);
+int sq_wsoftmax_ce_fwd_bwd_f32(const float *logits, const uint8_t *onehot, const float *weights,
+                               int64_t npix, int C, float grad_scale, double *partials,
+                               double *loss, float *dlogits, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEQUITR_HIP_H */

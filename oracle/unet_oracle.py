@@ -1,0 +1,49 @@
+"""U-Net forward on the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Wiring restated from sequitr/networks/unet.py:224-322 (UNet.build, conv_block,
+down_layer, up_layer); leaf ops are the build defaults of SURVEY.md A.1 because
+the reference leaves them abstract (unet.py:326-343).  State-dict keys mirror
+the reference's variable scopes (unet.py:234,268-271,294,312-318,252).
+"""
+import numpy as np
+
+from . import c_oracle as co
+
+DEFAULT_FILTERS = (16, 32, 64, 128, 256)      # sequitr/networks/unet.py:40
+
+
+def unet_forward(x, weights, params=None, return_net=False):
+    """x: (N,H,W,num_inputs) float32; weights: {scope/kernel|bias: ndarray}.
+
+    Inference mode: dropout (unet.py:274-276) is the identity.
+    Returns logits (N,H,W,num_outputs) [, list of per-layer activations].
+    """
+    params = params or {}
+    filters = tuple(params.get("filters", DEFAULT_FILTERS))
+    bridge = params.get("bridge", "eltwise_mul")               # unet.py:138
+    if bridge == "concat":
+        raise NotImplementedError("concat bridge is restated in torch_ref only")
+
+    def conv_block(t, scope):                                  # unet.py:265-277
+        for k in ("conv1", "conv2"):
+            t = co.conv2d(t, weights[scope + "/" + k + "/kernel"],
+                          weights[scope + "/" + k + "/bias"], act="relu")
+        return t
+
+    x = np.ascontiguousarray(x, np.float32)
+    net = [conv_block(x, "UNet/down0")]                        # unet.py:238
+    for i in range(1, len(filters)):                           # unet.py:241-243
+        net.append(conv_block(co.maxpool2x2(net[-1]), "UNet/down%d" % i))
+    for i in reversed(range(len(filters) - 1)):                # unet.py:246-249
+        s = "UNet/up%d" % i
+        up = co.convT2x2s2(net[-1], weights[s + "/upscale/kernel"], weights[s + "/upscale/bias"],
+                           skip=net[i], bridge=bridge)         # unet.py:312-319
+        net.append(conv_block(up, s))                          # unet.py:321
+    logits = co.conv2d(net[-1], weights["UNet/to_image/kernel"],
+                       weights["UNet/to_image/bias"], act=None)  # unet.py:252-253
+    net.append(logits)
+    return (logits, net) if return_net else logits
+
+
+def predict_mask(logits):
+    return co.argmax_u8(logits)

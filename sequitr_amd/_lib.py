@@ -1,0 +1,63 @@
+"""ctypes loader for libsequitr_hip.so (the C-ABI of include/sequitr_hip.h).
+
+The product path has NO fallback: if the library is missing or a symbol is
+absent this module raises, loudly.  Build with ``make -C sequitr_amd/csrc`` or
+``python -c "import __graft_entry__ as g; g.build()"``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libsequitr_hip.so")
+
+c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+
+# name -> (restype, argtypes); must list every symbol include/sequitr_hip.h declares
+SIGNATURES = {
+    "sq_version": (c_int, []),
+    "sq_last_error": (ctypes.c_char_p, []),
+    "sq_conv2d_nhwc_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_int, c_void_p]),
+    "sq_maxpool2x2_fwd_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "sq_avgpool2x2_fwd_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "sq_convT2x2s2_nhwc_fwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "sq_bridge_fwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
+    "sq_conv1x1_argmax_fwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "sq_argmax_u8": (c_int, [c_void_p] * 2 + [c_int64, c_int, c_void_p]),
+    "sq_pixelnorm_fwd_f32": (c_int, [c_void_p] * 2 + [c_int64, c_int, c_float, c_void_p]),
+    "sq_upsample_nn2x_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "sq_wsoftmax_ce_partials": (c_int64, [c_int64]),
+    "sq_wsoftmax_ce_fwd_bwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_float] + [c_void_p] * 4),
+}
+
+_lib = None
+
+
+class SequitrHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SequitrHipError(
+            "libsequitr_hip.so not found at %s -- the HIP back end is mandatory "
+            "(no CPU fallback); build it with `make -C sequitr_amd/csrc`" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise SequitrHipError("libsequitr_hip.so does not export %s" % name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        msg = load().sq_last_error()
+        raise SequitrHipError("%s failed (%d): %s" % (name, rc, msg.decode() if msg else "?"))

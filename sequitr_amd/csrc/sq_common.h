@@ -1,0 +1,52 @@
+// Shared host/device helpers for libsequitr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sequitr_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void sq_set_error(const char *fmt, ...);
+
+#define SQ_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            sq_set_error(__VA_ARGS__);   \
+            return SQ_EINVAL;            \
+        }                                \
+    } while (0)
+
+#define SQ_ALIGNED16(p) ((((uintptr_t)(p)) & 15u) == 0)
+
+#define SQ_REQUIRE_ALIGNED(p)                                     \
+    do {                                                          \
+        if (!SQ_ALIGNED16(p)) {                                   \
+            sq_set_error("%s: pointer %s not 16-byte aligned", __func__, #p); \
+            return SQ_EALIGN;                                     \
+        }                                                         \
+    } while (0)
+
+static inline int sq_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        sq_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return SQ_ELAUNCH;
+    }
+    return SQ_OK;
+}
+
+__device__ __forceinline__ float sq_act(float v, int act) {
+    if (act == SQ_ACT_RELU) return v > 0.0f ? v : 0.0f;
+    if (act == SQ_ACT_LEAKY) return v > 0.0f ? v : 0.2f * v;
+    return v;
+}
+
+// XCD-aware, bijective block remap (8 XCDs, blocks dealt round-robin): gives each
+// XCD a contiguous run of tiles so neighbouring tiles' halos hit the same L2.
+// Speed only; any placement is correct.
+__device__ __forceinline__ unsigned sq_xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, k = bid >> 3;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}

@@ -1,0 +1,184 @@
+// conv_transpose_layer hook (sequitr/networks/unet.py:336-338) fused with the up_layer
+// bridge (unet.py:312-319), and the weighted softmax cross-entropy.
+#include "sq_common.h"
+
+namespace {
+
+// ---- 2x2 stride-2 transpose convolution as a GEMM on v_mfma_f32_16x16x4_f32 --------
+// Non-overlapping: every input pixel p=(n,i,j) produces the 2x2 output patch
+//   y[n,2i+a,2j+b,o] = chain_c fmaf(w[a,b,o,c], x[p,c]) + bias[o]   (c ascending)
+// i.e. D[rho][p] with rho = (2a+b)*Cout + o and Wt[rho][c] = the TF kernel (2,2,Cout,Cin)
+// read flat.  Block = 64 rows x 64 input pixels, wave w owns rows 16w..16w+15 and four
+// 16-pixel column blocks; a lane ends up with 4 consecutive o of one output pixel, so the
+// bridge operand is one 16-B load and the result one 16-B store.
+constexpr int CT_PS = 18;  // 16-channel chunk + 2 pad floats: conflict-free ds_read_b32
+
+__global__ __launch_bounds__(256) void convT2x2_mfma_f32_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    const float *__restrict__ skip, float *__restrict__ y, int64_t P, int H, int W, int Cin,
+    int Cout, int bridge) {
+    __shared__ __attribute__((aligned(16))) float as[64 * CT_PS];
+    __shared__ __attribute__((aligned(16))) float xs[64 * CT_PS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int r0 = blockIdx.y * 64;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int srow = tid >> 2, sq = tid & 3;  // staging: 64 rows x 4 float4
+    for (int cc = 0; cc < Cin; cc += 16) {
+        {
+            const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)(r0 + srow) * Cin + cc + sq * 4);
+            float *d = as + srow * CT_PS + sq * 4;
+            *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2 *>(d + 2) = make_float2(v.z, v.w);
+        }
+        {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + srow < P)
+                v = *reinterpret_cast<const float4 *>(x + (size_t)(p0 + srow) * Cin + cc + sq * 4);
+            float *d = xs + srow * CT_PS + sq * 4;
+            *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2 *>(d + 2) = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float a = as[(16 * wv + li) * CT_PS + s * 4 + kk];
+            float b[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) b[cb] = xs[(cb * 16 + li) * CT_PS + s * 4 + kk];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[cb], acc[cb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int rho = r0 + 16 * wv + 4 * kk;
+    const int ab = rho / Cout, o = rho % Cout;
+    const int a = ab >> 1, b = ab & 1;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4 *>(bias + o);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int64_t p = p0 + cb * 16 + li;
+        if (p >= P) continue;
+        const int j = (int)(p % W);
+        const int64_t t = p / W;
+        const int i = (int)(t % H);
+        const int64_t n = t / H;
+        const size_t off = ((size_t)(n * 2 * H + 2 * i + a) * (2 * W) + 2 * j + b) * Cout + o;
+        float4 v = make_float4(acc[cb][0] + bv.x, acc[cb][1] + bv.y, acc[cb][2] + bv.z, acc[cb][3] + bv.w);
+        if (!bias) v = make_float4(acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]);
+        if (bridge != SQ_BRIDGE_NONE) {
+            const float4 k = *reinterpret_cast<const float4 *>(skip + off);
+            if (bridge == SQ_BRIDGE_ADD) v = make_float4(v.x + k.x, v.y + k.y, v.z + k.z, v.w + k.w);
+            else if (bridge == SQ_BRIDGE_MUL) v = make_float4(v.x * k.x, v.y * k.y, v.z * k.z, v.w * k.w);
+            else v = make_float4(v.x - k.x, v.y - k.y, v.z - k.z, v.w - k.w);
+        }
+        *reinterpret_cast<float4 *>(y + off) = v;
+    }
+}
+
+// ---- weighted softmax cross-entropy, forward + backward in one pass over the logits -----
+// Pure HBM: per pixel reads C f32 logits + C u8 labels + 1 f32 weight, writes C f32 dlogits.
+// Loss partials are summed in fp64 in a fixed order (thread grid-stride order, then a
+// fixed LDS tree, then one thread over the block partials) => run-to-run reproducible.
+constexpr int CE_MAXC = 8;
+
+__global__ __launch_bounds__(256) void wsoftmax_ce_f32_kernel(
+    const float *__restrict__ z, const uint8_t *__restrict__ yoh, const float *__restrict__ wgt,
+    int64_t npix, int C, float gscale, double *__restrict__ partials, float *__restrict__ dz) {
+    __shared__ double red[256];
+    double tsum = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+        float zc[CE_MAXC], yc[CE_MAXC];
+        float m = -INFINITY, yt = 0.f, dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < CE_MAXC; ++c) {
+            if (c < C) {
+                zc[c] = z[p * C + c];
+                yc[c] = (float)yoh[p * C + c];
+                m = zc[c] > m ? zc[c] : m;
+                yt += yc[c];
+                dot = __builtin_fmaf(yc[c], zc[c], dot);
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CE_MAXC; ++c)
+            if (c < C) s += expf(zc[c] - m);
+        const float lse = m + logf(s);
+        const float wp = wgt[p];
+        tsum += (double)(wp * (lse * yt - dot));
+        if (dz) {
+            const float g = wp * gscale;
+#pragma unroll
+            for (int c = 0; c < CE_MAXC; ++c)
+                if (c < C) dz[p * C + c] = g * (expf(zc[c] - lse) * yt - yc[c]);
+        }
+    }
+    red[threadIdx.x] = tsum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+__global__ void ce_finish_kernel(const double *__restrict__ partials, int n, double inv_npix,
+                                 double *__restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += partials[i];
+        *loss = s * inv_npix;
+    }
+}
+
+inline int64_t ce_blocks(int64_t npix) {
+    int64_t b = (npix + 255) / 256;
+    return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" int sq_convT2x2s2_nhwc_fwd_f32(const float *x, const float *w, const float *bias,
+                                          const float *skip, float *y, int N, int H, int W, int Cin,
+                                          int Cout, int bridge, void *stream) {
+    SQ_REQUIRE(x && w && y, "sq_convT2x2s2_nhwc_fwd_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0, "sq_convT2x2s2_nhwc_fwd_f32: bad shape");
+    SQ_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0 && Cin > 0 && Cout > 0,
+               "sq_convT2x2s2_nhwc_fwd_f32: Cin=%d and Cout=%d must be multiples of 16", Cin, Cout);
+    SQ_REQUIRE(bridge >= SQ_BRIDGE_NONE && bridge <= SQ_BRIDGE_SUB, "sq_convT2x2s2_nhwc_fwd_f32: bad bridge %d", bridge);
+    SQ_REQUIRE(bridge == SQ_BRIDGE_NONE || skip, "sq_convT2x2s2_nhwc_fwd_f32: bridge needs a skip tensor");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(w); SQ_REQUIRE_ALIGNED(y);
+    if (bias) SQ_REQUIRE_ALIGNED(bias);
+    if (skip) SQ_REQUIRE_ALIGNED(skip);
+    const int64_t P = (int64_t)N * H * W;
+    dim3 grid((unsigned)((P + 63) / 64), (unsigned)(4 * Cout / 64));
+    hipLaunchKernelGGL(convT2x2_mfma_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       x, w, bias, skip, y, P, H, W, Cin, Cout, bridge);
+    return sq_check_launch("sq_convT2x2s2_nhwc_fwd_f32");
+}
+
+extern "C" int64_t sq_wsoftmax_ce_partials(int64_t npix) { return npix > 0 ? ce_blocks(npix) : 0; }
+
+extern "C" int sq_wsoftmax_ce_fwd_bwd_f32(const float *logits, const uint8_t *onehot,
+                                          const float *weights, int64_t npix, int C, float grad_scale,
+                                          double *partials, double *loss, float *dlogits, void *stream) {
+    SQ_REQUIRE(logits && onehot && weights && partials && loss, "sq_wsoftmax_ce_fwd_bwd_f32: null pointer");
+    SQ_REQUIRE(npix > 0 && C >= 1 && C <= CE_MAXC, "sq_wsoftmax_ce_fwd_bwd_f32: C=%d unsupported (1..%d)", C, CE_MAXC);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nb = (int)ce_blocks(npix);
+    hipLaunchKernelGGL(wsoftmax_ce_f32_kernel, dim3(nb), dim3(256), 0, st, logits, onehot, weights, npix, C,
+                       grad_scale / (float)npix, partials, dlogits);
+    int rc = sq_check_launch("sq_wsoftmax_ce_fwd_bwd_f32");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, partials, nb, 1.0 / (double)npix, loss);
+    return sq_check_launch("sq_wsoftmax_ce_fwd_bwd_f32(finish)");
+}

@@ -1,0 +1,341 @@
+"""U-Net on the MI355X HIP back end, behind the reference's operator API.
+
+Mirrors sequitr/networks/unet.py: ``UNet(params, mode)`` with the same ``params``
+keys and attributes (unet.py:126-216), ``build(features) -> logits`` with the same
+wiring (unet.py:224-262), ``conv_block`` / ``down_layer`` / ``up_layer``
+(unet.py:265-322) and the overridable leaf hooks ``conv_layer``,
+``conv_layer_1x1``, ``conv_transpose_layer``, ``pool_layer`` (unet.py:326-343) --
+plus ``max_pool_layer``, the name ``build`` actually calls (unet.py:242).
+
+The reference's base class is abstract and its ``UNet2D`` subclass is not in the
+tree; ``UNet2D`` here supplies the leaf ops with the documented
+defaults of SURVEY.md A.1, every one a hand-written HIP kernel reached through
+the C-ABI (include/sequitr_hip.h).  TF variable scopes are mirrored by a scope
+stack, so ``state_dict()`` keys equal the reference's variable names
+(``UNet/down0/conv1/kernel`` ...).
+"""
+import contextlib
+import logging
+
+import numpy as np
+import torch
+
+from .. import ops
+
+DEFAULT_FILTERS = (16, 32, 64, 128, 256)                       # unet.py:40
+DEFAULT_DROPOUT = 0.4                                          # unet.py:41
+BRIDGE_TYPES = ('eltwise_add', 'eltwise_mul', 'eltwise_sub', 'concat', None)   # unet.py:42
+
+TRAIN, EVAL, PREDICT = 'train', 'eval', 'infer'                # tf.estimator.ModeKeys values
+
+logger = logging.getLogger('worker_process')                   # unet.py:46
+
+
+def variance_scaling(shape, rng, scale=1.0):
+    """TF-1.x ``tf.initializers.variance_scaling()`` defaults (unet.py:143):
+    mode fan_in, truncated normal at +-2 sigma, stddev = sqrt(scale/fan_in)/0.8796...
+    fan_in = shape[-2] * prod(shape[:-2]) as TF's _compute_fans does (for a
+    conv2d_transpose kernel (kh,kw,Cout,Cin) that is Cout*kh*kw)."""
+    fan_in = float(shape[-2] * int(np.prod(shape[:-2])))
+    std = np.sqrt(scale / max(1.0, fan_in)) / .87962566103423978
+    out = rng.standard_normal(size=shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():                                           # TF re-draws outliers
+        out[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return (out * std).astype(np.float32)
+
+
+def unet_variable_shapes(params):
+    """(key, shape) of every U-Net variable in creation (= build) order; keys are the
+    reference's variable-scope names (unet.py:234,252,268-271,294,312-318)."""
+    f = list(params.get('filters', DEFAULT_FILTERS))
+    k = tuple(params.get('kernel', (3, 3)))
+    cin = params.get('num_inputs', 1)
+    nout = params.get('num_outputs', 2)
+    concat = params.get('bridge', 'eltwise_mul') == 'concat'
+    out = []
+    for i, fo in enumerate(f):
+        for j, ci in enumerate((cin, fo)):
+            s = 'UNet/down%d/conv%d' % (i, j + 1)
+            out += [(s + '/kernel', k + (ci, fo)), (s + '/bias', (fo,))]
+        cin = fo
+    for i in reversed(range(len(f) - 1)):
+        s = 'UNet/up%d' % i
+        out += [(s + '/upscale/kernel', (2, 2, f[i], f[i + 1])), (s + '/upscale/bias', (f[i],))]
+        for j, ci in enumerate((2 * f[i] if concat else f[i], f[i])):
+            out += [(s + '/conv%d/kernel' % (j + 1), k + (ci, f[i])), (s + '/conv%d/bias' % (j + 1), (f[i],))]
+    out += [('UNet/to_image/kernel', (1, 1, f[0], nout)), ('UNet/to_image/bias', (nout,))]
+    return out
+
+
+def init_unet_weights(params, seed=0):
+    """Host-side initial weights {key: float32 ndarray}: variance_scaling kernels, zero
+    biases.  Needs no GPU; UNet2D.initialize() uploads exactly these."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for key, shape in unet_variable_shapes(params):
+        w[key] = variance_scaling(shape, rng) if key.endswith('kernel') else np.zeros(shape, np.float32)
+    return w
+
+
+class UNet(object):
+    """Base class: wiring only, leaf hooks abstract (as sequitr/networks/unet.py:53-343)."""
+
+    def __init__(self, params, mode):
+        self._mode = mode
+        self.name = params.get('name', 'UNet2d_test')          # unet.py:132-139
+        self.filters = params.get('filters', DEFAULT_FILTERS)
+        self.dropout = params.get('dropout', DEFAULT_DROPOUT)
+        self.n_inputs = params.get('num_inputs', 1)
+        self.n_outputs = params.get('num_outputs', 2)
+        self.shape = params.get('shape', (1024, 1024))
+        self.bridge_type = params.get('bridge', 'eltwise_mul')
+        self.kernel = params.get('kernel', (3, 3))
+        self._net = None
+        self._scopes = []
+
+    # -- geometry properties, unet.py:148-167 --------------------------------------
+    @property
+    def width(self):
+        return self.shape[0]
+
+    @property
+    def height(self):
+        return self.shape[1]
+
+    @property
+    def slices(self):
+        if self.ndim < 3:
+            return 0
+        return self.shape[2]
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def training(self):                                        # unet.py:170-172
+        return self._mode == TRAIN
+
+    @property
+    def btype(self):
+        raise DeprecationWarning("Use @bridge_type")
+
+    @property
+    def bridge_type(self):
+        return self._bridge_type
+
+    @bridge_type.setter
+    def bridge_type(self, bridge):                             # unet.py:182-202
+        if bridge not in BRIDGE_TYPES:
+            raise ValueError('Bridge type not recognized')
+        if bridge in ('eltwise_add', 'eltwise_mul', 'eltwise_sub'):
+            self.bridge = lambda x, y, _k=bridge: ops.bridge(x, y, _k)
+        elif bridge == 'concat':
+            self.bridge = lambda x, y: torch.cat([x, y], -1)   # upscale first (unet.py:197)
+        else:
+            logger.warning('Bridge function in UNet not recognized')
+            self.bridge = lambda x, y: x
+        self._default_bridge = self.bridge
+        self._bridge_type = bridge
+
+    # -- scope stack standing in for tf.variable_scope ------------------------------
+    @contextlib.contextmanager
+    def variable_scope(self, name):
+        self._scopes.append(name)
+        try:
+            yield
+        finally:
+            self._scopes.pop()
+
+    @property
+    def scope(self):
+        return '/'.join(self._scopes)
+
+    def reshape_input(self, features):                         # unet.py:205-216
+        full_shape = [-1, self.slices, self.width, self.height, self.n_inputs]
+        input_shape = [d for d in full_shape if d != 0]
+        return features.reshape(input_shape)
+
+    def logits(self):                                          # unet.py:220-222
+        return self._net[-1]
+
+    def build(self, features):
+        """unet.py:224-262: returns the un-normalised logits (N,W,H,num_outputs)."""
+        logger.info('Building UNet ({0:s})...'.format(self.__class__.__name__))
+        with self.variable_scope('UNet'):
+            input_layer = self.reshape_input(features)
+            self._net = [self.down_layer(input_layer, self.filters[0], name=0)]
+            for i, f in enumerate(self.filters[1:]):
+                prev_layer = self.max_pool_layer(self._net[-1])
+                self._net.append(self.down_layer(prev_layer, f, name=i + 1))
+            for i, f in reversed(list(enumerate(self.filters[:-1]))):
+                prev_layer = self._net[-1]
+                bridge = self._net[i]
+                self._net.append(self.up_layer(prev_layer, f, bridge, name=i))
+            with self.variable_scope('to_image'):
+                logits = self.conv_layer_1x1(self._net[-1], self.n_outputs)
+        logger.info('Output layer -> shape {0:s}'.format(str(tuple(logits.shape))))
+        self._net.append(logits)
+        logger.info('...Done')
+        return logits
+
+    def conv_block(self, x, filters):                          # unet.py:265-277
+        with self.variable_scope('conv1'):
+            conv1 = self.conv_layer(x, filters)
+        with self.variable_scope('conv2'):
+            conv2 = self.conv_layer(conv1, filters)
+        return self.dropout_layer(conv2)
+
+    def dropout_layer(self, x):
+        """tf.layers.dropout(rate=self.dropout, training=self.training), unet.py:274-276."""
+        return x
+
+    def down_layer(self, x, filters, name=None):               # unet.py:282-296
+        logger.info('Down layer -> shape {0:s}'.format(str(tuple(x.shape))))
+        with self.variable_scope('down{0:d}'.format(name)):
+            out = self.conv_block(x, filters)
+        return out
+
+    def up_layer(self, x, filters, bridge, name=None):         # unet.py:299-322
+        logger.info('Up layer -> shape {0:s} (bridge: {1:s})'.format(str(tuple(x.shape)),
+                                                                      str(self.bridge_type)))
+        with self.variable_scope('up{0:d}'.format(name)):
+            with self.variable_scope('upscale'):
+                upscale = self.conv_transpose_layer(x, filters)
+            with self.variable_scope('bridge'):
+                bridge = self.bridge(upscale, bridge)
+            out = self.conv_block(bridge, filters)
+        return out
+
+    # -- leaf hooks, unet.py:326-343 -------------------------------------------------
+    def conv_layer(self, x, filters):
+        """ Convolution layer, conv-relu with padding """
+        raise NotImplementedError
+
+    def conv_layer_1x1(self, x, filters):
+        """ Return a 1x1 convolution layer """
+        raise NotImplementedError
+
+    def conv_transpose_layer(self, x, filters):
+        """ Transpose convolution (aka deconvolution) layer """
+        raise NotImplementedError
+
+    def pool_layer(self, x):
+        """ Max pool operation """
+        raise NotImplementedError
+
+    def max_pool_layer(self, x):
+        """ the name build() calls (unet.py:242, UNet_LEGACY unet.py:727) """
+        return self.pool_layer(x)
+
+
+class UNet2D(UNet):
+    """2-D U-Net whose leaf ops are the HIP kernels of libsequitr_hip.so.
+
+    Defaults: conv_layer = 3x3 SAME conv + bias + ReLU;
+    pool = 2x2/s2 max; conv_transpose_layer = 2x2/s2 transpose conv + bias, no
+    activation; conv_layer_1x1 = 1x1 conv + bias, no activation.  Extra params
+    keys: ``device`` (torch device, default cuda:current), ``seed`` (weight init).
+    """
+
+    def __init__(self, params, mode=PREDICT):
+        UNet.__init__(self, params, mode)
+        if mode not in (TRAIN, EVAL, PREDICT):
+            raise ValueError("mode must be 'train', 'eval' or 'infer'")
+        dev = params.get('device', None)
+        self.device = torch.device(dev) if dev is not None else torch.device('cuda', torch.cuda.current_device())
+        if self.device.type != 'cuda':
+            raise RuntimeError('UNet2D runs on the HIP back end only (device=%s)' % self.device)
+        if tuple(self.kernel) not in ((3, 3), (1, 1)):
+            raise ValueError('kernel %s unsupported: the HIP conv kernels are 3x3 or 1x1' % (self.kernel,))
+        self._params = dict(params)
+        self._seed = params.get('seed', 0)
+        self._rng = np.random.default_rng(self._seed)
+        self._vars = {}                                        # scope/name -> device tensor
+        self._mask = None
+
+    # -- variables ---------------------------------------------------------------------
+    def get_variable(self, name, shape, init):
+        key = self.scope + '/' + name
+        v = self._vars.get(key)
+        if v is None:
+            v = torch.from_numpy(init(shape)).to(self.device)
+            self._vars[key] = v
+        elif tuple(v.shape) != tuple(shape):
+            raise ValueError('variable %s has shape %s, wanted %s' % (key, tuple(v.shape), tuple(shape)))
+        return v
+
+    def _kernel(self, shape):
+        return self.get_variable('kernel', shape, lambda s: variance_scaling(s, self._rng))
+
+    def _bias(self, n):
+        return self.get_variable('bias', (n,), lambda s: np.zeros(s, np.float32))
+
+    def state_dict(self):
+        return {k: v.detach().cpu().numpy() for k, v in self._vars.items()}
+
+    def load_state_dict(self, weights):
+        for k, v in weights.items():
+            self._vars[k] = torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(self.device)
+
+    def initialize(self):
+        """Create every variable without running a tile (same draws as a first build)."""
+        self.load_state_dict(init_unet_weights(self._params, self._seed))
+        return self
+
+    # -- input ---------------------------------------------------------------------------
+    def reshape_input(self, features):
+        if isinstance(features, np.ndarray):
+            features = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32))
+        if not isinstance(features, torch.Tensor):
+            raise TypeError('features must be a numpy array or a torch tensor')
+        features = features.to(self.device, dtype=torch.float32, non_blocking=True)
+        return UNet.reshape_input(self, features).contiguous()
+
+    # -- leaf hooks ------------------------------------------------------------------------
+    def conv_layer(self, x, filters):
+        k = tuple(self.kernel)
+        return ops.conv2d(x, self._kernel(k + (x.shape[-1], filters)), self._bias(filters), act='relu')
+
+    def conv_layer_1x1(self, x, filters):
+        w, b = self._kernel((1, 1, x.shape[-1], filters)), self._bias(filters)
+        if filters <= 4 and x.shape[-1] % 4 == 0:
+            logits, self._mask = ops.conv1x1_argmax(x, w, b)   # logits + prediction in one pass
+            return logits
+        return ops.conv2d(x, w, b, act=None)
+
+    def conv_transpose_layer(self, x, filters):
+        return ops.convT2x2s2(x, self._kernel((2, 2, filters, x.shape[-1])), self._bias(filters))
+
+    def pool_layer(self, x):
+        return ops.maxpool2x2(x)
+
+    def up_layer(self, x, filters, bridge, name=None):
+        """Same wiring as the base class, but when neither conv_transpose_layer nor the
+        bridge has been overridden the two run as ONE kernel (convT epilogue applies the
+        bridge), saving a write + two reads of the up-scaled tensor."""
+        fused = (type(self).conv_transpose_layer is UNet2D.conv_transpose_layer
+                 and self.bridge is self._default_bridge
+                 and self.bridge_type in ('eltwise_add', 'eltwise_mul', 'eltwise_sub'))
+        if not fused:
+            return UNet.up_layer(self, x, filters, bridge, name=name)
+        with self.variable_scope('up{0:d}'.format(name)):
+            with self.variable_scope('upscale'):
+                w, b = self._kernel((2, 2, filters, x.shape[-1])), self._bias(filters)
+            merged = ops.convT2x2s2(x, w, b, skip=bridge, bridge=self.bridge_type)
+            out = self.conv_block(merged, filters)
+        return out
+
+    def build(self, features):
+        self._mask = None
+        return UNet.build(self, features)
+
+    # -- prediction ------------------------------------------------------------------------
+    def predict(self, features):
+        """build + argmax: returns the uint8 class mask (N,W,H), ties -> lowest class."""
+        logits = self.build(features)
+        if self._mask is None or self._mask.shape != logits.shape[:-1]:
+            self._mask = ops.argmax_u8(logits)
+        return self._mask

@@ -1,0 +1,110 @@
+"""GPU parity for the whole U-Net forward (sequitr/networks/unet.py:224-322 wiring) through
+the operator API: logits, every intermediate layer and the argmax mask are BIT-EXACT
+against the C oracle; full-size batches are covered by size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle
+from sequitr_amd import ops
+from sequitr_amd.networks.unet import UNet2D, init_unet_weights
+from tests.util import tiles, assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+
+def make(params, seed=0, cls=UNet2D):
+    net = cls(dict(params, device="cuda:0"), "infer")
+    w = init_unet_weights(params, seed)
+    net.load_state_dict(w)
+    return net, w
+
+
+@pytest.mark.parametrize("bridge", ["eltwise_mul", "eltwise_add", "eltwise_sub", None])
+def test_forward_64px_every_layer_bit_exact(bridge):
+    params = {"shape": (64, 64), "bridge": bridge}
+    net, w = make(params, seed=3)
+    x = tiles(0, 2, 64, 64)
+    mask = net.predict(x)
+    ref_logits, ref_net = unet_oracle.unet_forward(x, w, params, return_net=True)
+    assert len(net._net) == len(ref_net) == 10
+    for i, (a, b) in enumerate(zip(net._net, ref_net)):
+        assert_bit_exact(a.cpu().numpy(), b, "layer %d (%s)" % (i, bridge))
+    assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref_logits), "mask")
+
+
+def test_lazy_init_equals_host_init():
+    """variables created lazily during build() draw the same stream as init_unet_weights."""
+    params = {"shape": (32, 32), "seed": 7, "device": "cuda:0"}
+    net = UNet2D(params, "infer")
+    net.build(tiles(1, 1, 32, 32))
+    w = init_unet_weights(params, seed=7)
+    sd = net.state_dict()
+    assert set(sd) == set(w)
+    for k in w:
+        assert np.array_equal(sd[k], w[k]), k
+
+
+def test_forward_512px_tile_bit_exact():
+    """BASELINE config 1/2 tile size: one 512x512x1 tile, default filters, vs the oracle."""
+    params = {"shape": (512, 512)}
+    net, w = make(params, seed=0)
+    x = tiles(0, 1, 512, 512)
+    mask = net.predict(x)
+    ref = unet_oracle.unet_forward(x, w, params)
+    assert_bit_exact(net.logits().cpu().numpy(), ref, "logits 512")
+    assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "mask 512")
+
+
+def test_full_batch_properties():
+    """N=32 x 512^2 (BASELINE config 2) without a 5-minute oracle run: (i) two runs are
+    bit-identical; (ii) tiles are independent -- tile k of the batch equals the same tile
+    run alone; (iii) the fused mask equals argmax of the logits."""
+    params = {"shape": (512, 512)}
+    net, _ = make(params, seed=0)
+    x = torch.from_numpy(tiles(1, 32, 512, 512)).cuda()
+    m1 = net.predict(x).clone()
+    l1 = net.logits().clone()
+    m2 = net.predict(x)
+    assert torch.equal(l1, net.logits()) and torch.equal(m1, m2)
+    for k in (0, 17, 31):
+        mk = net.predict(x[k:k + 1].contiguous())
+        assert torch.equal(net.logits()[0], l1[k]) and torch.equal(mk[0], m1[k])
+    assert torch.equal(ops.argmax_u8(l1), m1)
+    frac = m1.float().mean().item()
+    assert 0.0 < frac < 1.0
+
+
+def test_hook_override_and_unfused_path():
+    """Operator API: a subclass may override any leaf hook (unet.py:326-343); overriding
+    conv_transpose_layer disables the fused convT+bridge kernel and must give the same bits."""
+    class Plain(UNet2D):
+        def conv_transpose_layer(self, x, filters):
+            return UNet2D.conv_transpose_layer(self, x, filters)
+
+        def max_pool_layer(self, x):              # the name build() calls, unet.py:242
+            self.pool_calls = getattr(self, "pool_calls", 0) + 1
+            return UNet2D.pool_layer(self, x)
+
+    params = {"shape": (64, 64)}
+    a, _ = make(params, seed=5)
+    b, _ = make(params, seed=5, cls=Plain)
+    x = tiles(2, 1, 64, 64)
+    assert torch.equal(a.build(x), b.build(x))
+    assert b.pool_calls == 4
+
+
+def test_concat_bridge_runs():
+    params = {"shape": (32, 32), "bridge": "concat", "filters": (16, 32, 64)}
+    net, w = make(params, seed=1)
+    logits = net.build(tiles(3, 1, 32, 32))
+    from oracle import torch_ref
+    ref = torch_ref.unet_forward(tiles(3, 1, 32, 32), w, params)
+    assert np.max(np.abs(logits.cpu().numpy() - ref)) < 1e-4
+
+
+def test_rejects_cpu_device_and_bad_bridge():
+    with pytest.raises(RuntimeError):
+        UNet2D({"device": "cpu"}, "infer")
+    with pytest.raises(ValueError):
+        UNet2D({"bridge": "nope", "device": "cuda:0"}, "infer")
