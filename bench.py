@@ -74,7 +74,8 @@ def cpu_baseline(weights, params, budget_s=20.0):
     """Bounded CPU sample: time the torch-CPU (oneDNN, fp32, channels_last) restatement on a
     few tiles of the same workload; never the thing shipped, only the reported baseline."""
     from oracle.torch_ref import TorchCpuUNet
-    threads = os.cpu_count() or 1
+    # a 1-GPU box owns a 16-core share of the host (more threads only thrash the cgroup)
+    threads = int(os.environ.get("SQ_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     net = TorchCpuUNet(weights, params, threads=threads)
     x1 = np.random.default_rng(1).standard_normal((1, TILE, TILE, 1)).astype(np.float32)
     net(x1)                                            # warm-up (oneDNN primitive creation)

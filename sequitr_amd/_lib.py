@@ -45,6 +45,11 @@ def load():
         raise SequitrHipError(
             "libsequitr_hip.so not found at %s -- the HIP back end is mandatory "
             "(no CPU fallback); build it with `make -C sequitr_amd/csrc`" % LIB_PATH)
+    # torch ships its own libamdhip64 (soname libamdhip64.so.7).  It must be in the process
+    # BEFORE this library is loaded, so that our DT_NEEDED libamdhip64.so.7 binds to the same
+    # HIP runtime torch allocates from; loaded the other way round the process ends up with
+    # two runtimes and every launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

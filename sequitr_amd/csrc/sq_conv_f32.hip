@@ -14,6 +14,7 @@
 // tile rows 4w..4w+3.  Per chunk the (16+K-1)^2 halo (KC channels, pixel stride KC+2
 // floats => conflict-free ds_read_b32 for the B operand) and the K*K*KC x BN weight
 // slab (row stride BN or BN+16 => conflict-free A operand) are staged in LDS.
+#include <stdlib.h>
 #include "sq_common.h"
 
 namespace {
@@ -284,7 +285,22 @@ int launch_small(const float *x, const float *w, const float *bias, float *logit
     return sq_check_launch(what);
 }
 
+// SQ_CONV_IMPL=1 selects the simple one-tile-per-block kernel of this file (kept for in-process
+// A/B timing); the default (2) is the pipelined persistent kernel of sq_conv_f32_v2.hip.  Both
+// produce identical bits.  Read once; not a correctness knob.
+int conv_impl() {
+    static int impl = 0;
+    if (!impl) {
+        const char *e = getenv("SQ_CONV_IMPL");
+        impl = (e && e[0] == '1') ? 1 : 2;
+    }
+    return impl;
+}
+
 }  // namespace
+
+int sq_conv_mfma_v2(const float *x, const float *w, const float *bias, float *y, int N, int H, int W,
+                    int Cin, int Cout, int K, float wscale, int act, hipStream_t st);
 
 extern "C" int sq_conv2d_nhwc_fwd_f32(const float *x, const float *w, const float *bias, float *y,
                                       int N, int H, int W, int Cin, int Cout, int K, float wscale,
@@ -306,6 +322,8 @@ extern "C" int sq_conv2d_nhwc_fwd_f32(const float *x, const float *w, const floa
     if (Cin == 2)
         return K == 3 ? launch_direct<2, 3>(x, w, bias, y, N, H, W, Cout, wscale, act, st)
                       : launch_direct<2, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
+    if ((Cin % 16 == 0 || Cin == 8) && conv_impl() == 2)
+        return sq_conv_mfma_v2(x, w, bias, y, N, H, W, Cin, Cout, K, wscale, act, st);
     if (Cin % 16 == 0)
         return K == 3 ? dispatch_bn<3, 16>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st)
                       : dispatch_bn<1, 16>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st);
