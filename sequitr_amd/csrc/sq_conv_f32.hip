@@ -322,7 +322,9 @@ extern "C" int sq_conv2d_nhwc_fwd_f32(const float *x, const float *w, const floa
     if (Cin == 2)
         return K == 3 ? launch_direct<2, 3>(x, w, bias, y, N, H, W, Cout, wscale, act, st)
                       : launch_direct<2, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
-    if ((Cin % 16 == 0 || Cin == 8) && conv_impl() == 2)
+    // the pipelined kernel addresses tensors through 32-bit buffer offsets: < 2 GiB each
+    const bool fits32 = (size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31);
+    if ((Cin % 16 == 0 || Cin == 8) && conv_impl() == 2 && fits32)
         return sq_conv_mfma_v2(x, w, bias, y, N, H, W, Cin, Cout, K, wscale, act, st);
     if (Cin % 16 == 0)
         return K == 3 ? dispatch_bn<3, 16>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st)

@@ -30,7 +30,7 @@ struct Cfg2 {
     static constexpr int WITEMS = WROWS * (BN / 4);
     static constexpr int WSLOTS = (WITEMS + 255) / 256;
     static constexpr int NSTEP = KS * KS * (KC / 4);
-    static constexpr int OCC = BN >= 64 ? 2 : 3;  // blocks per CU (LDS-limited)
+    static constexpr int OCC = BN >= 64 ? 2 : (BN >= 32 ? 3 : 4);  // blocks per CU (LDS-limited)
     static_assert((XS_FLOATS * 4) % 16 == 0, "weight slab must start 16-B aligned");
 };
 
@@ -60,32 +60,58 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
     float4 xr[C::XSLOTS];
     float4 wr[C::WSLOTS];
 
+    // Buffer resources: out-of-range offsets read as 0 / drop the store, so image borders,
+    // ragged tiles and the "idx >= items" tail need no branches (hipcc otherwise wraps every
+    // predicated load in its own s_cbranch_execz block and the loads stop overlapping).
+    // All descriptor inputs are kernel arguments => provably wave-uniform (no waterfall loop).
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x), 0, (int)((size_t)N * H * W * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(w), 0, KS * KS * Cin * Cout * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        y, 0, (int)((size_t)N * H * W * Cout * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;   // tensors are < 2 GiB (checked on the host)
+
+    // per-thread, tile-independent part of the halo addresses
+    int xrel[C::XSLOTS], xpy[C::XSLOTS], xpx[C::XSLOTS];
+#pragma unroll
+    for (int sl = 0; sl < C::XSLOTS; ++sl) {
+        const int idx = tid + sl * 256;
+        const int pix = idx / C::QPP, q = idx % C::QPP;
+        xpy[sl] = pix / C::HALO_W;
+        xpx[sl] = pix % C::HALO_W;
+        xrel[sl] = idx < C::XITEMS ? ((xpy[sl] * W + xpx[sl]) * Cin + q * 4) * 4 : (int)OOB;
+    }
+    int wrel[C::WSLOTS];
+#pragma unroll
+    for (int sl = 0; sl < C::WSLOTS; ++sl) {
+        const int idx = tid + sl * 256;
+        const int r = idx / (BN / 4), q4 = idx % (BN / 4);
+        const int tap = r / KC, c = r % KC;
+        const int co = n0 + q4 * 4;
+        wrel[sl] = (idx < C::WITEMS && co < Cout) ? ((tap * Cin + c) * Cout + co) * 4 : (int)OOB;
+    }
+
     // ---- issue the global loads of one work item (tile, chunk) into registers -------------
     auto issue = [&](int tile, int cc, bool want_w) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW - PAD, y0 = ty * TH - PAD;
+        const int base = (((n * H + y0) * W + x0) * Cin + cc) * 4;     // may be "negative": wraps back
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
-            const int idx = tid + sl * 256;
-            const int pix = idx / C::QPP, q = idx % C::QPP;
-            const int py = pix / C::HALO_W, px = pix % C::HALO_W;
-            const int gy = y0 + py, gx = x0 + px;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < C::XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4 *>(x + ((size_t)(n * H + gy) * W + gx) * Cin + cc + q * 4);
-            xr[sl] = v;
+            const bool inb = (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
+                             xrel[sl] != (int)OOB;
+            const unsigned off = inb ? (unsigned)(base + xrel[sl]) : OOB;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+            xr[sl] = *reinterpret_cast<const float4 *>(&v);
         }
         if (want_w) {
+            const int wbase = cc * Cout * 4;
 #pragma unroll
             for (int sl = 0; sl < C::WSLOTS; ++sl) {
-                const int idx = tid + sl * 256;
-                const int r = idx / (BN / 4), q4 = idx % (BN / 4);
-                const int tap = r / KC, c = r % KC;
-                const int co = n0 + q4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < C::WITEMS && co < Cout)
-                    v = *reinterpret_cast<const float4 *>(w + ((size_t)(tap * Cin + cc + c)) * Cout + co);
-                wr[sl] = v;
+                const unsigned off = wrel[sl] != (int)OOB ? (unsigned)(wbase + wrel[sl]) : OOB;
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0);
+                wr[sl] = *reinterpret_cast<const float4 *>(&v);
             }
         }
     };
@@ -128,8 +154,47 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
         for (int r = 0; r < 4; ++r) b[r] = xb_lds[((r + ky) * C::HALO_W + kx) * C::PS + s * 4];
     };
 
+    // activation as two selects (no per-element scalar branches in the store tail):
+    //   v > 0 ? v : (relu ? +0 : v * slope),  slope = 1 (none) or 0.2 (leaky)
+    const float slope = act == SQ_ACT_LEAKY ? 0.2f : 1.0f;
+    const bool is_relu = act == SQ_ACT_RELU;
+    auto actf = [&](float v) {
+        const float neg = is_relu ? 0.0f : v * slope;
+        return v > 0.0f ? v : neg;
+    };
+
+    auto epilogue = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int gx = tx * TW + li;
+#pragma unroll
+        for (int nb = 0; nb < NR; ++nb) {
+            const int co = n0 + nb * 16 + 4 * kk;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias && co < Cout) bv = *reinterpret_cast<const float4 *>(bias + co);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gy = ty * TH + 4 * wv + r;
+                f32x4 o;
+                o[0] = actf(bias ? acc[r][nb][0] + bv.x : acc[r][nb][0]);
+                o[1] = actf(bias ? acc[r][nb][1] + bv.y : acc[r][nb][1]);
+                o[2] = actf(bias ? acc[r][nb][2] + bv.z : acc[r][nb][2]);
+                o[3] = actf(bias ? acc[r][nb][3] + bv.w : acc[r][nb][3]);
+                const bool ok = gy < H && gx < W && co < Cout;
+                const unsigned off = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 4) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    *reinterpret_cast<__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned *>(&o),
+                    yrsrc, off, 0, 0);
+                acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};      // ready for the next tile
+            }
+        }
+    };
+
     issue(t_begin, 0, true);
     commit(true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NR; ++nb) acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
     int tile = t_begin, chunk = 0;
@@ -140,64 +205,41 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
         const bool has_next = it + 1 < nitems;
         if (has_next) issue(ntile, nchk * KC, restage_w);
 
-        if (chunk == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int nb = 0; nb < NR; ++nb) acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        // ---- MFMA phase: NSTEP steps, fragments one step ahead --------------------------------
+        // ---- MFMA phase: NSTEP steps; the ds_reads of step s+1 are issued BEFORE the MFMAs
+        // of step s (sched_barrier fences stop hipcc sinking them back to just-in-time) ----------
         {
             float a0[NR], b0[4], a1[NR], b1[4];
             load_frag(0, a0, b0);
 #pragma unroll
             for (int st = 0; st < C::NSTEP; st += 2) {
                 if (st + 1 < C::NSTEP) load_frag(st + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int nb = 0; nb < NR; ++nb)
                         acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nb], b0[r], acc[r][nb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (st + 1 < C::NSTEP) {
                     if (st + 2 < C::NSTEP) load_frag(st + 2, a0, b0);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int nb = 0; nb < NR; ++nb)
                             acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[nb], b1[r], acc[r][nb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-        // ---- epilogue after the last chunk of a tile ---------------------------------------------
-        if (chunk == nchunk - 1) {
-            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-            const int gx = tx * TW + li;
-#pragma unroll
-            for (int nb = 0; nb < NR; ++nb) {
-                const int co = n0 + nb * 16 + 4 * kk;
-                if (co < Cout) {
-                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (bias) bv = *reinterpret_cast<const float4 *>(bias + co);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int gy = ty * TH + 4 * wv + r;
-                        if (gy < H && gx < W) {
-                            float4 o;
-                            o.x = sq_act(bias ? acc[r][nb][0] + bv.x : acc[r][nb][0], act);
-                            o.y = sq_act(bias ? acc[r][nb][1] + bv.y : acc[r][nb][1], act);
-                            o.z = sq_act(bias ? acc[r][nb][2] + bv.z : acc[r][nb][2], act);
-                            o.w = sq_act(bias ? acc[r][nb][3] + bv.w : acc[r][nb][3], act);
-                            *reinterpret_cast<float4 *>(y + ((size_t)(n * H + gy) * W + gx) * Cout + co) = o;
-                        }
-                    }
-                }
-            }
-        }
+        // ---- stage the next item, THEN store this tile: the stores drain under the next MFMA
+        // phase instead of being waited for together with the prefetch (vmcnt is in-order) -------
         if (has_next) {
             __syncthreads();            // every wave is done reading this item's LDS image
             commit(restage_w);
-            __syncthreads();
         }
+        if (chunk == nchunk - 1) epilogue(tile);
+        if (has_next) __syncthreads();
         tile = ntile;
         chunk = nchk;
     }
