@@ -1,0 +1,330 @@
+"""Image pipe chain -- host-side mirror of the reference's tile pre-processing contract.
+
+Same public surface as sequitr/pipeline.py: ``ImagePipeline(pipeline)`` with
+``__call__`` / ``__len__`` / ``update`` / ``save`` / ``load`` (pipeline.py:42-98), the JSON
+form ``{"ImagePipeline": {ClassName: {ctor kwargs}}}`` (pipeline.py:104-154), the
+``ImagePipe`` base that lifts 2-D input to (H,W,1) float32 (pipeline.py:162-189) and the
+concrete pipes.  ``ImagePipeline.process`` is an alias of ``__call__`` (the north star's
+"pipeline.process() entry point"; the reference has no such name).
+
+Written for Python 3 / numpy / scipy.  Results are pinned against arrays the reference
+itself produced (tests/golden/pipeline_golden.npz, tests/test_pipeline.py).
+``ImageResize`` / ``ImageRotate`` use scipy.ndimage because scikit-image is not
+installed; they are outside the hot path and are "parity unpinned".
+"""
+import inspect
+import json
+import sys
+from collections import OrderedDict
+
+import numpy as np
+from scipy import ndimage
+from scipy.spatial import Delaunay
+
+
+class ImagePipeline(object):
+    """Chain of ImagePipe objects applied in order (pipeline.py:42-98)."""
+
+    def __init__(self, pipeline=None):
+        self.__pipeline = []
+        self.pipeline = [] if pipeline is None else pipeline
+
+    @property
+    def pipeline(self):
+        return self.__pipeline
+
+    @pipeline.setter
+    def pipeline(self, pipeline):
+        if not isinstance(pipeline, list):
+            return                                             # the reference ignores non-lists
+        if pipeline and not any(isinstance(p, ImagePipe) for p in pipeline):
+            raise TypeError('Pipeline contains non pipe objects')
+        self.__pipeline = pipeline
+
+    def __call__(self, image):
+        for pipe in self.pipeline:
+            image = pipe(image)
+        return image
+
+    process = __call__
+
+    def __len__(self):
+        n = 1
+        for pipe in self.pipeline:
+            n *= len(pipe)
+        return n
+
+    def update(self):
+        for pipe in self.pipeline:
+            pipe.update()
+
+    def save(self, filename):
+        save_image_pipeline(filename, self)
+
+    @staticmethod
+    def load(filename):
+        return load_image_pipeline(filename)
+
+
+def _ctor_args(pipe):
+    return [a for a in inspect.getfullargspec(pipe.__init__)[0] if a != 'self']
+
+
+def save_image_pipeline(filename, pipeline_object):
+    """JSON layout of pipeline.py:104-133: ordered {class name: {ctor arg: value}}."""
+    if not isinstance(pipeline_object, ImagePipeline):
+        raise TypeError('Pipeline must be of type ImagePipeline')
+    if not filename.endswith('.json'):
+        filename += '.json'
+    pipes = OrderedDict()
+    for pipe in pipeline_object.pipeline:
+        pipes[pipe.__class__.__name__] = {a: getattr(pipe, a) for a in _ctor_args(pipe)}
+    with open(filename, 'w') as f:
+        json.dump({'ImagePipeline': pipes}, f, indent=2, separators=(',', ': '))
+
+
+def load_image_pipeline(filename):
+    """Inverse of save (pipeline.py:137-154): class looked up by name in this module."""
+    with open(filename, 'r') as f:
+        spec = json.load(f, object_pairs_hook=OrderedDict)
+    me = sys.modules[__name__]
+    pipes = []
+    for name, kwargs in spec['ImagePipeline'].items():
+        cls = getattr(me, name, None)
+        if cls is None or not (isinstance(cls, type) and issubclass(cls, ImagePipe)):
+            raise ValueError('Unknown image pipe: {0}'.format(name))
+        kwargs = {k: (tuple(v) if isinstance(v, list) else v) for k, v in kwargs.items()}
+        pipes.append(cls(**kwargs))
+    return ImagePipeline(pipes)
+
+
+class ImagePipe(object):
+    """Base pipe (pipeline.py:162-189)."""
+
+    def __init__(self):
+        self.iter = 0
+
+    def __call__(self, image):
+        if image.ndim < 3:
+            image = image[..., np.newaxis].astype('float32')
+        return self.pipe(image)
+
+    def pipe(self, image):
+        raise NotImplementedError('Image pipe is not defined.')
+
+    def __len__(self):
+        return 1
+
+    def update(self):
+        self.iter = (self.iter + 1) % len(self)
+
+
+def _rescale01(image):
+    lo, hi = np.min(image), np.max(image)
+    return (image - lo) / (hi - lo), lo, hi
+
+
+class ImageResize(ImagePipe):
+    """pipeline.py:195-221.  scipy.ndimage.zoom stands in for skimage.transform.resize."""
+
+    def __init__(self, size=(1024, 1024), order=0):
+        ImagePipe.__init__(self)
+        self.size = size
+        self.order = order
+
+    def pipe(self, image):
+        unit, lo, hi = _rescale01(image)
+        factors = [float(self.size[0]) / unit.shape[0], float(self.size[1]) / unit.shape[1]]
+        factors += [1.0] * (unit.ndim - 2)
+        unit = ndimage.zoom(unit, factors, order=self.order, mode='reflect')
+        return unit * (hi - lo) + lo
+
+
+class ImageFlip(ImagePipe):
+    """The four mirror states in sequence (pipeline.py:226-241)."""
+
+    def __init__(self):
+        ImagePipe.__init__(self)
+        self.flips = [[], [np.fliplr], [np.flipud], [np.fliplr, np.flipud]]
+
+    def pipe(self, image):
+        for f in self.flips[self.iter]:
+            image = f(image)
+        return image
+
+    def __len__(self):
+        return len(self.flips)
+
+
+class ImageBlur(ImagePipe):
+    """Per-channel 2-D Gaussian (pipeline.py:244-263); multiplicity 1 (the reference's
+    ``__len__`` reads a non-existent attribute, SURVEY A.5 -- surface kept, defect not)."""
+
+    def __init__(self, sigma=0.5):
+        ImagePipe.__init__(self)
+        self.sigma = sigma
+
+    def pipe(self, image):
+        for c in range(image.shape[-1]):
+            image[..., c] = ndimage.gaussian_filter(image[..., c], self.sigma)
+        return image
+
+
+class ImageOutliers(ImagePipe):
+    """Hot-pixel removal against a median filter (pipeline.py:266-295)."""
+
+    def __init__(self, sigma=2, threshold=5.):
+        ImagePipe.__init__(self)
+        self.sigma = sigma
+        self.threshold = threshold
+
+    def pipe(self, image):
+        for c in range(image.shape[-1]):
+            plane = image[..., c].copy()
+            med = ndimage.median_filter(plane, self.sigma)
+            hot = np.abs(image[..., c] - med) > self.threshold
+            plane[hot] = med[hot]
+            image[..., c] = plane
+        return image
+
+
+class ImageRotate(ImagePipe):
+    """pipeline.py:298-333.  scipy.ndimage.rotate stands in for skimage.transform.rotate."""
+
+    def __init__(self, rotations=16, order=0, max_theta=360):
+        ImagePipe.__init__(self)
+        self.rotations = rotations
+        self.max_theta = max_theta
+        self.order = order
+        self.iter = 0
+
+    @property
+    def theta(self):
+        return (-self.max_theta / 2.) + self.max_theta * (float(self.iter) / float(self.rotations))
+
+    def pipe(self, image):
+        unit, lo, hi = _rescale01(image)
+        unit = ndimage.rotate(unit, self.theta, axes=(1, 0), reshape=False, order=self.order, mode='reflect')
+        return unit * (hi - lo) + lo
+
+    def __len__(self):
+        return self.rotations
+
+
+class ImageNorm(ImagePipe):
+    """Per-channel (x - mean) / (1e-99 + std), in place (pipeline.py:338-356).  This is the
+    tile normalisation contract of the network input."""
+
+    def __init__(self):
+        ImagePipe.__init__(self)
+        self.epsilon = 1e-99
+
+    def pipe(self, image):
+        for c in range(image.shape[-1]):
+            plane = image[..., c]
+            image[..., c] = (plane - np.mean(plane)) / (self.epsilon + np.std(plane))
+        return image
+
+
+class ImageBGSubtract(ImagePipe):
+    """Second-order polynomial background, least squares over all pixels (pipeline.py:360-405)."""
+
+    def __init__(self):
+        ImagePipe.__init__(self)
+
+    def pipe(self, image):
+        rows, cols = image.shape[0], image.shape[1]
+        u, v = np.meshgrid(np.arange(0, cols), np.arange(0, rows))
+        uf, vf = u.reshape(-1).astype(np.float64), v.reshape(-1).astype(np.float64)
+        A = np.stack([np.ones_like(uf), uf, vf, uf ** 2, uf * vf, vf ** 2], axis=1)
+        k = np.linalg.inv(A.T.dot(A)).dot(A.T).dot(np.ravel(image))
+        bg = k[0] + k[1] * u + k[2] * v + k[3] * (u ** 2) + k[4] * u * v + k[5] * (v ** 2)
+        return image - bg[..., np.newaxis]
+
+
+class ImageSample(ImagePipe):
+    """Random square ROIs with remembered positions (pipeline.py:408-451)."""
+
+    def __init__(self, samples=16, ROI_size=(512, 512)):
+        ImagePipe.__init__(self)
+        self.samples = samples
+        self.ROI_size = ROI_size
+        self.im_size = None
+        self.boundary = int(ROI_size[0] / 2.)
+        self.coords = None
+
+    def pipe(self, image):
+        out = np.zeros((self.samples, self.ROI_size[0], self.ROI_size[1], image.shape[-1]))
+        self.im_size = image.shape
+        if not self.coords:
+            self.update()
+        b = self.boundary
+        for i, (x, y) in enumerate(self.coords):
+            out[i, ...] = image[x - b:x + b, y - b:y + b, ...]
+        return out
+
+    def update(self):
+        b = self.boundary
+        x = np.random.randint(b, high=self.im_size[0] - b, size=(self.samples,))
+        y = np.random.randint(b, high=self.im_size[1] - b, size=(self.samples,))
+        self.coords = list(zip(x, y))
+
+    def __len__(self):
+        return self.samples
+
+
+class ImageWeightMap(ImagePipe):
+    """EDT weight map (pipeline.py:455-479): with d = EDT(1 - img),
+    w0 * (1 - img) * exp(-d^2 / (2 sigma^2 + 1e-99)) + img + 1; float64 out."""
+
+    def __init__(self, w0=10., sigma=5.):
+        ImagePipe.__init__(self)
+        self.w0 = w0
+        self.sigma = sigma
+
+    def pipe(self, image):
+        bg = 1. - image
+        d = ndimage.distance_transform_edt(bg)
+        return self.w0 * bg * np.exp(-(d * d) / (2. * self.sigma ** 2 + 1e-99)) + image + 1.
+
+
+class ImageWeightMap2(ImagePipe):
+    """Delaunay "narrowness" weight map (pipeline.py:482-566), restated literally:
+    boundary points = erosion outline XOR outline of the 3x-dilated mask (von Neumann SE);
+    every background pixel takes the LONGEST edge of the Delaunay simplex it falls in
+    (1024 outside the hull); Gaussian sigma fixed at 1; then the same exponential form."""
+
+    OUTSIDE = 1024.
+
+    def __init__(self, w0=10., sigma=5.):
+        ImagePipe.__init__(self)
+        self.w0 = w0
+        self.sigma = sigma
+
+    def pipe(self, image):
+        cross = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+        b = np.squeeze(image.astype('bool'))
+
+        def outline(m):
+            return np.logical_xor(ndimage.binary_erosion(m, iterations=1, structure=cross), m)
+
+        grown = ndimage.binary_dilation(b, iterations=3, structure=cross)
+        pts_mask = np.logical_xor(outline(b), outline(grown))
+        px, py = np.where(pts_mask)
+        tri = Delaunay(np.column_stack((px, py)))
+        self.tri = tri
+
+        fx, fy = np.where(np.logical_not(b))
+        simplex = tri.find_simplex(np.column_stack((fx, fy)))
+        # longest edge of every simplex, vectorised (the reference loops per pixel, pipeline.py:545)
+        verts = tri.points[tri.simplices]                              # (S,3,2)
+        edges = verts - np.roll(verts, -1, axis=1)
+        longest = np.sqrt((edges ** 2).sum(-1)).max(-1)
+        vals = np.where(simplex >= 0, longest[np.maximum(simplex, 0)], self.OUTSIDE)
+
+        wm = np.zeros(image.shape)
+        wm[fx, fy, ...] = vals.reshape((-1, 1))
+        mask = b[..., np.newaxis].astype('float32')
+        wm = ndimage.gaussian_filter(wm, 1.)
+        wm = self.w0 * (1. - mask) * np.exp(-(wm * wm) / (2. * self.sigma ** 2 + 1e-99))
+        return wm + 1. + mask

@@ -1,0 +1,54 @@
+"""GPU: BASELINE config 1 plumbing on the real back end -- a .job file through worker() to
+jobs.SERVER_segment, outputs checked bit-for-bit against the oracle."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import unet_oracle
+from sequitr_amd import worker
+from sequitr_amd.networks.unet import init_unet_weights
+from tests.test_jobs_config import write_job
+from tests.util import assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+
+def test_segment_job_end_to_end(tmp_path):
+    x = np.random.default_rng(0).standard_normal((3, 64, 64, 1)).astype(np.float32)
+    np.save(str(tmp_path / "tiles.npy"), x)
+    params = {"input": str(tmp_path / "tiles.npy"), "shape": (64, 64), "num_outputs": 2, "seed": 0, "batch": 2}
+    fn = write_job(tmp_path, func="SERVER_segment", params=repr(params), options="{'gpu': 0, 'save_logits': True}")
+    out = str(tmp_path / "out")
+    worker.worker(argparse.Namespace(job=fn, out=out))
+    logs = open(os.path.join(out, [f for f in os.listdir(out) if f.startswith("LOG_")][0])).read()
+    assert "exception" not in logs, logs
+    mask, logits = np.load(os.path.join(out, "mask.npy")), np.load(os.path.join(out, "logits.npy"))
+    ref = unet_oracle.unet_forward(x, init_unet_weights({"shape": (64, 64)}, 0), {"shape": (64, 64)})
+    assert_bit_exact(logits, ref, "job logits")
+    assert_bit_exact(mask, unet_oracle.predict_mask(ref), "job mask")
+    info = json.load(open(os.path.join(out, "segment.json")))
+    assert info["tiles"] == 3 and info["device"] == "cuda:0"
+
+
+def test_segment_job_with_pipeline_and_saved_model(tmp_path, monkeypatch):
+    from sequitr_amd import core, utils
+    from sequitr_amd.pipeline import ImagePipeline, ImageNorm
+    monkeypatch.setattr(core.TensorflowConfiguration, "MODELDIR", str(tmp_path / "models"))
+    os.mkdir(str(tmp_path / "models"))
+    w = init_unet_weights({"shape": (32, 32)}, seed=9)
+    cfg = utils.NetConfiguration.from_params({"shape": (32, 32)})
+    utils.save_model(w, cfg)
+    ImagePipeline([ImageNorm()]).save(str(tmp_path / "pipe.json"))
+    raw = (np.random.default_rng(1).random((2, 32, 32)) * 4000).astype(np.float32)     # camera counts
+    np.save(str(tmp_path / "raw.npy"), raw)
+    params = {"input": str(tmp_path / "raw.npy"), "shape": (32, 32), "model": "UNet2D_test",
+              "pipeline": str(tmp_path / "pipe.json")}
+    fn = write_job(tmp_path, func="SERVER_segment", params=repr(params), options="{'save_logits': True}")
+    out = str(tmp_path / "out")
+    worker.worker(argparse.Namespace(job=fn, out=out))
+    normed = np.stack([ImageNorm()(t.copy()) for t in raw]).astype(np.float32)
+    ref = unet_oracle.unet_forward(normed, w, {"shape": (32, 32)})
+    assert_bit_exact(np.load(os.path.join(out, "logits.npy")), ref, "job logits (pipeline + saved model)")
