@@ -121,6 +121,58 @@ int sq_wsoftmax_ce_fwd_bwd_f32(const float *logits, const uint8_t *onehot, const
                                int64_t npix, int C, float grad_scale, double *partials,
                                double *loss, float *dlogits, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training side.  The reference trains through TensorFlow's automatic differentiation of the
+ * same graph (sequitr/networks/gan.py:721,740-751; the U-Net model_fn is absent);
+ * these entry points are the hand-written gradients of the forward operators above.
+ * Gradient reductions use fixed-order two-stage sums (no float atomics): reproducible.
+ * ---------------------------------------------------------------------------------------- */
+
+/* dgrad filter: wt[ky][kx][co][ci] = w[K-1-ky][K-1-kx][ci][co]; then
+ * dX = sq_conv2d_nhwc_fwd_f32(dY, wt, NULL, ..., Cin := Cout, Cout := Cin, act NONE). */
+int sq_conv_weight_transform_f32(const float *w, float *wt, int K, int Cin, int Cout, void *stream);
+
+/* dW (K,K,Cin,Cout) and db (Cout, may be NULL) of the KxK SAME convolution from X (N,H,W,Cin)
+ * and dY (N,H,W,Cout).  Cin in {1 (K=3 only), 8} or Cin % 16 == 0; Cout % 4 == 0.
+ * workspace: sq_conv2d_nhwc_wgrad_workspace_f32(...) bytes (returns -1 for unsupported shapes). */
+int64_t sq_conv2d_nhwc_wgrad_workspace_f32(int N, int H, int W, int Cin, int Cout, int K);
+int sq_conv2d_nhwc_wgrad_f32(const float *x, const float *dy, float *dw, float *db, float *workspace,
+                             int N, int H, int W, int Cin, int Cout, int K, void *stream);
+
+/* d(pre-activation) = dY * act'(.), decided from the activation OUTPUT y (y > 0 <=> pre > 0). */
+int sq_act_bwd_f32(const float *dy, const float *y, float *dx, int64_t n, int act, void *stream);
+
+/* max-pool backward: gradient to the first maximum in raster order; x (N,H,W,C) is the pool input. */
+int sq_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int N, int H, int W, int C, void *stream);
+
+/* dst (N,H,W,C) = scale * src (N,H/2,W/2,C) broadcast over 2x2: avg-pool backward (scale 0.25)
+ * and double_size forward (scale 1).  sq_sumpool2x2: y = sum of each 2x2 patch (double_size backward). */
+int sq_broadcast2x2_f32(const float *src, float *dst, int N, int H, int W, int C, float scale, void *stream);
+int sq_sumpool2x2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
+
+/* bridge backward: (da, db) from dY and the forward operands a (up-scaled) and b (skip). */
+int sq_bridge_bwd_f32(const float *dy, const float *a, const float *b, float *da, float *db, int64_t n,
+                      int bridge, void *stream);
+
+/* g[n,i,j,(2a+b)*C+c] = dy[n,2i+a,2j+b,c]: makes the 2x2/s2 transpose-conv backward two 1x1 convs. */
+int sq_space_to_depth2_f32(const float *dy, float *g, int N, int H, int W, int C, void *stream);
+
+/* to_image head backward (1x1 conv, Cin in {8,16,32}, Cout <= 4): dx (may be NULL), dw (Cin,Cout), db. */
+int64_t sq_conv1x1_small_bwd_workspace_f32(int64_t npix, int Cin, int Cout);
+int sq_conv1x1_small_bwd_f32(const float *x, const float *w, const float *dz, float *dx, float *dw, float *db,
+                             float *workspace, int64_t npix, int Cin, int Cout, void *stream);
+
+/* tf.layers.dropout (sequitr/networks/unet.py:274-276): y = x * keep / (1 - rate).  mask (u8, n) is
+ * written from a counter-based hash of (seed, index), or read when mask_given != 0. */
+int sq_dropout_fwd_f32(const float *x, float *y, uint8_t *mask, int64_t n, float rate, uint32_t seed,
+                       int mask_given, void *stream);
+int sq_dropout_bwd_f32(const float *dy, const uint8_t *mask, float *dx, int64_t n, float rate, void *stream);
+
+/* tf.train.AdamOptimizer update over a flat parameter buffer (sequitr/networks/gan.py:736-751):
+ * g is first multiplied by grad_scale (1/world for data-parallel averaging); step counts from 1. */
+int sq_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
+                     float beta2, float eps, int step, float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

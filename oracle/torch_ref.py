@@ -135,3 +135,42 @@ def wsoftmax_ce(logits, onehot, weights):
     loss = (w * ce).sum() / w.numel()
     loss.backward()
     return float(loss.detach()), z.grad.numpy()
+
+
+def unet_loss_and_grads(x_nhwc, onehot, wmap, weights, params=None, dropout_masks=None, dtype=torch.float64):
+    """fp64 autograd reference of one training forward/backward (tests/test_gpu_train.py):
+    returns (loss, {variable name: gradient ndarray}, logits).  Dropout uses the SUPPLIED masks
+    (list of NHWC uint8 arrays in call order) and rate params['dropout']."""
+    params = params or {}
+    filters = tuple(params.get("filters", (16, 32, 64, 128, 256)))
+    bridge = params.get("bridge", "eltwise_mul")
+    rate = float(params.get("dropout", 0.0)) if dropout_masks is not None else 0.0
+    masks = list(dropout_masks) if dropout_masks is not None else None
+    W = {k: torch.as_tensor(np.asarray(v)).to(dtype).requires_grad_(True) for k, v in weights.items()}
+    x = to_nchw(x_nhwc, dtype)
+
+    def conv(t, w_hwio, b, act):
+        y = F.conv2d(t, w_hwio.permute(3, 2, 0, 1), b, padding=w_hwio.shape[0] // 2)
+        return F.relu(y) if act else y
+
+    def block(t, s):
+        for k in ("conv1", "conv2"):
+            t = conv(t, W[s + "/" + k + "/kernel"], W[s + "/" + k + "/bias"], True)
+        if masks is not None and rate > 0:
+            m = torch.as_tensor(np.asarray(masks.pop(0))).to(dtype).permute(0, 3, 1, 2)
+            t = t * m / (1.0 - rate)
+        return t
+
+    net = [block(x, "UNet/down0")]
+    for i in range(1, len(filters)):
+        net.append(block(F.max_pool2d(net[-1], 2, 2), "UNet/down%d" % i))
+    for i in reversed(range(len(filters) - 1)):
+        s = "UNet/up%d" % i
+        up = F.conv_transpose2d(net[-1], W[s + "/upscale/kernel"].permute(3, 2, 0, 1), W[s + "/upscale/bias"], stride=2)
+        net.append(block(bridge_op(up, net[i], bridge), s))
+    logits = conv(net[-1], W["UNet/to_image/kernel"], W["UNet/to_image/bias"], False).permute(0, 2, 3, 1)
+    y = torch.as_tensor(np.asarray(onehot)).to(dtype)
+    wm = torch.as_tensor(np.asarray(wmap)).to(dtype).reshape(logits.shape[:-1])
+    loss = (wm * -(y * F.log_softmax(logits, -1)).sum(-1)).sum() / wm.numel()
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in W.items()}, logits.detach().numpy()

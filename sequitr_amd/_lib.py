@@ -27,6 +27,20 @@ SIGNATURES = {
     "sq_upsample_nn2x_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "sq_wsoftmax_ce_partials": (c_int64, [c_int64]),
     "sq_wsoftmax_ce_fwd_bwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_float] + [c_void_p] * 4),
+    "sq_conv_weight_transform_f32": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
+    "sq_conv2d_nhwc_wgrad_workspace_f32": (c_int64, [c_int] * 6),
+    "sq_conv2d_nhwc_wgrad_f32": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "sq_act_bwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
+    "sq_maxpool2x2_bwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "sq_broadcast2x2_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_float, c_void_p]),
+    "sq_sumpool2x2_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "sq_bridge_bwd_f32": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_void_p]),
+    "sq_space_to_depth2_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "sq_conv1x1_small_bwd_workspace_f32": (c_int64, [c_int64, c_int, c_int]),
+    "sq_conv1x1_small_bwd_f32": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]),
+    "sq_dropout_fwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_float, ctypes.c_uint32, c_int, c_void_p]),
+    "sq_dropout_bwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_float, c_void_p]),
+    "sq_adam_step_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 4 + [c_int, c_float, c_void_p]),
 }
 
 _lib = None

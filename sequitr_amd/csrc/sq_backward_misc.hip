@@ -1,0 +1,398 @@
+// Backward / training-side HBM-bound kernels of the sequitr hot path (gfx950): activation and
+// pooling gradients, bridge gradients, the space-to-depth view that turns the 2x2/s2
+// transpose-conv backward into 1x1 convolutions, the filter transform for dgrad, the to_image
+// head backward, dropout, and the Adam update over the flat parameter buffer.
+#include "sq_common.h"
+
+namespace {
+
+inline unsigned grid_for(int64_t items) {
+    int64_t b = (items + 255) / 256;
+    if (b > 2048) b = 2048;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+#define SQ_GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n); i += (int64_t)gridDim.x * 256)
+
+// dgrad filter: wt[ky][kx][co][ci] = w[K-1-ky][K-1-kx][ci][co]  (HWIO with the roles of I and O swapped)
+__global__ __launch_bounds__(256) void weight_transform_kernel(const float *__restrict__ w, float *__restrict__ wt,
+                                                                int K, int Cin, int Cout) {
+    const int total = K * K * Cin * Cout;
+    SQ_GRID_STRIDE(i, total) {
+        const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), tap = (int)(i / ((int64_t)Cin * Cout));
+        const int ky = tap / K, kx = tap % K;
+        wt[i] = w[(((K - 1 - ky) * K + (K - 1 - kx)) * Cin + ci) * Cout + co];
+    }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ y,
+                                                       float4 *__restrict__ dx, int64_t n4, int act) {
+    const float slope = act == SQ_ACT_LEAKY ? 0.2f : (act == SQ_ACT_RELU ? 0.0f : 1.0f);
+    SQ_GRID_STRIDE(i, n4) {
+        const float4 g = dy[i], v = y[i];
+        dx[i] = make_float4(v.x > 0.f ? g.x : g.x * slope, v.y > 0.f ? g.y : g.y * slope,
+                            v.z > 0.f ? g.z : g.z * slope, v.w > 0.f ? g.w : g.w * slope);
+    }
+}
+
+// max-pool backward: the gradient goes to the FIRST maximum in raster order (TF MaxPoolGrad)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4 *__restrict__ x, const float4 *__restrict__ dy,
+                                                           float4 *__restrict__ dx, int N, int H, int W, int C4) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int64_t total = (int64_t)N * Ho * Wo * C4;
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        int64_t t = i / C4;
+        const int xo = (int)(t % Wo);
+        t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int64_t b00 = (((int64_t)n * H + 2 * yo) * W + 2 * xo) * C4 + c;
+        const int64_t b01 = b00 + C4, b10 = b00 + (int64_t)W * C4, b11 = b10 + C4;
+        const float4 a = x[b00], b = x[b01], d = x[b10], e = x[b11], g = dy[i];
+        float4 ra, rb, rd, re;
+#define SQ_POOL_BWD(f)                                                     \
+        {                                                                  \
+            float m = a.f; int k = 0;                                      \
+            if (b.f > m) { m = b.f; k = 1; }                               \
+            if (d.f > m) { m = d.f; k = 2; }                               \
+            if (e.f > m) { m = e.f; k = 3; }                               \
+            ra.f = k == 0 ? g.f : 0.f; rb.f = k == 1 ? g.f : 0.f;          \
+            rd.f = k == 2 ? g.f : 0.f; re.f = k == 3 ? g.f : 0.f;          \
+        }
+        SQ_POOL_BWD(x) SQ_POOL_BWD(y) SQ_POOL_BWD(z) SQ_POOL_BWD(w)
+#undef SQ_POOL_BWD
+        dx[b00] = ra; dx[b01] = rb; dx[b10] = rd; dx[b11] = re;
+    }
+}
+
+// avg-pool backward (scale 0.25) and nearest-2x up-sampling forward share the broadcast; the
+// up-sampling backward (sum of the 2x2 patch) is avg-pool forward x 4 -> `scale` parameter.
+__global__ __launch_bounds__(256) void broadcast2x2_kernel(const float4 *__restrict__ dy, float4 *__restrict__ dx,
+                                                            int N, int H, int W, int C4, float scale) {
+    const int64_t total = (int64_t)N * H * W * C4;           // H, W = the LARGE side
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        int64_t t = i / C4;
+        const int xx = (int)(t % W);
+        t /= W;
+        const int yy = (int)(t % H);
+        const int n = (int)(t / H);
+        float4 g = dy[(((int64_t)n * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * C4 + c];
+        g.x *= scale; g.y *= scale; g.z *= scale; g.w *= scale;
+        dx[i] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const float4 *__restrict__ x, float4 *__restrict__ y,
+                                                          int N, int H, int W, int C4) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int64_t total = (int64_t)N * Ho * Wo * C4;
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        int64_t t = i / C4;
+        const int xo = (int)(t % Wo);
+        t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int64_t b = (((int64_t)n * H + 2 * yo) * W + 2 * xo) * C4 + c;
+        const float4 a = x[b], bb = x[b + C4], d = x[b + (int64_t)W * C4], e = x[b + (int64_t)W * C4 + C4];
+        y[i] = make_float4((a.x + bb.x) + (d.x + e.x), (a.y + bb.y) + (d.y + e.y), (a.z + bb.z) + (d.z + e.z),
+                           (a.w + bb.w) + (d.w + e.w));
+    }
+}
+
+__global__ __launch_bounds__(256) void bridge_bwd_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ a,
+                                                          const float4 *__restrict__ b, float4 *__restrict__ da,
+                                                          float4 *__restrict__ db, int64_t n4, int op) {
+    SQ_GRID_STRIDE(i, n4) {
+        const float4 g = dy[i];
+        if (op == SQ_BRIDGE_MUL) {
+            const float4 u = a[i], v = b[i];
+            da[i] = make_float4(g.x * v.x, g.y * v.y, g.z * v.z, g.w * v.w);
+            db[i] = make_float4(g.x * u.x, g.y * u.y, g.z * u.z, g.w * u.w);
+        } else {
+            da[i] = g;
+            db[i] = op == SQ_BRIDGE_SUB ? make_float4(-g.x, -g.y, -g.z, -g.w) : g;
+        }
+    }
+}
+
+// g[n,i,j,(2a+b)*C + c] = dy[n,2i+a,2j+b,c]
+__global__ __launch_bounds__(256) void space_to_depth2_kernel(const float4 *__restrict__ dy, float4 *__restrict__ g,
+                                                               int N, int H, int W, int C4) {
+    const int64_t total = (int64_t)N * H * W * 4 * C4;       // H, W = the SMALL side
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        int64_t t = i / C4;
+        const int ab = (int)(t & 3);
+        t >>= 2;
+        const int j = (int)(t % W);
+        t /= W;
+        const int ii = (int)(t % H);
+        const int n = (int)(t / H);
+        g[i] = dy[(((int64_t)n * 2 * H + 2 * ii + (ab >> 1)) * (2 * W) + 2 * j + (ab & 1)) * C4 + c];
+    }
+}
+
+// to_image head backward (1x1, Cout <= 4, Cin in {8,16,32}): dx[p,c] = sum_o dz[p,o] w[c,o]; dW / db
+// as block partials [gridDim.x][CIN*COUT + COUT] (wave shuffle tree, then waves 0..3 in order),
+// finished in fixed block order by head_finish_kernel.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);  v += __shfl_xor(v, 2);  v += __shfl_xor(v, 1);
+    return v;
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                        const float *__restrict__ dz, float *__restrict__ dx,
+                                                        float *__restrict__ partials, int64_t npix) {
+    constexpr int NVAL = CIN * COUT + COUT;
+    __shared__ float red[4][NVAL];
+    float gw[CIN][COUT], gb[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) gb[o] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) gw[c][o] = 0.f;
+    // wave-uniform trip count so the shuffles below see full waves
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < npix; base += stride) {
+        const int64_t p = base + threadIdx.x;
+        if (p < npix) {
+            float g[COUT];
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) { g[o] = dz[p * COUT + o]; gb[o] += g[o]; }
+#pragma unroll
+            for (int c4 = 0; c4 < CIN / 4; ++c4) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + p * CIN + c4 * 4);
+                const float xv[4] = {v.x, v.y, v.z, v.w};
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int o = 0; o < COUT; ++o) {
+                        s = __builtin_fmaf(g[o], w[(c4 * 4 + j) * COUT + o], s);
+                        gw[c4 * 4 + j][o] = __builtin_fmaf(xv[j], g[o], gw[c4 * 4 + j][o]);
+                    }
+                    r[j] = s;
+                }
+                if (dx) *reinterpret_cast<float4 *>(dx + p * CIN + c4 * 4) = make_float4(r[0], r[1], r[2], r[3]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            const float v = wave_sum(gw[c][o]);
+            if (lane == 0) red[wv][c * COUT + o] = v;
+        }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+        const float v = wave_sum(gb[o]);
+        if (lane == 0) red[wv][CIN * COUT + o] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NVAL)
+        partials[(size_t)blockIdx.x * NVAL + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void head_finish_kernel(const float *__restrict__ partials, float *__restrict__ dw,
+                                                           float *__restrict__ db, int nblk, int nw, int nb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nw + nb) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * (nw + nb) + i];
+    if (i < nw) dw[i] = s;
+    else if (db) db[i - nw] = s;
+}
+
+// counter-based dropout mask: keep iff hash(seed, element index) >= rate * 2^32
+__device__ __forceinline__ unsigned hash32(unsigned a, unsigned b) {
+    unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    h += b * 0x27D4EB2Fu; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                           uint8_t *__restrict__ mask, int64_t n, float rate,
+                                                           unsigned seed, int mask_given) {
+    const unsigned thr = (unsigned)(rate * 4294967296.0);
+    const float inv = 1.0f / (1.0f - rate);
+    SQ_GRID_STRIDE(i, n) {
+        uint8_t keep;
+        if (mask_given) keep = mask[i];
+        else { keep = hash32(seed, (unsigned)i) >= thr ? 1 : 0; mask[i] = keep; }
+        y[i] = keep ? x[i] * inv : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ mask,
+                                                           float *__restrict__ dx, int64_t n, float rate) {
+    const float inv = 1.0f / (1.0f - rate);
+    SQ_GRID_STRIDE(i, n) dx[i] = mask[i] ? dy[i] * inv : 0.f;
+}
+
+// Adam (tf.train.AdamOptimizer form): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps)
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                    float *__restrict__ m, float *__restrict__ v, int64_t n,
+                                                    float lr_t, float b1, float b2, float eps, float gscale) {
+    SQ_GRID_STRIDE(i, n) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - lr_t * mi / (__builtin_sqrtf(vi) + eps);
+    }
+}
+
+}  // namespace
+
+#define SQ_ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int sq_conv_weight_transform_f32(const float *w, float *wt, int K, int Cin, int Cout, void *stream) {
+    SQ_REQUIRE(w && wt && K > 0 && Cin > 0 && Cout > 0, "sq_conv_weight_transform_f32: bad arguments");
+    hipLaunchKernelGGL(weight_transform_kernel, dim3(grid_for((int64_t)K * K * Cin * Cout)), dim3(256), 0,
+                       SQ_ST(stream), w, wt, K, Cin, Cout);
+    return sq_check_launch("sq_conv_weight_transform_f32");
+}
+
+extern "C" int sq_act_bwd_f32(const float *dy, const float *y, float *dx, int64_t n, int act, void *stream) {
+    SQ_REQUIRE(dy && y && dx && n > 0 && n % 4 == 0, "sq_act_bwd_f32: bad arguments (n %% 4 == 0)");
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_act_bwd_f32: bad activation %d", act);
+    SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(y); SQ_REQUIRE_ALIGNED(dx);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(y),
+                       reinterpret_cast<float4 *>(dx), n / 4, act);
+    return sq_check_launch("sq_act_bwd_f32");
+}
+
+extern "C" int sq_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int N, int H, int W, int C,
+                                     void *stream) {
+    SQ_REQUIRE(x && dy && dx, "sq_maxpool2x2_bwd_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0,
+               "sq_maxpool2x2_bwd_f32: need even H,W and C %% 4 == 0");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(dx);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                       SQ_ST(stream), reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(dy),
+                       reinterpret_cast<float4 *>(dx), N, H, W, C / 4);
+    return sq_check_launch("sq_maxpool2x2_bwd_f32");
+}
+
+extern "C" int sq_broadcast2x2_f32(const float *src, float *dst, int N, int H, int W, int C, float scale,
+                                   void *stream) {
+    SQ_REQUIRE(src && dst, "sq_broadcast2x2_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0,
+               "sq_broadcast2x2_f32: need even H,W (large side) and C %% 4 == 0");
+    SQ_REQUIRE_ALIGNED(src); SQ_REQUIRE_ALIGNED(dst);
+    hipLaunchKernelGGL(broadcast2x2_kernel, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), N, H, W, C / 4, scale);
+    return sq_check_launch("sq_broadcast2x2_f32");
+}
+
+extern "C" int sq_sumpool2x2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream) {
+    SQ_REQUIRE(x && y, "sq_sumpool2x2_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0,
+               "sq_sumpool2x2_f32: need even H,W and C %% 4 == 0");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(y);
+    hipLaunchKernelGGL(sumpool2x2_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                       SQ_ST(stream), reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), N, H, W, C / 4);
+    return sq_check_launch("sq_sumpool2x2_f32");
+}
+
+extern "C" int sq_bridge_bwd_f32(const float *dy, const float *a, const float *b, float *da, float *db, int64_t n,
+                                 int bridge, void *stream) {
+    SQ_REQUIRE(dy && da && db && n > 0 && n % 4 == 0, "sq_bridge_bwd_f32: bad arguments (n %% 4 == 0)");
+    SQ_REQUIRE(bridge >= SQ_BRIDGE_ADD && bridge <= SQ_BRIDGE_SUB, "sq_bridge_bwd_f32: bad bridge %d", bridge);
+    SQ_REQUIRE(bridge != SQ_BRIDGE_MUL || (a && b), "sq_bridge_bwd_f32: eltwise_mul needs both forward operands");
+    SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(da); SQ_REQUIRE_ALIGNED(db);
+    hipLaunchKernelGGL(bridge_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(a),
+                       reinterpret_cast<const float4 *>(b), reinterpret_cast<float4 *>(da),
+                       reinterpret_cast<float4 *>(db), n / 4, bridge);
+    return sq_check_launch("sq_bridge_bwd_f32");
+}
+
+extern "C" int sq_space_to_depth2_f32(const float *dy, float *g, int N, int H, int W, int C, void *stream) {
+    SQ_REQUIRE(dy && g, "sq_space_to_depth2_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "sq_space_to_depth2_f32: C %% 4 == 0");
+    SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(g);
+    hipLaunchKernelGGL(space_to_depth2_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(g), N, H, W, C / 4);
+    return sq_check_launch("sq_space_to_depth2_f32");
+}
+
+static inline int head_blocks(int64_t npix) {
+    int64_t b = (npix + 255) / 256;
+    return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
+}
+
+extern "C" int64_t sq_conv1x1_small_bwd_workspace_f32(int64_t npix, int Cin, int Cout) {
+    if (npix <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    return (int64_t)head_blocks(npix) * (Cin * Cout + Cout) * 4;
+}
+
+template <int CIN>
+static int head_launch(int Cout, int nb, hipStream_t st, const float *x, const float *w, const float *dz, float *dx,
+                       float *ws, int64_t npix) {
+    switch (Cout) {
+    case 1: hipLaunchKernelGGL((head_bwd_kernel<CIN, 1>), dim3(nb), dim3(256), 0, st, x, w, dz, dx, ws, npix); return 0;
+    case 2: hipLaunchKernelGGL((head_bwd_kernel<CIN, 2>), dim3(nb), dim3(256), 0, st, x, w, dz, dx, ws, npix); return 0;
+    case 3: hipLaunchKernelGGL((head_bwd_kernel<CIN, 3>), dim3(nb), dim3(256), 0, st, x, w, dz, dx, ws, npix); return 0;
+    case 4: hipLaunchKernelGGL((head_bwd_kernel<CIN, 4>), dim3(nb), dim3(256), 0, st, x, w, dz, dx, ws, npix); return 0;
+    }
+    return -1;
+}
+
+extern "C" int sq_conv1x1_small_bwd_f32(const float *x, const float *w, const float *dz, float *dx, float *dw,
+                                        float *db, float *workspace, int64_t npix, int Cin, int Cout,
+                                        void *stream) {
+    SQ_REQUIRE(x && w && dz && dw && workspace, "sq_conv1x1_small_bwd_f32: null pointer");
+    SQ_REQUIRE(npix > 0 && (Cin == 8 || Cin == 16 || Cin == 32) && Cout >= 1 && Cout <= 4,
+               "sq_conv1x1_small_bwd_f32: Cin=%d (8|16|32), Cout=%d (1..4)", Cin, Cout);
+    SQ_REQUIRE_ALIGNED(x);
+    if (dx) SQ_REQUIRE_ALIGNED(dx);
+    const int nb = head_blocks(npix);
+    hipStream_t st = SQ_ST(stream);
+    if (Cin == 8) head_launch<8>(Cout, nb, st, x, w, dz, dx, workspace, npix);
+    else if (Cin == 16) head_launch<16>(Cout, nb, st, x, w, dz, dx, workspace, npix);
+    else head_launch<32>(Cout, nb, st, x, w, dz, dx, workspace, npix);
+    int rc = sq_check_launch("sq_conv1x1_small_bwd_f32");
+    if (rc) return rc;
+    const int nw = Cin * Cout;
+    hipLaunchKernelGGL(head_finish_kernel, dim3((nw + Cout + 255) / 256), dim3(256), 0, st, workspace, dw, db, nb, nw, Cout);
+    return sq_check_launch("sq_conv1x1_small_bwd_f32(finish)");
+}
+
+extern "C" int sq_dropout_fwd_f32(const float *x, float *y, uint8_t *mask, int64_t n, float rate, uint32_t seed,
+                                  int mask_given, void *stream) {
+    SQ_REQUIRE(x && y && mask && n > 0, "sq_dropout_fwd_f32: bad arguments");
+    SQ_REQUIRE(rate >= 0.f && rate < 1.f, "sq_dropout_fwd_f32: rate must be in [0,1)");
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), x, y, mask, n, rate, seed,
+                       mask_given);
+    return sq_check_launch("sq_dropout_fwd_f32");
+}
+
+extern "C" int sq_dropout_bwd_f32(const float *dy, const uint8_t *mask, float *dx, int64_t n, float rate, void *stream) {
+    SQ_REQUIRE(dy && mask && dx && n > 0, "sq_dropout_bwd_f32: bad arguments");
+    SQ_REQUIRE(rate >= 0.f && rate < 1.f, "sq_dropout_bwd_f32: rate must be in [0,1)");
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), dy, mask, dx, n, rate);
+    return sq_check_launch("sq_dropout_bwd_f32");
+}
+
+extern "C" int sq_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
+                                float beta2, float eps, int step, float grad_scale, void *stream) {
+    SQ_REQUIRE(p && g && m && v && n > 0 && step >= 1, "sq_adam_step_f32: bad arguments");
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), p, g, m, v, n, (float)lr_t, beta1,
+                       beta2, eps, grad_scale);
+    return sq_check_launch("sq_adam_step_f32");
+}

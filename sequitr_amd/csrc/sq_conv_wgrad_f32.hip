@@ -1,0 +1,423 @@
+// Weight gradient of the KxK SAME convolution (conv_layer / weighted_conv2d backward) on
+// v_mfma_f32_16x16x4_f32, gfx950.
+//
+//   dW[tap][ci][co] = sum over pixels p of  X[p + tap][ci] * dY[p][co]
+//   db[co]          = sum over pixels p of  dY[p][co]
+//
+// GEMM view per (16-channel ci chunk, BN-channel co chunk) pair: D[i = ci][j = co], reduction
+// over PIXELS (4 per MFMA: A[i][k] = X[pixel k][ci i], B[k][j] = dY[pixel k][co j]), one
+// accumulator block per tap.  Blocks are persistent over 16x16 pixel tiles and keep their
+// K*K*NR accumulator blocks in registers across all their tiles; the next tile's X halo and
+// dY tile are prefetched into registers during the MFMA phase (as in sq_conv_f32_v2.hip).
+// The reduction over the 4.2M pixels of a level-0 batch is split across blocks and finished
+// by a second kernel that adds the block partials IN A FIXED ORDER: no float atomics, results
+// are run-to-run reproducible (MI355X_MICROARCH.md "Global float atomics").
+#include "sq_common.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16;
+
+template <int BN, int KS, int KC>
+struct WCfg {
+    static constexpr int HALO_W = TW + KS - 1;
+    static constexpr int HP = HALO_W * (TH + KS - 1);
+    static constexpr int PSX = KC;                               // kk*KC + ci: conflict-free for KC = 16
+    static constexpr int PSY = (BN % 32 == 0) ? BN + 16 : BN;    // kk*PSY + co: conflict-free
+    static constexpr int XS_FLOATS = HP * PSX;
+    static constexpr int YS_FLOATS = TH * TW * PSY;
+    static constexpr int NTAP = KS * KS;
+    static constexpr int NR = BN / 16;
+    static constexpr int ROWS = NTAP * 16 + 1;                   // +1: the bias-gradient row
+    static constexpr int RED_FLOATS = ROWS * BN;                 // cross-wave reduction image
+    static constexpr int LDS_FLOATS = (XS_FLOATS + YS_FLOATS) > RED_FLOATS ? (XS_FLOATS + YS_FLOATS) : RED_FLOATS;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static constexpr int QPP = KC / 4;
+    static constexpr int XITEMS = HP * QPP;
+    static constexpr int XSLOTS = (XITEMS + 255) / 256;
+    static constexpr int YITEMS = TH * TW * (BN / 4);
+    static constexpr int YSLOTS = YITEMS / 256;
+    static_assert(YITEMS % 256 == 0, "dY tile must divide evenly over the block");
+    static_assert((XS_FLOATS * 4) % 16 == 0, "dY image must start 16-B aligned");
+};
+
+// partials layout: [gridDim.x][npairs][ROWS][BN]
+template <int BN, int KS, int KC>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ partials,
+    int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block) {
+    using C = WCfg<BN, KS, KC>;
+    constexpr int NR = C::NR, PAD = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *xs = smem;
+    float *ys = smem + C::XS_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int nco = (Cout + BN - 1) / BN;
+    const int ci0 = (blockIdx.y / nco) * KC, co0 = (blockIdx.y % nco) * BN;
+    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_end = min(t_begin + tiles_per_block, ntiles);
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x), 0, (int)((size_t)N * H * W * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(dy), 0, (int)((size_t)N * H * W * Cout * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    int xrel[C::XSLOTS], xpy[C::XSLOTS], xpx[C::XSLOTS];
+#pragma unroll
+    for (int sl = 0; sl < C::XSLOTS; ++sl) {
+        const int idx = tid + sl * 256;
+        const int pix = idx / C::QPP, q = idx % C::QPP;
+        xpy[sl] = pix / C::HALO_W;
+        xpx[sl] = pix % C::HALO_W;
+        xrel[sl] = idx < C::XITEMS ? ((xpy[sl] * W + xpx[sl]) * Cin + ci0 + q * 4) * 4 : (int)OOB;
+    }
+    int yrel[C::YSLOTS], ypy[C::YSLOTS], ypx[C::YSLOTS];
+#pragma unroll
+    for (int sl = 0; sl < C::YSLOTS; ++sl) {
+        const int idx = tid + sl * 256;
+        const int pix = idx / (BN / 4), q = idx % (BN / 4);
+        ypy[sl] = pix / TW;
+        ypx[sl] = pix % TW;
+        yrel[sl] = (co0 + q * 4 < Cout) ? ((ypy[sl] * W + ypx[sl]) * Cout + co0 + q * 4) * 4 : (int)OOB;
+    }
+
+    float4 xr[C::XSLOTS], yr[C::YSLOTS];
+    auto issue = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx * TW, y0 = ty * TH;
+        const int xbase = (((n * H + y0 - PAD) * W + x0 - PAD) * Cin) * 4;
+        const int ybase = (((n * H + y0) * W + x0) * Cout) * 4;
+#pragma unroll
+        for (int sl = 0; sl < C::XSLOTS; ++sl) {
+            const bool inb = (unsigned)(y0 - PAD + xpy[sl]) < (unsigned)H &&
+                             (unsigned)(x0 - PAD + xpx[sl]) < (unsigned)W && xrel[sl] != (int)OOB;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? (unsigned)(xbase + xrel[sl]) : OOB, 0, 0);
+            xr[sl] = *reinterpret_cast<const float4 *>(&v);
+        }
+#pragma unroll
+        for (int sl = 0; sl < C::YSLOTS; ++sl) {
+            const bool inb = (y0 + ypy[sl]) < H && (x0 + ypx[sl]) < W && yrel[sl] != (int)OOB;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, inb ? (unsigned)(ybase + yrel[sl]) : OOB, 0, 0);
+            yr[sl] = *reinterpret_cast<const float4 *>(&v);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int sl = 0; sl < C::XSLOTS; ++sl) {
+            const int idx = tid + sl * 256;
+            if (idx < C::XITEMS)
+                *reinterpret_cast<float4 *>(xs + (idx / C::QPP) * C::PSX + (idx % C::QPP) * 4) = xr[sl];
+        }
+#pragma unroll
+        for (int sl = 0; sl < C::YSLOTS; ++sl) {
+            const int idx = tid + sl * 256;
+            *reinterpret_cast<float4 *>(ys + (idx / (BN / 4)) * C::PSY + (idx % (BN / 4)) * 4) = yr[sl];
+        }
+    };
+
+    f32x4 acc[C::NTAP][NR];
+    float bsum[NR];
+#pragma unroll
+    for (int t = 0; t < C::NTAP; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NR; ++nb) acc[t][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < NR; ++nb) bsum[nb] = 0.f;
+
+    // A: X[pixel kk of the group][ci li]; B: dY[pixel kk][co li]
+    const float *xa_lds = xs + ((4 * wv) * C::HALO_W + kk) * C::PSX + li;
+    const float *yb_lds = ys + ((4 * wv) * TW + kk) * C::PSY + li;
+
+    auto load_frag = [&](int ks, float (&a)[C::NTAP], float (&b)[NR]) {
+        const int r = ks >> 2, g = ks & 3;                     // tile row within the wave, 4-pixel group
+#pragma unroll
+        for (int t = 0; t < C::NTAP; ++t)
+            a[t] = xa_lds[((r + t / KS) * C::HALO_W + 4 * g + t % KS) * C::PSX];
+#pragma unroll
+        for (int nb = 0; nb < NR; ++nb) b[nb] = yb_lds[(r * TW + 4 * g) * C::PSY + nb * 16];
+    };
+
+    if (t_begin < t_end) {
+        issue(t_begin);
+        commit();
+    }
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const bool has_next = tile + 1 < t_end;
+        if (has_next) issue(tile + 1);
+        {
+            float a0[C::NTAP], b0[NR], a1[C::NTAP], b1[NR];
+            load_frag(0, a0, b0);
+#pragma unroll
+            for (int ks = 0; ks < 16; ks += 2) {
+                load_frag(ks + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NR; ++nb) {
+                    bsum[nb] += b0[nb];
+#pragma unroll
+                    for (int t = 0; t < C::NTAP; ++t)
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b0[nb], acc[t][nb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 < 16) load_frag(ks + 2, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NR; ++nb) {
+                    bsum[nb] += b1[nb];
+#pragma unroll
+                    for (int t = 0; t < C::NTAP; ++t)
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b1[nb], acc[t][nb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        if (has_next) {
+            commit();
+            __syncthreads();
+        }
+    }
+
+    // ---- cross-wave reduction in a fixed order (wave 0, 1, 2, 3), then one partial per block ----
+    // D layout: lane holds rows (ci) 4*kk+{0..3}, column (co) li of every [tap][nb] block.
+    float *red = smem;
+#pragma unroll
+    for (int nb = 0; nb < NR; ++nb) {       // fold the 4 pixel slots (kk) of the bias sums
+        bsum[nb] += __shfl_xor(bsum[nb], 16);
+        bsum[nb] += __shfl_xor(bsum[nb], 32);
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int t = 0; t < C::NTAP; ++t)
+#pragma unroll
+                for (int nb = 0; nb < NR; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float *d = red + (t * 16 + 4 * kk + j) * BN + nb * 16 + li;
+                        *d = (w == 0) ? acc[t][nb][j] : *d + acc[t][nb][j];
+                    }
+            if (kk == 0) {
+#pragma unroll
+                for (int nb = 0; nb < NR; ++nb) {
+                    float *d = red + (C::NTAP * 16) * BN + nb * 16 + li;
+                    *d = (w == 0) ? bsum[nb] : *d + bsum[nb];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *out = partials + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * C::RED_FLOATS;
+    for (int i = tid; i < C::RED_FLOATS; i += 256) out[i] = red[i];
+}
+
+// second stage: dW[tap][ci][co] = sum_b partials[b][pair][tap*16 + ci%16][co%BN], b ascending
+template <int BN, int KS, int KC>
+__global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const float *__restrict__ partials,
+                                                                 float *__restrict__ dw, float *__restrict__ db,
+                                                                 int nblk, int Cin, int Cout) {
+    using C = WCfg<BN, KS, KC>;
+    const int nco = (Cout + BN - 1) / BN, npairs = (Cin / KC) * nco;
+    const int total = C::NTAP * Cin * Cout;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < total) {
+        const int co = i % Cout, ci = (i / Cout) % Cin, tap = i / (Cout * Cin);
+        const int pair = (ci / KC) * nco + co / BN;
+        const size_t off = (size_t)pair * C::RED_FLOATS + (tap * 16 + ci % KC) * BN + co % BN;
+        float s = 0.f;
+        for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * npairs * C::RED_FLOATS + off];
+        dw[i] = s;
+    } else if (db && i < total + Cout) {
+        const int co = i - total;
+        const int pair = co / BN;                              // ci chunk 0
+        const size_t off = (size_t)pair * C::RED_FLOATS + (C::NTAP * 16) * BN + co % BN;
+        float s = 0.f;
+        for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * npairs * C::RED_FLOATS + off];
+        db[co] = s;
+    }
+}
+
+template <int BN, int KS, int KC>
+int64_t ws_floats(int N, int H, int W, int Cin, int Cout, int *gx_out, int *tpb_out) {
+    using C = WCfg<BN, KS, KC>;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * N;
+    const int npairs = (Cin / KC) * ((Cout + BN - 1) / BN);
+    int want = (512 + npairs - 1) / npairs;                    // ~2 resident blocks per CU overall
+    if (want < 1) want = 1;
+    int tpb = (ntiles + want - 1) / want;
+    if (tpb < 1) tpb = 1;
+    const int gx = (ntiles + tpb - 1) / tpb;
+    if (gx_out) *gx_out = gx;
+    if (tpb_out) *tpb_out = tpb;
+    return (int64_t)gx * npairs * C::RED_FLOATS;
+}
+
+template <int BN, int KS, int KC>
+int launch(const float *x, const float *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin,
+           int Cout, hipStream_t st) {
+    using C = WCfg<BN, KS, KC>;
+    static bool attr_set = false;
+    auto kern = conv_wgrad_f32_kernel<BN, KS, KC>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess) {
+            sq_set_error("conv_wgrad_f32: cannot reserve %d bytes of LDS", C::LDS_BYTES);
+            return SQ_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    int gx, tpb;
+    ws_floats<BN, KS, KC>(N, H, W, Cin, Cout, &gx, &tpb);
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int npairs = (Cin / KC) * ((Cout + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3(gx, npairs), dim3(256), C::LDS_BYTES, st, x, dy, ws, N, H, W, Cin, Cout,
+                       tiles_x, tiles_y, tiles_x * tiles_y * N, tpb);
+    int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_f32");
+    if (rc) return rc;
+    const int total = KS * KS * Cin * Cout + (db ? Cout : 0);
+    hipLaunchKernelGGL((conv_wgrad_finish_kernel<BN, KS, KC>), dim3((total + 255) / 256), dim3(256), 0, st, ws, dw,
+                       db, gx, Cin, Cout);
+    return sq_check_launch("sq_conv2d_nhwc_wgrad_f32(finish)");
+}
+
+#define SQ_WGRAD_DISPATCH(FN, ...)                                                        \
+    do {                                                                                  \
+        if (Cin % 16 == 0) {                                                              \
+            if (K == 3) { if (Cout > 16) return FN<32, 3, 16>(__VA_ARGS__); return FN<16, 3, 16>(__VA_ARGS__); } \
+            if (Cout > 16) return FN<32, 1, 16>(__VA_ARGS__);                             \
+            return FN<16, 1, 16>(__VA_ARGS__);                                            \
+        }                                                                                 \
+        if (K == 3) { if (Cout > 16) return FN<32, 3, 8>(__VA_ARGS__); return FN<16, 3, 8>(__VA_ARGS__); } \
+        if (Cout > 16) return FN<32, 1, 8>(__VA_ARGS__);                                  \
+        return FN<16, 1, 8>(__VA_ARGS__);                                                 \
+    } while (0)
+
+int64_t ws_dispatch(int N, int H, int W, int Cin, int Cout, int K) {
+    SQ_WGRAD_DISPATCH(ws_floats, N, H, W, Cin, Cout, nullptr, nullptr);
+}
+int launch_dispatch(const float *x, const float *dy, float *dw, float *db, float *ws, int N, int H, int W,
+                    int Cin, int Cout, int K, hipStream_t st) {
+    SQ_WGRAD_DISPATCH(launch, x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
+}
+
+// ---- first layer (Cin == 1, 3x3): the 9 taps ride the 16 MFMA rows ---------------------------------
+//   A[i = tap][k = pixel] = X[pixel + tap] (rows 9..15 zero), B[k][j = co] = dY[pixel][co]
+// partials: [gridDim.x][10][Cout]  (9 taps + the bias row); blockIdx.y = 16-channel co group.
+__global__ __launch_bounds__(256) void conv_wgrad_cin1_f32_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ partials, int N, int H, int W,
+    int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block) {
+    constexpr int HW = TW + 2;
+    __shared__ float xs[HW * HW + 8];
+    __shared__ __attribute__((aligned(16))) float ys[TH * TW * 16];
+    __shared__ float red[4][10 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int co0 = blockIdx.y * 16;
+    const int t_begin = blockIdx.x * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
+    const int ky = li / 3, kx = li % 3;
+    const bool live_row = li < 9;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx * TW, y0 = ty * TH;
+        for (int idx = tid; idx < HW * HW; idx += 256) {
+            const int gy = y0 - 1 + idx / HW, gx = x0 - 1 + idx % HW;
+            xs[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)n * H + gy) * W + gx] : 0.f;
+        }
+        for (int idx = tid; idx < TH * TW * 4; idx += 256) {
+            const int pix = idx >> 2, q = idx & 3;
+            const int gy = y0 + pix / TW, gx = x0 + pix % TW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < H && gx < W && co0 + q * 4 < Cout)
+                v = *reinterpret_cast<const float4 *>(dy + (((size_t)n * H + gy) * W + gx) * Cout + co0 + q * 4);
+            *reinterpret_cast<float4 *>(ys + pix * 16 + q * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const int r = 4 * wv + (ks >> 2), g = ks & 3;
+            const float a = live_row ? xs[(r + ky) * HW + 4 * g + kk + kx] : 0.f;
+            const float b = ys[(r * TW + 4 * g + kk) * 16 + li];
+            bsum += b;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    // D: rows (taps) 4*kk + j, column (co) li
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * kk + j < 9) red[wv][(4 * kk + j) * 16 + li] = acc[j];
+    if (kk == 0) red[wv][9 * 16 + li] = bsum;
+    __syncthreads();
+    if (tid < 160) {
+        const int row = tid / 16, c = tid % 16;
+        if (co0 + c < Cout)
+            partials[((size_t)blockIdx.x * 10 + row) * Cout + co0 + c] =
+                ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_cin1_finish_kernel(const float *__restrict__ partials,
+                                                                      float *__restrict__ dw, float *__restrict__ db,
+                                                                      int nblk, int Cout) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 10 * Cout) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * 10 * Cout + i];
+    if (i < 9 * Cout) dw[i] = s;
+    else if (db) db[i - 9 * Cout] = s;
+}
+
+int cin1_grid(int N, int H, int W, int *tpb_out) {
+    const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * N;
+    int tpb = (ntiles + 1023) / 1024;
+    if (tpb < 1) tpb = 1;
+    if (tpb_out) *tpb_out = tpb;
+    return (ntiles + tpb - 1) / tpb;
+}
+
+bool shape_ok(int N, int H, int W, int Cin, int Cout, int K) {
+    if (Cin == 1 && K == 3 && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 4 == 0) return true;
+    return N > 0 && H > 0 && W > 0 && (K == 1 || K == 3) && (Cin % 16 == 0 || Cin == 8) && Cin > 0 &&
+           Cout > 0 && Cout % 4 == 0 && (size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31);
+}
+
+}  // namespace
+
+extern "C" int64_t sq_conv2d_nhwc_wgrad_workspace_f32(int N, int H, int W, int Cin, int Cout, int K) {
+    if (!shape_ok(N, H, W, Cin, Cout, K)) return -1;
+    if (Cin == 1) return (int64_t)cin1_grid(N, H, W, nullptr) * 10 * Cout * 4;
+    return ws_dispatch(N, H, W, Cin, Cout, K) * 4;
+}
+
+extern "C" int sq_conv2d_nhwc_wgrad_f32(const float *x, const float *dy, float *dw, float *db,
+                                        float *workspace, int N, int H, int W, int Cin, int Cout, int K,
+                                        void *stream) {
+    SQ_REQUIRE(x && dy && dw && workspace, "sq_conv2d_nhwc_wgrad_f32: null pointer");
+    SQ_REQUIRE(shape_ok(N, H, W, Cin, Cout, K),
+               "sq_conv2d_nhwc_wgrad_f32: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d K=%d "
+               "(Cin 8 or %%16, Cout %%4, K 1|3, tensors < 2 GiB)", N, H, W, Cin, Cout, K);
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(workspace);
+    if (Cin == 1) {
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        int tpb;
+        const int gx = cin1_grid(N, H, W, &tpb);
+        const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+        hipLaunchKernelGGL(conv_wgrad_cin1_f32_kernel, dim3(gx, (Cout + 15) / 16), dim3(256), 0, st, x, dy, workspace,
+                           N, H, W, Cout, tiles_x, tiles_y, tiles_x * tiles_y * N, tpb);
+        int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_f32(cin1)");
+        if (rc) return rc;
+        hipLaunchKernelGGL(conv_wgrad_cin1_finish_kernel, dim3((10 * Cout + 255) / 256), dim3(256), 0, st, workspace,
+                           dw, db, gx, Cout);
+        return sq_check_launch("sq_conv2d_nhwc_wgrad_f32(cin1 finish)");
+    }
+    return launch_dispatch(x, dy, dw, db, workspace, N, H, W, Cin, Cout, K, reinterpret_cast<hipStream_t>(stream));
+}

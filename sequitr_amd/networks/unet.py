@@ -20,6 +20,7 @@ import logging
 import numpy as np
 import torch
 
+from .. import functional as F
 from .. import ops
 
 DEFAULT_FILTERS = (16, 32, 64, 128, 256)                       # unet.py:40
@@ -131,7 +132,8 @@ class UNet(object):
         if bridge not in BRIDGE_TYPES:
             raise ValueError('Bridge type not recognized')
         if bridge in ('eltwise_add', 'eltwise_mul', 'eltwise_sub'):
-            self.bridge = lambda x, y, _k=bridge: ops.bridge(x, y, _k)
+            self.bridge = lambda x, y, _k=bridge: (F.bridge(x, y, _k) if (x.requires_grad or y.requires_grad)
+                                                   else ops.bridge(x, y, _k))
         elif bridge == 'concat':
             self.bridge = lambda x, y: torch.cat([x, y], -1)   # upscale first (unet.py:197)
         else:
@@ -254,6 +256,8 @@ class UNet2D(UNet):
         self._seed = params.get('seed', 0)
         self._rng = np.random.default_rng(self._seed)
         self._vars = {}                                        # scope/name -> device tensor
+        self._dropout_calls = 0
+        self.dropout_masks = None
         self._mask = None
 
     # -- variables ---------------------------------------------------------------------
@@ -295,28 +299,52 @@ class UNet2D(UNet):
         return UNet.reshape_input(self, features).contiguous()
 
     # -- leaf hooks ------------------------------------------------------------------------
+    # inference: raw fused kernels; training (mode == 'train'): the differentiable wrappers of
+    # sequitr_amd.functional (same forward kernels + hand-written gradient kernels)
     def conv_layer(self, x, filters):
         k = tuple(self.kernel)
-        return ops.conv2d(x, self._kernel(k + (x.shape[-1], filters)), self._bias(filters), act='relu')
+        w, b = self._kernel(k + (x.shape[-1], filters)), self._bias(filters)
+        if self.training:
+            return F.conv2d(x, w, b, act='relu')
+        return ops.conv2d(x, w, b, act='relu')
 
     def conv_layer_1x1(self, x, filters):
         w, b = self._kernel((1, 1, x.shape[-1], filters)), self._bias(filters)
-        if filters <= 4 and x.shape[-1] % 4 == 0:
+        small = filters <= 4 and x.shape[-1] % 4 == 0
+        if self.training:
+            if small and x.shape[-1] in (8, 16, 32):
+                return F.conv1x1_head(x, w, b)
+            return F.conv2d(x, w, b, act=None)
+        if small:
             logits, self._mask = ops.conv1x1_argmax(x, w, b)   # logits + prediction in one pass
             return logits
         return ops.conv2d(x, w, b, act=None)
 
     def conv_transpose_layer(self, x, filters):
-        return ops.convT2x2s2(x, self._kernel((2, 2, filters, x.shape[-1])), self._bias(filters))
+        w, b = self._kernel((2, 2, filters, x.shape[-1])), self._bias(filters)
+        if self.training:
+            return F.convT2x2s2(x, w, b)
+        return ops.convT2x2s2(x, w, b)
 
     def pool_layer(self, x):
-        return ops.maxpool2x2(x)
+        return F.maxpool2x2(x) if self.training else ops.maxpool2x2(x)
+
+    def dropout_layer(self, x):
+        """tf.layers.dropout(rate, training) after conv2 of every block (unet.py:274-276):
+        identity at inference; Bernoulli(1-rate) mask / (1-rate) in training.  ``dropout_masks``
+        (list of uint8 tensors, consumed in call order) pins the masks for parity tests."""
+        if not self.training or self.dropout <= 0.0:
+            return x
+        mask = self.dropout_masks.pop(0) if getattr(self, 'dropout_masks', None) else None
+        self._dropout_calls += 1
+        return F.dropout(x, self.dropout, seed=self._seed * 1000003 + self._dropout_calls, mask=mask)
 
     def up_layer(self, x, filters, bridge, name=None):
         """Same wiring as the base class, but when neither conv_transpose_layer nor the
-        bridge has been overridden the two run as ONE kernel (convT epilogue applies the
-        bridge), saving a write + two reads of the up-scaled tensor."""
-        fused = (type(self).conv_transpose_layer is UNet2D.conv_transpose_layer
+        bridge has been overridden the two run as ONE kernel at inference (convT epilogue
+        applies the bridge), saving a write + two reads of the up-scaled tensor."""
+        fused = (not self.training
+                 and type(self).conv_transpose_layer is UNet2D.conv_transpose_layer
                  and self.bridge is self._default_bridge
                  and self.bridge_type in ('eltwise_add', 'eltwise_mul', 'eltwise_sub'))
         if not fused:

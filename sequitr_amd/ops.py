@@ -175,3 +175,165 @@ def wsoftmax_ce(logits, onehot, weights, want_grad=True, grad_scale=1.0):
                                              float(grad_scale), ws.data_ptr(), ws.data_ptr() + 8 * nparts,
                                              _ptr(dz), _stream()), "sq_wsoftmax_ce_fwd_bwd_f32")
     return ws[nparts], dz
+
+
+# ----------------------------------------------------------------------------------------------
+# training-side operators (gradients of the ops above; include/sequitr_hip.h "Training side")
+# ----------------------------------------------------------------------------------------------
+_WS_CACHE = {}
+
+
+def _workspace(nbytes, device):
+    """Per-device scratch reused across launches on the same stream (caller-owned memory)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((max(int(nbytes), 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
+        _WS_CACHE[key] = ws
+    return ws
+
+
+def conv_weight_transform(w):
+    """HWIO (K,K,Cin,Cout) -> dgrad filter (K,K,Cout,Cin), taps rotated by 180 degrees."""
+    _chk(w, "w", ndim=4)
+    K, _, Cin, Cout = w.shape
+    wt = torch.empty((K, K, Cout, Cin), dtype=torch.float32, device=w.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_conv_weight_transform_f32(_ptr(w), _ptr(wt), K, Cin, Cout, _stream()),
+               "sq_conv_weight_transform_f32")
+    return wt
+
+
+def conv2d_dgrad(dy, w, wscale=1.0):
+    """dX of conv2d: a forward convolution of dY with the transformed filter."""
+    return conv2d(dy, conv_weight_transform(w), None, act=None, wscale=wscale)
+
+
+def conv2d_wgrad(x, dy, K, want_bias=True):
+    """(dW (K,K,Cin,Cout), db (Cout) or None) from X (N,H,W,Cin) and dY (N,H,W,Cout)."""
+    _chk(x, "x", ndim=4), _chk(dy, "dy", ndim=4)
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    if tuple(dy.shape[:3]) != (N, H, W):
+        raise ValueError("x %s and dy %s differ in N,H,W" % (tuple(x.shape), tuple(dy.shape)))
+    lib = _lib.load()
+    nbytes = lib.sq_conv2d_nhwc_wgrad_workspace_f32(N, H, W, Cin, Cout, K)
+    if nbytes < 0:
+        raise _lib.SequitrHipError("conv2d_wgrad: unsupported shape Cin=%d Cout=%d K=%d" % (Cin, Cout, K))
+    ws = _workspace(nbytes, x.device)
+    dw = torch.empty((K, K, Cin, Cout), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    _lib.check(lib.sq_conv2d_nhwc_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout,
+                                           K, _stream()), "sq_conv2d_nhwc_wgrad_f32")
+    return dw, db
+
+
+def act_bwd(dy, y, act):
+    _chk(dy, "dy"), _chk(y, "y")
+    if ACT[act] == 0:
+        return dy
+    dx = torch.empty_like(dy)
+    lib = _lib.load()
+    _lib.check(lib.sq_act_bwd_f32(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), ACT[act], _stream()), "sq_act_bwd_f32")
+    return dx
+
+
+def maxpool2x2_bwd(x, dy):
+    _chk(x, "x", ndim=4), _chk(dy, "dy", ndim=4)
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.sq_maxpool2x2_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), N, H, W, C, _stream()), "sq_maxpool2x2_bwd_f32")
+    return dx
+
+
+def broadcast2x2(src, scale=1.0):
+    """(N,h,w,C) -> (N,2h,2w,C), every source pixel copied (x scale) to its 2x2 patch."""
+    _chk(src, "src", ndim=4)
+    N, h, w, C = src.shape
+    dst = torch.empty((N, 2 * h, 2 * w, C), dtype=torch.float32, device=src.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_broadcast2x2_f32(_ptr(src), _ptr(dst), N, 2 * h, 2 * w, C, float(scale), _stream()),
+               "sq_broadcast2x2_f32")
+    return dst
+
+
+def sumpool2x2(x):
+    _chk(x, "x", ndim=4)
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_sumpool2x2_f32(_ptr(x), _ptr(y), N, H, W, C, _stream()), "sq_sumpool2x2_f32")
+    return y
+
+
+def bridge_bwd(dy, a, b, kind):
+    _chk(dy, "dy")
+    da, db = torch.empty_like(dy), torch.empty_like(dy)
+    lib = _lib.load()
+    _lib.check(lib.sq_bridge_bwd_f32(_ptr(dy), _ptr(a), _ptr(b), _ptr(da), _ptr(db), dy.numel(), BRIDGE[kind],
+                                    _stream()), "sq_bridge_bwd_f32")
+    return da, db
+
+
+def space_to_depth2(dy):
+    """(N,2H,2W,C) -> (N,H,W,4C), channel index (2a+b)*C + c."""
+    _chk(dy, "dy", ndim=4)
+    N, H2, W2, C = dy.shape
+    g = torch.empty((N, H2 // 2, W2 // 2, 4 * C), dtype=torch.float32, device=dy.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_space_to_depth2_f32(_ptr(dy), _ptr(g), N, H2 // 2, W2 // 2, C, _stream()),
+               "sq_space_to_depth2_f32")
+    return g
+
+
+def conv1x1_small_bwd(x, w, dz, want_dx=True):
+    """Backward of the to_image head: returns (dx or None, dw (1,1,Cin,Cout), db (Cout))."""
+    _chk(x, "x", ndim=4), _chk(w, "w", ndim=4), _chk(dz, "dz", ndim=4)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    npix = N * H * W
+    lib = _lib.load()
+    ws = _workspace(lib.sq_conv1x1_small_bwd_workspace_f32(npix, Cin, Cout), x.device)
+    dx = torch.empty_like(x) if want_dx else None
+    dw = torch.empty((1, 1, Cin, Cout), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.sq_conv1x1_small_bwd_f32(_ptr(x), _ptr(w), _ptr(dz), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws),
+                                           npix, Cin, Cout, _stream()), "sq_conv1x1_small_bwd_f32")
+    return dx, dw, db
+
+
+def dropout_fwd(x, rate, seed=0, mask=None):
+    """returns (y, mask u8).  A supplied mask is used as-is (parity tests)."""
+    _chk(x, "x")
+    y = torch.empty_like(x)
+    given = mask is not None
+    if given:
+        _chk(mask, "mask", dtype=torch.uint8)
+    else:
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_dropout_fwd_f32(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(rate), int(seed) & 0xFFFFFFFF,
+                                     1 if given else 0, _stream()), "sq_dropout_fwd_f32")
+    return y, mask
+
+
+def dropout_bwd(dy, mask, rate):
+    _chk(dy, "dy"), _chk(mask, "mask", dtype=torch.uint8)
+    dx = torch.empty_like(dy)
+    lib = _lib.load()
+    _lib.check(lib.sq_dropout_bwd_f32(_ptr(dy), _ptr(mask), _ptr(dx), dy.numel(), float(rate), _stream()),
+               "sq_dropout_bwd_f32")
+    return dx
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """In-place Adam update of the flat parameter buffer p."""
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, n)
+    if not (p.numel() == g.numel() == m.numel() == v.numel()):
+        raise ValueError("adam_step: buffers differ in size")
+    lib = _lib.load()
+    _lib.check(lib.sq_adam_step_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
+                                   float(beta2), float(eps), int(step), float(grad_scale), _stream()),
+               "sq_adam_step_f32")

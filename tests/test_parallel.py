@@ -1,0 +1,81 @@
+"""CPU (gloo, world_size 2): the data-parallel plumbing -- flat bucket views, tile sharding and
+the single all-reduce -- gives rank-averaged gradients equal to the single-process
+global-batch gradients."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sequitr_amd.parallel import FlatBucket, allreduce_sum_, shard_range
+
+
+def test_flat_bucket_views_share_storage_and_stay_aligned():
+    b = FlatBucket([("a/kernel", (3, 3, 1, 16)), ("a/bias", (16,)), ("h/kernel", (1, 1, 16, 2)), ("h/bias", (2,))], "cpu")
+    assert b.numel % 4 == 0 and b.numel >= 144 + 16 + 32 + 2
+    b.view("h/bias").fill_(7.0)
+    o, n = b.offsets["h/bias"]
+    assert o % 4 == 0 and torch.all(b.flat[o:o + n] == 7.0) and b.flat.sum() == 14.0
+    assert set(b.views()) == {"a/kernel", "a/bias", "h/kernel", "h/bias"} and b.view("a/kernel").shape == (3, 3, 1, 16)
+
+
+def test_shard_range_partitions_tiles():
+    for n, world in ((32, 8), (33, 8), (5, 8), (128, 3)):
+        r = [shard_range(n, k, world) for k in range(world)]
+        assert r[0][0] == 0 and r[-1][1] == n
+        assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+        sizes = [e - b for b, e in r]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model_grads(w, x, y):
+    """tiny conv net on torch CPU: returns loss grad w.r.t. w with MEAN-over-batch loss."""
+    w = w.clone().requires_grad_(True)
+    out = torch.nn.functional.conv2d(x, w, padding=1)
+    loss = ((out - y) ** 2).mean()
+    loss.backward()
+    return w.grad
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)
+        w = torch.randn(4, 1, 3, 3, generator=g, dtype=torch.float64)
+        x = torch.randn(8, 1, 16, 16, generator=g, dtype=torch.float64)
+        y = torch.randn(8, 4, 16, 16, generator=g, dtype=torch.float64)
+        b, e = shard_range(8, rank, world)
+        bucket = FlatBucket([("w", (4, 1, 3, 3))], "cpu", dtype=torch.float64)
+        bucket.view("w").copy_(_model_grads(w, x[b:e], y[b:e]))
+        n = allreduce_sum_(bucket.flat)
+        assert n == world
+        avg = bucket.view("w") / n
+        ref = _model_grads(w, x, y)                      # equal shard sizes: mean of means = global mean
+        ret[rank] = float((avg - ref).abs().max() / ref.abs().max())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_equals_global_batch_gradient():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world and all(v <= 1e-12 for v in ret.values()), dict(ret)
+
+
+def test_allreduce_is_noop_without_process_group():
+    t = torch.ones(8)
+    assert allreduce_sum_(t) == 1 and torch.all(t == 1)
