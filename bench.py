@@ -97,13 +97,74 @@ def cpu_baseline(weights, params, budget_s=20.0):
                       "reference TF-CPU path (TensorFlow not installable)" % (nt, net.threads)}
 
 
+def main_train(args):
+    """U-Net training step (fwd + weighted CE + bwd + flat all-reduce + Adam), 16 tiles per GPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    from sequitr_amd.train import UNetTrainer
+    nb = 16
+    params = {"shape": (TILE, TILE), "num_inputs": 1, "num_outputs": 2, "filters": FILTERS,
+              "bridge": "eltwise_mul", "dropout": 0.4, "device": str(dev), "seed": 0}
+    tr = UNetTrainer(params, learning_rate=0.01)
+    rng = np.random.default_rng(2 + rank)
+    x = torch.from_numpy(rng.standard_normal((nb, TILE, TILE, 1)).astype(np.float32)).to(dev)
+    lab = rng.random((nb, TILE, TILE)) < 0.3
+    onehot = torch.from_numpy(np.stack([~lab, lab], -1).astype(np.uint8)).to(dev)
+    wmap = torch.from_numpy((1 + 9 * rng.random((nb, TILE, TILE, 1))).astype(np.float32)).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(x, onehot, wmap)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(x, onehot, wmap)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        pix = float(world) * nb * TILE * TILE * args.steps
+        print(json.dumps({"metric": "trained Mpixels/sec on 512x512 tiles (fwd+loss+bwd+allreduce+Adam)",
+                          "value": round(pix / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic",
+                          "config": {"workload": "U-Net training, weighted softmax-CE, batch=16 512x512x1 tiles per "
+                                                 "GPU, dropout 0.4, Adam; fp32 (bf16 variant not built yet)",
+                                     "loss": float(tr.last_loss.item())}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = the headline metric (BASELINE configs[1]); train = configs[2]/[3] "
+                         "(U-Net training step, batch 16 per GPU) for DESIGN.md, not the driver's line")
     args = ap.parse_args()
+    if args.mode == "train":
+        return main_train(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -146,9 +146,10 @@ int sq_act_bwd_f32(const float *dy, const float *y, float *dx, int64_t n, int ac
 int sq_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int N, int H, int W, int C, void *stream);
 
 /* dst (N,H,W,C) = scale * src (N,H/2,W/2,C) broadcast over 2x2: avg-pool backward (scale 0.25)
- * and double_size forward (scale 1).  sq_sumpool2x2: y = sum of each 2x2 patch (double_size backward). */
+ * and double_size forward (scale 1).  sq_sumpool2x2: y = scale * sum of each 2x2 patch (double_size
+ * backward).  Any C (2-channel images take a scalar path). */
 int sq_broadcast2x2_f32(const float *src, float *dst, int N, int H, int W, int C, float scale, void *stream);
-int sq_sumpool2x2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
+int sq_sumpool2x2_f32(const float *x, float *y, int N, int H, int W, int C, float scale, void *stream);
 
 /* bridge backward: (da, db) from dY and the forward operands a (up-scaled) and b (skip). */
 int sq_bridge_bwd_f32(const float *dy, const float *a, const float *b, float *da, float *db, int64_t n,
@@ -172,6 +173,46 @@ int sq_dropout_bwd_f32(const float *dy, const uint8_t *mask, float *dx, int64_t 
  * g is first multiplied by grad_scale (1/world for data-parallel averaging); step counts from 1. */
 int sq_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
                      float beta2, float eps, int step, float grad_scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GAN side (sequitr/networks/gan.py).  weighted_conv2d / to_image / from_image are
+ * sq_conv2d_nhwc_fwd_f32 with wscale + act; the entries below are the remaining leaf ops, their
+ * gradients and the second-order pieces the WGAN-GP penalty needs (gan.py:719-729).
+ * ---------------------------------------------------------------------------------------- */
+
+/* pixel_norm gradients (gan.py:49-51): bwd: dx from (x, dy); bwd2: with v = dL/d(dx) returns
+ * dg = dL/d(dy) and dx2 = dL/dx through the backward expression. */
+int sq_pixelnorm_bwd_f32(const float *x, const float *dy, float *dx, int64_t npix, int C, float eps, void *stream);
+int sq_pixelnorm_bwd2_f32(const float *x, const float *g, const float *v, float *dg, float *dx2, int64_t npix,
+                          int C, float eps, void *stream);
+
+/* half_size / any tf.image.resize_nearest_neighbor(align_corners=True) (gan.py:128-136). */
+int sq_resize_nearest_f32(const float *x, float *y, int N, int Hi, int Wi, int Ho, int Wo, int C, void *stream);
+
+/* y = alpha*a + (1-alpha)*b: fade-in (gan.py:687-694, scalar alpha) and the real/fake interpolation
+ * (gan.py:709-714, alpha_per_sample (N) != NULL, per_sample = elements per sample). */
+int sq_lerp_f32(const float *a, const float *b, float *y, int64_t n, int64_t per_sample, float alpha,
+                const float *alpha_per_sample, void *stream);
+/* y = k*x, k = s or s_per_sample[n] (or 1-k when one_minus): the gradients of sq_lerp_f32. */
+int sq_scale_f32(const float *x, float *y, int64_t n, int64_t per_sample, float s, const float *s_per_sample,
+                 int one_minus, void *stream);
+
+/* stand-alone activation (k_leaky_relu_alpha, gan.py:44-46) */
+int sq_act_fwd_f32(const float *x, float *y, int64_t n, int act, void *stream);
+
+/* out[n] = sum_i a[n,i]*b[n,i] (b == a: squared gradient norm of gan.py:722); fixed-order two-stage sum. */
+int64_t sq_dot_per_sample_workspace_f32(int N);
+int sq_dot_per_sample_f32(const float *a, const float *b, float *out, float *workspace, int N, int64_t per_sample,
+                          void *stream);
+
+/* minibatch stdev scalar (gan.py:204-211): sqrt(mean over positions of the batch variance).
+ * workspace: 256 floats. */
+int sq_mbstd_fwd_f32(const float *x, float *out, float *workspace, int N, int64_t per_sample, void *stream);
+
+/* M (Ca,Cb) = sum_p a[p,:]^T b[p,:] with Ca <= 4, Cb % 4 == 0: weight gradient of to_image / from_image. */
+int64_t sq_wgrad1x1_small_workspace_f32(int64_t npix, int Ca, int Cb);
+int sq_wgrad1x1_small_f32(const float *a, const float *b, float *m, float *workspace, int64_t npix, int Ca, int Cb,
+                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ SIGNATURES = {
     "sq_act_bwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
     "sq_maxpool2x2_bwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "sq_broadcast2x2_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_float, c_void_p]),
-    "sq_sumpool2x2_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "sq_sumpool2x2_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_float, c_void_p]),
     "sq_bridge_bwd_f32": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_void_p]),
     "sq_space_to_depth2_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "sq_conv1x1_small_bwd_workspace_f32": (c_int64, [c_int64, c_int, c_int]),
@@ -41,6 +41,17 @@ SIGNATURES = {
     "sq_dropout_fwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_float, ctypes.c_uint32, c_int, c_void_p]),
     "sq_dropout_bwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_float, c_void_p]),
     "sq_adam_step_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 4 + [c_int, c_float, c_void_p]),
+    "sq_pixelnorm_bwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_float, c_void_p]),
+    "sq_pixelnorm_bwd2_f32": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_float, c_void_p]),
+    "sq_resize_nearest_f32": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
+    "sq_lerp_f32": (c_int, [c_void_p] * 3 + [c_int64, c_int64, c_float, c_void_p, c_void_p]),
+    "sq_scale_f32": (c_int, [c_void_p] * 2 + [c_int64, c_int64, c_float, c_void_p, c_int, c_void_p]),
+    "sq_act_fwd_f32": (c_int, [c_void_p] * 2 + [c_int64, c_int, c_void_p]),
+    "sq_dot_per_sample_workspace_f32": (c_int64, [c_int]),
+    "sq_dot_per_sample_f32": (c_int, [c_void_p] * 4 + [c_int, c_int64, c_void_p]),
+    "sq_mbstd_fwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_int64, c_void_p]),
+    "sq_wgrad1x1_small_workspace_f32": (c_int64, [c_int64, c_int, c_int]),
+    "sq_wgrad1x1_small_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
 }
 
 _lib = None

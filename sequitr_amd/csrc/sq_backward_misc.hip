@@ -68,7 +68,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4 *__restri
 
 // avg-pool backward (scale 0.25) and nearest-2x up-sampling forward share the broadcast; the
 // up-sampling backward (sum of the 2x2 patch) is avg-pool forward x 4 -> `scale` parameter.
-__global__ __launch_bounds__(256) void broadcast2x2_kernel(const float4 *__restrict__ dy, float4 *__restrict__ dx,
+// V = float4 when C % 4 == 0, else float (2-channel images of to_image / from_image).
+__device__ __forceinline__ float4 vscale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float vscale(float a, float s) { return a * s; }
+__device__ __forceinline__ float4 vsum4(float4 a, float4 b, float4 d, float4 e) {
+    return make_float4((a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z),
+                       (a.w + b.w) + (d.w + e.w));
+}
+__device__ __forceinline__ float vsum4(float a, float b, float d, float e) { return (a + b) + (d + e); }
+
+template <typename V>
+__global__ __launch_bounds__(256) void broadcast2x2_kernel(const V *__restrict__ dy, V *__restrict__ dx,
                                                             int N, int H, int W, int C4, float scale) {
     const int64_t total = (int64_t)N * H * W * C4;           // H, W = the LARGE side
     SQ_GRID_STRIDE(i, total) {
@@ -78,14 +88,13 @@ __global__ __launch_bounds__(256) void broadcast2x2_kernel(const float4 *__restr
         t /= W;
         const int yy = (int)(t % H);
         const int n = (int)(t / H);
-        float4 g = dy[(((int64_t)n * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * C4 + c];
-        g.x *= scale; g.y *= scale; g.z *= scale; g.w *= scale;
-        dx[i] = g;
+        dx[i] = vscale(dy[(((int64_t)n * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * C4 + c], scale);
     }
 }
 
-__global__ __launch_bounds__(256) void sumpool2x2_kernel(const float4 *__restrict__ x, float4 *__restrict__ y,
-                                                          int N, int H, int W, int C4) {
+template <typename V>
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const V *__restrict__ x, V *__restrict__ y,
+                                                          int N, int H, int W, int C4, float scale) {
     const int Ho = H >> 1, Wo = W >> 1;
     const int64_t total = (int64_t)N * Ho * Wo * C4;
     SQ_GRID_STRIDE(i, total) {
@@ -96,9 +105,7 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const float4 *__restric
         const int yo = (int)(t % Ho);
         const int n = (int)(t / Ho);
         const int64_t b = (((int64_t)n * H + 2 * yo) * W + 2 * xo) * C4 + c;
-        const float4 a = x[b], bb = x[b + C4], d = x[b + (int64_t)W * C4], e = x[b + (int64_t)W * C4 + C4];
-        y[i] = make_float4((a.x + bb.x) + (d.x + e.x), (a.y + bb.y) + (d.y + e.y), (a.z + bb.z) + (d.z + e.z),
-                           (a.w + bb.w) + (d.w + e.w));
+        y[i] = vscale(vsum4(x[b], x[b + C4], x[b + (int64_t)W * C4], x[b + (int64_t)W * C4 + C4]), scale);
     }
 }
 
@@ -290,21 +297,28 @@ extern "C" int sq_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx,
 extern "C" int sq_broadcast2x2_f32(const float *src, float *dst, int N, int H, int W, int C, float scale,
                                    void *stream) {
     SQ_REQUIRE(src && dst, "sq_broadcast2x2_f32: null tensor pointer");
-    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0,
-               "sq_broadcast2x2_f32: need even H,W (large side) and C %% 4 == 0");
-    SQ_REQUIRE_ALIGNED(src); SQ_REQUIRE_ALIGNED(dst);
-    hipLaunchKernelGGL(broadcast2x2_kernel, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(256), 0, SQ_ST(stream),
-                       reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), N, H, W, C / 4, scale);
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0,
+               "sq_broadcast2x2_f32: need even H,W (large side)");
+    if (C % 4 == 0 && SQ_ALIGNED16(src) && SQ_ALIGNED16(dst))
+        hipLaunchKernelGGL(broadcast2x2_kernel<float4>, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(256), 0,
+                           SQ_ST(stream), reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), N, H,
+                           W, C / 4, scale);
+    else
+        hipLaunchKernelGGL(broadcast2x2_kernel<float>, dim3(grid_for((int64_t)N * H * W * C)), dim3(256), 0,
+                           SQ_ST(stream), src, dst, N, H, W, C, scale);
     return sq_check_launch("sq_broadcast2x2_f32");
 }
 
-extern "C" int sq_sumpool2x2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream) {
+extern "C" int sq_sumpool2x2_f32(const float *x, float *y, int N, int H, int W, int C, float scale, void *stream) {
     SQ_REQUIRE(x && y, "sq_sumpool2x2_f32: null tensor pointer");
-    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0,
-               "sq_sumpool2x2_f32: need even H,W and C %% 4 == 0");
-    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(y);
-    hipLaunchKernelGGL(sumpool2x2_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
-                       SQ_ST(stream), reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), N, H, W, C / 4);
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, "sq_sumpool2x2_f32: need even H,W");
+    if (C % 4 == 0 && SQ_ALIGNED16(x) && SQ_ALIGNED16(y))
+        hipLaunchKernelGGL(sumpool2x2_kernel<float4>, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 4))),
+                           dim3(256), 0, SQ_ST(stream), reinterpret_cast<const float4 *>(x),
+                           reinterpret_cast<float4 *>(y), N, H, W, C / 4, scale);
+    else
+        hipLaunchKernelGGL(sumpool2x2_kernel<float>, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * C)), dim3(256), 0,
+                           SQ_ST(stream), x, y, N, H, W, C, scale);
     return sq_check_launch("sq_sumpool2x2_f32");
 }
 

@@ -1,0 +1,372 @@
+// GAN-side operators of sequitr/networks/gan.py for gfx950 (all HBM-bound, f32):
+//   pixel_norm backward and its second-order backward (the WGAN-GP penalty differentiates the
+//   discriminator's input gradient, gan.py:721-729, and from_image applies pixel_norm, gan.py:115-125),
+//   nearest-neighbour resize with align_corners (half_size, gan.py:128-131), the fade-in blend
+//   (gan.py:687-694), the real/fake interpolation (gan.py:709-714), per-sample squared norms
+//   (gan.py:722), minibatch-stdev (gan.py:204-212), an activation forward, and the weight gradient of
+//   1x1 convolutions with a handful of channels on one side (to_image / from_image).
+#include "sq_common.h"
+
+namespace {
+
+inline unsigned grid_for(int64_t items) {
+    int64_t b = (items + 255) / 256;
+    if (b > 2048) b = 2048;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+#define SQ_GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n); i += (int64_t)gridDim.x * 256)
+
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    return v;
+}
+
+// pixel_norm: y = x r, r = rsqrt(mean_c x^2 + eps).  One 16-lane group per pixel.
+//   MODE 1 (backward):      dx = r g - r^3 s x,                       s = mean_c(g x)
+//   MODE 2 (2nd backward):  given v = dL/d(dx):
+//        dg = r v - r^3 t x,                                          t = mean_c(v x)
+//        dx2 = -r^3 u x + 3 r^5 s t x - r^3 t g - r^3 s v,            u = mean_c(v g)
+template <int MODE>
+__global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                             const float *__restrict__ v, float *__restrict__ out1,
+                                                             float *__restrict__ out2, int64_t npix, int C, float eps) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15, sub = lane >> 4;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    const float invC = 1.0f / (float)C;
+    for (int64_t pb = wave * 4; pb < npix; pb += nwaves * 4) {
+        const int64_t p = pb + sub;
+        const bool live = p < npix;
+        float sxx = 0.f, sgx = 0.f, svx = 0.f, svg = 0.f;
+        if (live)
+            for (int c = 4 * l16; c < C; c += 64) {
+                const float4 xv = *reinterpret_cast<const float4 *>(x + p * C + c);
+                const float4 gv = *reinterpret_cast<const float4 *>(g + p * C + c);
+                sxx += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+                sgx += gv.x * xv.x + gv.y * xv.y + gv.z * xv.z + gv.w * xv.w;
+                if (MODE == 2) {
+                    const float4 vv = *reinterpret_cast<const float4 *>(v + p * C + c);
+                    svx += vv.x * xv.x + vv.y * xv.y + vv.z * xv.z + vv.w * xv.w;
+                    svg += vv.x * gv.x + vv.y * gv.y + vv.z * gv.z + vv.w * gv.w;
+                }
+            }
+        sxx = group16_sum(sxx); sgx = group16_sum(sgx);
+        if (MODE == 2) { svx = group16_sum(svx); svg = group16_sum(svg); }
+        const float r = 1.0f / __builtin_sqrtf(sxx * invC + eps);
+        const float r3 = r * r * r, s = sgx * invC, t = svx * invC, u = svg * invC;
+        if (live)
+            for (int c = 4 * l16; c < C; c += 64) {
+                const float4 xv = *reinterpret_cast<const float4 *>(x + p * C + c);
+                const float4 gv = *reinterpret_cast<const float4 *>(g + p * C + c);
+                if (MODE == 1) {
+                    *reinterpret_cast<float4 *>(out1 + p * C + c) =
+                        make_float4(r * gv.x - r3 * s * xv.x, r * gv.y - r3 * s * xv.y, r * gv.z - r3 * s * xv.z,
+                                    r * gv.w - r3 * s * xv.w);
+                } else {
+                    const float4 vv = *reinterpret_cast<const float4 *>(v + p * C + c);
+                    *reinterpret_cast<float4 *>(out1 + p * C + c) =
+                        make_float4(r * vv.x - r3 * t * xv.x, r * vv.y - r3 * t * xv.y, r * vv.z - r3 * t * xv.z,
+                                    r * vv.w - r3 * t * xv.w);
+                    const float a = -r3 * u + 3.0f * r3 * r * r * s * t, b = -r3 * t, d = -r3 * s;
+                    *reinterpret_cast<float4 *>(out2 + p * C + c) =
+                        make_float4(a * xv.x + b * gv.x + d * vv.x, a * xv.y + b * gv.y + d * vv.y,
+                                    a * xv.z + b * gv.z + d * vv.z, a * xv.w + b * gv.w + d * vv.w);
+                }
+            }
+    }
+}
+
+// tf.image.resize_nearest_neighbor(align_corners=True): src = round(d * (in-1)/(out-1))
+__global__ __launch_bounds__(256) void resize_nn_kernel(const float *__restrict__ x, float *__restrict__ y, int N,
+                                                         int Hi, int Wi, int Ho, int Wo, int C) {
+    const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    const int64_t total = (int64_t)N * Ho * Wo * C;
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int xo = (int)(t % Wo);
+        t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        int ys = (int)__builtin_roundf((float)yo * sy), xs = (int)__builtin_roundf((float)xo * sx);
+        ys = ys < Hi - 1 ? ys : Hi - 1;
+        xs = xs < Wi - 1 ? xs : Wi - 1;
+        y[i] = x[(((int64_t)n * Hi + ys) * Wi + xs) * C + c];
+    }
+}
+
+// y = alpha*a + (1-alpha)*b ; alpha is a scalar, or per-sample (r, gan.py:709-714) when `per` != NULL
+__global__ __launch_bounds__(256) void lerp_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b,
+                                                    float4 *__restrict__ y, int64_t n4, int64_t per_sample4,
+                                                    float alpha, const float *__restrict__ per) {
+    SQ_GRID_STRIDE(i, n4) {
+        const float al = per ? per[i / per_sample4] : alpha;
+        const float be = 1.0f - al;
+        const float4 u = a[i], v = b[i];
+        y[i] = make_float4(al * u.x + be * v.x, al * u.y + be * v.y, al * u.z + be * v.z, al * u.w + be * v.w);
+    }
+}
+
+// y = s * x with s scalar or per-sample: the gradients of the blends above
+__global__ __launch_bounds__(256) void scale_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int64_t n4,
+                                                     int64_t per_sample4, float s, const float *__restrict__ per,
+                                                     int one_minus) {
+    SQ_GRID_STRIDE(i, n4) {
+        float k = per ? per[i / per_sample4] : s;
+        if (one_minus) k = 1.0f - k;
+        const float4 u = x[i];
+        y[i] = make_float4(k * u.x, k * u.y, k * u.z, k * u.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int64_t n4,
+                                                       int act) {
+    SQ_GRID_STRIDE(i, n4) {
+        const float4 v = x[i];
+        y[i] = make_float4(sq_act(v.x, act), sq_act(v.y, act), sq_act(v.z, act), sq_act(v.w, act));
+    }
+}
+
+// per-sample dot products out[n] = sum_i a[n,i]*b[n,i]  (b == a: squared norm); one block per
+// (sample, slice), fixed-order finish over the slices in dot_finish_kernel
+constexpr int DOT_SLICES = 32;
+__global__ __launch_bounds__(256) void dot_per_sample_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b,
+                                                              float *__restrict__ partials, int64_t per4) {
+    __shared__ float red[256];
+    const int n = blockIdx.y, sl = blockIdx.x;
+    const int64_t lo = per4 * sl / DOT_SLICES, hi = per4 * (sl + 1) / DOT_SLICES;
+    float s = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float4 u = a[(int64_t)n * per4 + i], v = b[(int64_t)n * per4 + i];
+        s += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[n * DOT_SLICES + sl] = red[0];
+}
+__global__ void dot_finish_kernel(const float *__restrict__ partials, float *__restrict__ out, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < DOT_SLICES; ++k) s += partials[n * DOT_SLICES + k];
+    out[n] = s;
+}
+
+// minibatch stdev (gan.py:204-212): sqrt( mean_p ( mean_n (x_np - mean_n x_np)^2 ) ), P = per-sample size.
+// One thread per position p (two passes over the batch), block partial sums, single-block finish.
+__global__ __launch_bounds__(256) void mbstd_kernel(const float *__restrict__ x, float *__restrict__ partials, int N,
+                                                     int64_t P) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    SQ_GRID_STRIDE(p, P) {
+        float mu = 0.f;
+        for (int n = 0; n < N; ++n) mu += x[(int64_t)n * P + p];
+        mu /= (float)N;
+        float var = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float d = x[(int64_t)n * P + p] - mu;
+            var = __builtin_fmaf(d, d, var);
+        }
+        acc += var / (float)N;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+__global__ void mbstd_finish_kernel(const float *__restrict__ partials, int nb, float invP, float *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < nb; ++i) s += partials[i];
+        *out = __builtin_sqrtf(s * invP);
+    }
+}
+
+// M[ca][cb] = sum_p a[p,ca] * b[p,cb]   with CA <= 4 (the image side of to_image / from_image) and
+// Cb % 4 == 0.  Thread = (pixel lane, cb quad); block partials [grid][CA][Cb]; fixed-order finish.
+template <int CA>
+__global__ __launch_bounds__(256) void wgrad1x1_small_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                              float *__restrict__ partials, int64_t npix, int Cb) {
+    extern __shared__ float red[];                           // [256][CA*4]
+    const int q4 = Cb / 4;                                   // quads per pixel
+    const int quads_per_pass = 256 < q4 ? 256 : q4;
+    const int pl = 256 / quads_per_pass;                     // pixel lanes per block
+    const int tq = threadIdx.x % quads_per_pass, tp = threadIdx.x / quads_per_pass;
+    float *out = partials + (size_t)blockIdx.x * CA * Cb;
+    for (int qb = 0; qb < q4; qb += quads_per_pass) {
+        const int q = qb + tq;
+        float acc[CA][4];
+#pragma unroll
+        for (int c = 0; c < CA; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][j] = 0.f;
+        if (q < q4 && tp < pl)
+            for (int64_t p = (int64_t)blockIdx.x * pl + tp; p < npix; p += (int64_t)gridDim.x * pl) {
+                const float4 bv = *reinterpret_cast<const float4 *>(b + p * Cb + q * 4);
+#pragma unroll
+                for (int c = 0; c < CA; ++c) {
+                    const float av = a[p * CA + c];
+                    acc[c][0] = __builtin_fmaf(av, bv.x, acc[c][0]);
+                    acc[c][1] = __builtin_fmaf(av, bv.y, acc[c][1]);
+                    acc[c][2] = __builtin_fmaf(av, bv.z, acc[c][2]);
+                    acc[c][3] = __builtin_fmaf(av, bv.w, acc[c][3]);
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < CA; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[threadIdx.x * (CA * 4) + c * 4 + j] = acc[c][j];
+        __syncthreads();
+        if (tp == 0 && q < q4) {
+#pragma unroll
+            for (int c = 0; c < CA; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s = 0.f;
+                    for (int k = 0; k < pl; ++k) s += red[(k * quads_per_pass + tq) * (CA * 4) + c * 4 + j];
+                    out[c * Cb + q * 4 + j] = s;
+                }
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void wgrad1x1_small_finish_kernel(const float *__restrict__ partials,
+                                                                     float *__restrict__ m, int nblk, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * total + i];
+    m[i] = s;
+}
+
+inline int small_blocks(int64_t npix) {
+    int64_t b = (npix + 255) / 256;
+    return (int)(b > 256 ? 256 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+#define SQ_ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int sq_pixelnorm_bwd_f32(const float *x, const float *dy, float *dx, int64_t npix, int C, float eps,
+                                    void *stream) {
+    SQ_REQUIRE(x && dy && dx && npix > 0 && C > 0 && C % 4 == 0, "sq_pixelnorm_bwd_f32: bad arguments (C %% 4 == 0)");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(dx);
+    hipLaunchKernelGGL(pixelnorm_bwd_kernel<1>, dim3(grid_for(npix * 16)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr,
+                       dx, nullptr, npix, C, eps);
+    return sq_check_launch("sq_pixelnorm_bwd_f32");
+}
+
+extern "C" int sq_pixelnorm_bwd2_f32(const float *x, const float *g, const float *v, float *dg, float *dx2,
+                                     int64_t npix, int C, float eps, void *stream) {
+    SQ_REQUIRE(x && g && v && dg && dx2 && npix > 0 && C > 0 && C % 4 == 0,
+               "sq_pixelnorm_bwd2_f32: bad arguments (C %% 4 == 0)");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(g); SQ_REQUIRE_ALIGNED(v); SQ_REQUIRE_ALIGNED(dg); SQ_REQUIRE_ALIGNED(dx2);
+    hipLaunchKernelGGL(pixelnorm_bwd_kernel<2>, dim3(grid_for(npix * 16)), dim3(256), 0, SQ_ST(stream), x, g, v, dg,
+                       dx2, npix, C, eps);
+    return sq_check_launch("sq_pixelnorm_bwd2_f32");
+}
+
+extern "C" int sq_resize_nearest_f32(const float *x, float *y, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                                     void *stream) {
+    SQ_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "sq_resize_nearest_f32: bad arguments");
+    hipLaunchKernelGGL(resize_nn_kernel, dim3(grid_for((int64_t)N * Ho * Wo * C)), dim3(256), 0, SQ_ST(stream), x, y, N,
+                       Hi, Wi, Ho, Wo, C);
+    return sq_check_launch("sq_resize_nearest_f32");
+}
+
+extern "C" int sq_lerp_f32(const float *a, const float *b, float *y, int64_t n, int64_t per_sample, float alpha,
+                           const float *alpha_per_sample, void *stream) {
+    SQ_REQUIRE(a && b && y && n > 0 && n % 4 == 0 && per_sample > 0 && per_sample % 4 == 0 && n % per_sample == 0,
+               "sq_lerp_f32: sizes must be multiples of 4 and n a multiple of per_sample");
+    SQ_REQUIRE_ALIGNED(a); SQ_REQUIRE_ALIGNED(b); SQ_REQUIRE_ALIGNED(y);
+    hipLaunchKernelGGL(lerp_kernel, dim3(grid_for(n / 4)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b),
+                       reinterpret_cast<float4 *>(y), n / 4, per_sample / 4, alpha, alpha_per_sample);
+    return sq_check_launch("sq_lerp_f32");
+}
+
+extern "C" int sq_scale_f32(const float *x, float *y, int64_t n, int64_t per_sample, float s,
+                            const float *s_per_sample, int one_minus, void *stream) {
+    SQ_REQUIRE(x && y && n > 0 && n % 4 == 0 && per_sample > 0 && per_sample % 4 == 0 && n % per_sample == 0,
+               "sq_scale_f32: sizes must be multiples of 4 and n a multiple of per_sample");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(y);
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n / 4)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), n / 4, per_sample / 4, s,
+                       s_per_sample, one_minus);
+    return sq_check_launch("sq_scale_f32");
+}
+
+extern "C" int sq_act_fwd_f32(const float *x, float *y, int64_t n, int act, void *stream) {
+    SQ_REQUIRE(x && y && n > 0 && n % 4 == 0, "sq_act_fwd_f32: bad arguments (n %% 4 == 0)");
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_act_fwd_f32: bad activation %d", act);
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(y);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), n / 4, act);
+    return sq_check_launch("sq_act_fwd_f32");
+}
+
+extern "C" int64_t sq_dot_per_sample_workspace_f32(int N) { return N > 0 ? (int64_t)N * DOT_SLICES * 4 : -1; }
+
+extern "C" int sq_dot_per_sample_f32(const float *a, const float *b, float *out, float *workspace, int N,
+                                     int64_t per_sample, void *stream) {
+    SQ_REQUIRE(a && b && out && workspace && N > 0 && N <= 65535 && per_sample > 0 && per_sample % 4 == 0,
+               "sq_dot_per_sample_f32: bad arguments (per_sample %% 4 == 0)");
+    SQ_REQUIRE_ALIGNED(a); SQ_REQUIRE_ALIGNED(b);
+    hipLaunchKernelGGL(dot_per_sample_kernel, dim3(DOT_SLICES, N), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b), workspace,
+                       per_sample / 4);
+    int rc = sq_check_launch("sq_dot_per_sample_f32");
+    if (rc) return rc;
+    hipLaunchKernelGGL(dot_finish_kernel, dim3((N + 63) / 64), dim3(64), 0, SQ_ST(stream), workspace, out, N);
+    return sq_check_launch("sq_dot_per_sample_f32(finish)");
+}
+
+extern "C" int sq_mbstd_fwd_f32(const float *x, float *out, float *workspace, int N, int64_t per_sample,
+                                void *stream) {
+    SQ_REQUIRE(x && out && workspace && N > 0 && per_sample > 0, "sq_mbstd_fwd_f32: bad arguments");
+    int nb = (int)((per_sample + 255) / 256);
+    if (nb > 256) nb = 256;                                   // workspace: 256 floats
+    hipLaunchKernelGGL(mbstd_kernel, dim3(nb), dim3(256), 0, SQ_ST(stream), x, workspace, N, per_sample);
+    int rc = sq_check_launch("sq_mbstd_fwd_f32");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mbstd_finish_kernel, dim3(1), dim3(64), 0, SQ_ST(stream), workspace, nb, 1.0f / (float)per_sample,
+                       out);
+    return sq_check_launch("sq_mbstd_fwd_f32(finish)");
+}
+
+extern "C" int64_t sq_wgrad1x1_small_workspace_f32(int64_t npix, int Ca, int Cb) {
+    if (npix <= 0 || Ca < 1 || Ca > 4 || Cb <= 0 || Cb % 4) return -1;
+    return (int64_t)small_blocks(npix) * Ca * Cb * 4;
+}
+
+extern "C" int sq_wgrad1x1_small_f32(const float *a, const float *b, float *m, float *workspace, int64_t npix,
+                                     int Ca, int Cb, void *stream) {
+    SQ_REQUIRE(a && b && m && workspace, "sq_wgrad1x1_small_f32: null pointer");
+    SQ_REQUIRE(npix > 0 && Ca >= 1 && Ca <= 4 && Cb > 0 && Cb % 4 == 0,
+               "sq_wgrad1x1_small_f32: Ca=%d (1..4), Cb=%d (multiple of 4)", Ca, Cb);
+    SQ_REQUIRE_ALIGNED(b);
+    const int nb = small_blocks(npix);
+    hipStream_t st = SQ_ST(stream);
+    const size_t lds = 256 * Ca * 4 * sizeof(float);
+    switch (Ca) {
+    case 1: hipLaunchKernelGGL(wgrad1x1_small_kernel<1>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
+    case 2: hipLaunchKernelGGL(wgrad1x1_small_kernel<2>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
+    case 3: hipLaunchKernelGGL(wgrad1x1_small_kernel<3>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
+    default: hipLaunchKernelGGL(wgrad1x1_small_kernel<4>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
+    }
+    int rc = sq_check_launch("sq_wgrad1x1_small_f32");
+    if (rc) return rc;
+    const int total = Ca * Cb;
+    hipLaunchKernelGGL(wgrad1x1_small_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, m, nb, total);
+    return sq_check_launch("sq_wgrad1x1_small_f32(finish)");
+}

@@ -1,14 +1,131 @@
 """Differentiable wrappers: torch.autograd is the TAPE only (plumbing) -- every forward and every
 gradient is one of the hand-written HIP kernels in ops.py.  These let the reference's hook-style
-graph code (UNet.build, sequitr/networks/unet.py:224-322) be trained exactly as written: a hook
-may be overridden with any differentiable composition and gradients still flow.
+graph code (UNet.build, sequitr/networks/unet.py:224-322; generator_network /
+discriminator_network, sequitr/networks/gan.py:149-316) be trained as written.
+
+The convolution / activation / pixel-norm / pooling / blend functions form a set that is CLOSED
+under differentiation: each backward is itself a composition of these functions, so
+``torch.autograd.grad(..., create_graph=True)`` works through them.  That is what the WGAN-GP
+penalty needs -- it differentiates the discriminator's input gradient w.r.t. the discriminator's
+weights (gan.py:719-729, ``tf.gradients`` inside the loss).
 """
 import torch
 
 from . import ops
 
 
+# ---------------------------------------------------------------------------------------------
+# convolution: ConvFwd / ConvDgrad / ConvWgrad are each other's derivatives
+# ---------------------------------------------------------------------------------------------
+class _ConvFwd(torch.autograd.Function):
+    """y = conv2d(x, w * wscale), no bias, no activation (linear in x and in w)."""
+
+    @staticmethod
+    def forward(ctx, x, w, wscale):
+        ctx.wscale = wscale
+        ctx.save_for_backward(x, w)
+        return ops.conv2d(x, w, None, act=None, wscale=wscale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = _ConvDgrad.apply(dy, w, ctx.wscale) if ctx.needs_input_grad[0] else None
+        dw = _ConvWgrad.apply(x, dy, w.shape[0], ctx.wscale) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class _ConvDgrad(torch.autograd.Function):
+    """dx = A_w^T dy, the adjoint of ConvFwd in x."""
+
+    @staticmethod
+    def forward(ctx, dy, w, wscale):
+        ctx.wscale = wscale
+        ctx.save_for_backward(dy, w)
+        return ops.conv_dgrad_raw(dy.contiguous(), w, wscale)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        dy, w = ctx.saved_tensors
+        d_dy = _ConvFwd.apply(ddx.contiguous(), w, ctx.wscale) if ctx.needs_input_grad[0] else None
+        d_w = _ConvWgrad.apply(ddx.contiguous(), dy, w.shape[0], ctx.wscale) if ctx.needs_input_grad[1] else None
+        return d_dy, d_w, None
+
+
+class _ConvWgrad(torch.autograd.Function):
+    """dw[tap,ci,co] = wscale * sum_p x[p+tap,ci] dy[p,co]  (bilinear in x and dy)."""
+
+    @staticmethod
+    def forward(ctx, x, dy, K, wscale):
+        ctx.K, ctx.wscale = K, wscale
+        ctx.save_for_backward(x, dy)
+        dw, _ = ops.conv_wgrad_raw(x, dy.contiguous(), K, want_bias=False)
+        return dw if wscale == 1.0 else dw * wscale
+
+    @staticmethod
+    def backward(ctx, ddw):
+        x, dy = ctx.saved_tensors
+        ddw = ddw.contiguous()
+        d_x = _ConvDgrad.apply(dy, ddw, ctx.wscale) if ctx.needs_input_grad[0] else None
+        d_dy = _ConvFwd.apply(x, ddw, ctx.wscale) if ctx.needs_input_grad[1] else None
+        return d_x, d_dy, None, None
+
+
+class _ActBwd(torch.autograd.Function):
+    """dpre = dy * act'(pre), decided from the activation output y (piecewise constant in y)."""
+
+    @staticmethod
+    def forward(ctx, dy, y, act):
+        ctx.act = act
+        ctx.save_for_backward(y)
+        return ops.act_bwd(dy.contiguous(), y, act)
+
+    @staticmethod
+    def backward(ctx, ddpre):
+        (y,) = ctx.saved_tensors
+        return _ActBwd.apply(ddpre, y, ctx.act), None, None
+
+
+class _Act(torch.autograd.Function):
+    """stand-alone activation (k_leaky_relu_alpha, gan.py:44-46)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        y = ops.act_fwd(x.contiguous(), act)
+        ctx.act = act
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return _ActBwd.apply(dy, y, ctx.act), None
+
+
+def act(x, kind):
+    return _Act.apply(x, kind) if ops.ACT[kind] else x
+
+
+class _ChannelSum(torch.autograd.Function):
+    """db[c] = sum over pixels of t[..., c]."""
+
+    @staticmethod
+    def forward(ctx, t):
+        ctx.shape = t.shape
+        C = t.shape[-1]
+        npix = t.numel() // C
+        t = t.contiguous()
+        if C % 4 == 0:
+            return ops.wgrad1x1_small(ops._ones(npix, 1, t.device), t).view(C)
+        return ops.wgrad1x1_small(t, ops._ones(npix, 4, t.device))[:, 0].contiguous()
+
+    @staticmethod
+    def backward(ctx, ddb):
+        return ddb.expand(ctx.shape).contiguous()             # never on the GAN / U-Net training paths
+
+
 class _Conv2d(torch.autograd.Function):
+    """Fused forward kernel: act(conv2d(x, w*wscale) + bias)."""
+
     @staticmethod
     def forward(ctx, x, w, bias, act, wscale):
         y = ops.conv2d(x, w, bias, act=act, wscale=wscale)
@@ -19,16 +136,21 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        dy = dy.contiguous()
-        dpre = ops.act_bwd(dy, y, ctx.act) if y is not None else dy
-        K = w.shape[0]
+        dpre = _ActBwd.apply(dy, y, ctx.act) if y is not None else dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_dgrad(dpre, w, wscale=ctx.wscale)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = ops.conv2d_wgrad(x, dpre, K, want_bias=ctx.has_bias)
+            dx = _ConvDgrad.apply(dpre, w, ctx.wscale)
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and not torch.is_grad_enabled():
+            # first-order fast path: dW and db from ONE pass of the wgrad kernel
+            dw, db = ops.conv_wgrad_raw(x, dpre, w.shape[0], want_bias=need_b)
             if ctx.wscale != 1.0:
                 dw = dw * ctx.wscale                     # w' = w * wscale (gan.py:79)
+        else:
+            if ctx.needs_input_grad[1]:
+                dw = _ConvWgrad.apply(x, dpre, w.shape[0], ctx.wscale)
+            if need_b:
+                db = _ChannelSum.apply(dpre)
         return dx, dw, db, None, None
 
 
@@ -36,8 +158,15 @@ def conv2d(x, w, bias=None, act=None, wscale=1.0):
     return _Conv2d.apply(x, w, bias, act, float(wscale))
 
 
+def dense(x, w, bias=None, act=None):
+    """tf.layers.dense on (N, Cin) with w (Cin, Cout): a 1x1 convolution over a row of N "pixels"."""
+    N, Cin = x.shape
+    y = conv2d(x.reshape(1, 1, N, Cin), w.reshape(1, 1, Cin, w.shape[1]), bias, act=act)
+    return y.reshape(N, w.shape[1])
+
+
 class _Head(torch.autograd.Function):
-    """1x1 conv to <= 4 channels (to_image), no activation."""
+    """1x1 conv to <= 4 channels (U-Net to_image), no activation; first-order only."""
 
     @staticmethod
     def forward(ctx, x, w, bias):
@@ -57,6 +186,81 @@ def conv1x1_head(x, w, bias=None):
     return _Head.apply(x, w, bias)
 
 
+# ---------------------------------------------------------------------------------------------
+# pixel norm (gan.py:49-51), up to second order
+# ---------------------------------------------------------------------------------------------
+class _PixelNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        ctx.eps = eps
+        ctx.save_for_backward(x)
+        return ops.pixelnorm(x, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return _PixelNormBwd.apply(x, dy, ctx.eps), None
+
+
+class _PixelNormBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, eps):
+        ctx.eps = eps
+        g = g.contiguous()
+        ctx.save_for_backward(x, g)
+        return ops.pixelnorm_bwd(x, g, eps)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v):
+        x, g = ctx.saved_tensors
+        dg, dx2 = ops.pixelnorm_bwd2(x, g, v.contiguous(), ctx.eps)
+        return dx2, dg, None
+
+
+def pixel_norm(x, epsilon=1e-8):
+    return _PixelNorm.apply(x, float(epsilon))
+
+
+# ---------------------------------------------------------------------------------------------
+# 2x2 pooling / broadcasting (avg-pool, double_size) -- each other's derivatives
+# ---------------------------------------------------------------------------------------------
+class _Pool2x2(torch.autograd.Function):
+    """scale * (sum of each 2x2 patch); scale 0.25 = tf.layers.average_pooling2d (gan.py:189-192)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        if scale == 0.25 and x.shape[-1] % 4 == 0:
+            return ops.avgpool2x2(x)                          # ((a+b)+(c+d))*0.25, the oracle's order
+        return ops.sumpool2x2(x.contiguous(), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _Bcast2x2.apply(dy, ctx.scale), None
+
+
+class _Bcast2x2(torch.autograd.Function):
+    """scale * nearest-neighbour 2x up-sampling; scale 1 = double_size (gan.py:133-136)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return ops.broadcast2x2(x.contiguous(), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _Pool2x2.apply(dy.contiguous(), ctx.scale), None
+
+
+def avgpool2x2(x):
+    return _Pool2x2.apply(x, 0.25)
+
+
+def double_size(x):
+    return _Bcast2x2.apply(x, 1.0)
+
+
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -64,6 +268,7 @@ class _MaxPool(torch.autograd.Function):
         return ops.maxpool2x2(x)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         return ops.maxpool2x2_bwd(x, dy.contiguous())
@@ -73,6 +278,81 @@ def maxpool2x2(x):
     return _MaxPool.apply(x)
 
 
+# ---------------------------------------------------------------------------------------------
+# per-sample scaling / dot products and blends (fade-in, real/fake interpolation, penalty norm)
+# ---------------------------------------------------------------------------------------------
+class _ScalePerSample(torch.autograd.Function):
+    """y[n] = s[n] * x[n]  (or (1 - s[n]) * x[n])."""
+
+    @staticmethod
+    def forward(ctx, x, s, one_minus):
+        ctx.one_minus = one_minus
+        ctx.save_for_backward(x, s)
+        return ops.scale(x.contiguous(), s, one_minus=one_minus)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = _ScalePerSample.apply(dy, s, ctx.one_minus) if ctx.needs_input_grad[0] else None
+        ds = None
+        if ctx.needs_input_grad[1]:
+            ds = _DotPerSample.apply(dy, x)
+            if ctx.one_minus:
+                ds = -ds
+        return dx, ds, None
+
+
+class _DotPerSample(torch.autograd.Function):
+    """out[n] = sum_i a[n,i] * b[n,i]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return ops.dot_per_sample(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b = ctx.saved_tensors
+        dout = dout.contiguous()
+        da = _ScalePerSample.apply(b, dout, False) if ctx.needs_input_grad[0] else None
+        db = _ScalePerSample.apply(a, dout, False) if ctx.needs_input_grad[1] else None
+        return da, db
+
+
+def scale_per_sample(x, s, one_minus=False):
+    return _ScalePerSample.apply(x, s, one_minus)
+
+
+def dot_per_sample(a, b):
+    return _DotPerSample.apply(a, b)
+
+
+def lerp(a, b, alpha):
+    """alpha*a + (1-alpha)*b with scalar alpha (fade-in, gan.py:687-694) or a per-sample (N,)
+    tensor (r of gan.py:709-714).  One fused kernel forward; gradients are per-sample scalings."""
+    if not isinstance(alpha, torch.Tensor):
+        alpha = torch.full((a.shape[0],), float(alpha), dtype=torch.float32, device=a.device)
+    return _Lerp.apply(a, b, alpha)
+
+
+class _Lerp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        ctx.save_for_backward(alpha)
+        return ops.lerp(a.contiguous(), b.contiguous(), alpha)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (alpha,) = ctx.saved_tensors
+        da = _ScalePerSample.apply(dy, alpha, False) if ctx.needs_input_grad[0] else None
+        db = _ScalePerSample.apply(dy, alpha, True) if ctx.needs_input_grad[1] else None
+        return da, db, None
+
+
+# ---------------------------------------------------------------------------------------------
+# U-Net-only pieces (first order)
+# ---------------------------------------------------------------------------------------------
 class _ConvT(torch.autograd.Function):
     """2x2/s2 transpose conv + bias.  Backward = space-to-depth, then a 1x1 dgrad and a 1x1 wgrad:
     convT(x) == depth_to_space(conv1x1(x, W')) with W'[c][(2a+b)*Cout + o] = W[a,b,o,c]."""
@@ -84,6 +364,7 @@ class _ConvT(torch.autograd.Function):
         return ops.convT2x2s2(x, w, bias)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         Cout, Cin = w.shape[2], w.shape[3]
@@ -112,6 +393,7 @@ class _Bridge(torch.autograd.Function):
         return ops.bridge(a, b, kind)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         a, b = ctx.saved_tensors if ctx.kind == 'eltwise_mul' else (None, None)
         da, db = ops.bridge_bwd(dy.contiguous(), a, b, ctx.kind)
@@ -131,6 +413,7 @@ class _Dropout(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         (m,) = ctx.saved_tensors
         return ops.dropout_bwd(dy.contiguous(), m, ctx.rate), None, None, None
@@ -153,6 +436,7 @@ class _WeightedSoftmaxCE(torch.autograd.Function):
         return loss.to(torch.float32)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dloss):
         (dz,) = ctx.saved_tensors
         return dz * dloss, None, None

@@ -1,0 +1,472 @@
+"""Progressive WGAN-GP on the MI355X HIP back end -- mirror of sequitr/networks/gan.py.
+
+Same module-level leaf functions (``k_leaky_relu_alpha``, ``pixel_norm``, ``weighted_conv2d``,
+``to_image``, ``from_image``, ``half_size``, ``double_size``; gan.py:44-136), the same
+``discriminator_network(x, filters)`` / ``generator_network(z, filters)`` wiring (gan.py:149-316),
+``GAN2DConfiguration`` (gan.py:418-440) and ``GenerativeAdverserialNetwork`` with ``build`` /
+``train`` / ``predict`` (gan.py:443-924).  TensorFlow's graph, session and variable scopes are
+replaced by eager HIP kernel launches and ``scope.VariableStore``; variable names are the
+reference's (``GAN/generator/latent/conv/filter`` ...).
+
+What differs on purpose: the data source is a ``.npy`` stack or synthetic
+tiles instead of a TFRecord (TFRecord IO is out of scope); checkpoints are ``model_(HxW).npz``;
+``predict`` uses its ``latent`` argument (the reference feeds an undefined global, gan.py:923);
+the minibatch-stdev statistic (0.26 M elements) and the (N,)-sized loss algebra run as torch
+tensor ops -- everything that touches an image-sized tensor is a hand-written HIP kernel.
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+
+from .. import functional as F
+from .. import ops
+from .. import utils
+from . import scope
+from .scope import variable_scope
+
+logger = logging.getLogger('worker_process')
+
+TRAIN = 'train'
+
+
+# ---- handy functions (gan.py:44-51) ---------------------------------------------------------------
+def k_leaky_relu_alpha(features, **kwargs):
+    """ leaky ReLU with alpha of 0.2 (stand-alone form; convolutions fuse it) """
+    return F.act(features, 'leaky')
+
+
+def pixel_norm(x, epsilon=1e-8):
+    """ x * rsqrt(mean(x^2, axis=-1) + eps), gan.py:49-51 """
+    return F.pixel_norm(x.contiguous(), epsilon)
+
+
+def _act_name(activation):
+    if activation is None:
+        return None
+    if activation in ('leaky', k_leaky_relu_alpha):
+        return 'leaky'
+    if activation == 'relu':
+        return 'relu'
+    raise ValueError('unsupported activation %r (None, k_leaky_relu_alpha, "leaky", "relu")' % (activation,))
+
+
+def weighted_conv2d(inputs=None, filters=None, kernel_size=[3, 3], padding="same",
+                    activation=k_leaky_relu_alpha, name='conv', reuse=None, norm=True):
+    """Equalised-learning-rate convolution (gan.py:61-99): kernel ~ N(0,1) scaled at run time by
+    sqrt(2 / (kh*kw*filters)), + bias (1,1,1,filters), activation, optional pixel norm."""
+    if padding.lower() != 'same':
+        raise ValueError('only SAME padding is implemented')
+    kh, kw = int(kernel_size[0]), int(kernel_size[1])
+    cin = int(inputs.shape[-1])
+    with variable_scope(name):
+        kernels = scope.get_variable('filter', (kh, kw, cin, filters), scope.random_normal)
+        bias = scope.get_variable('bias', (1, 1, 1, filters), scope.zeros)
+    wscale = float(np.sqrt(np.float32(2.0 / float(kh * kw * filters))))
+    out = F.conv2d(inputs, kernels, bias.view(-1), act=_act_name(activation), wscale=wscale)
+    if norm:
+        out = pixel_norm(out)
+    return out
+
+
+def to_image(X, filters=2, n=None):
+    """ 1x1 convolution to an image, no activation, no norm (gan.py:102-113) """
+    return weighted_conv2d(inputs=X, filters=filters, kernel_size=[1, 1], activation=None,
+                           name='to_image{}'.format(n), norm=False)
+
+
+def from_image(X, filters=2, n=None):
+    """ 1x1 convolution from an image, leaky + pixel norm (gan.py:115-125) """
+    return weighted_conv2d(inputs=X, filters=filters, kernel_size=[1, 1], activation=k_leaky_relu_alpha,
+                           name='from_image{}'.format(n), norm=True)
+
+
+def half_size(X):
+    """ resize_nearest_neighbor(align_corners=True) to half the size (gan.py:128-131) """
+    return ops.resize_nearest(X.contiguous(), (X.shape[1] // 2, X.shape[2] // 2))
+
+
+def double_size(X):
+    """ resize_nearest_neighbor(align_corners=True) to double the size (gan.py:133-136) """
+    return F.double_size(X)
+
+
+def dense(inputs, units, activation=None, name='dense'):
+    """tf.layers.dense on the last axis: glorot-uniform kernel (in, units), zero bias."""
+    cin = int(inputs.shape[-1])
+    with variable_scope(name):
+        kernel = scope.get_variable('kernel', (cin, units), scope.glorot_uniform)
+        bias = scope.get_variable('bias', (units,), scope.zeros)
+    lead = inputs.shape[:-1]
+    y = F.dense(inputs.reshape(-1, cin), kernel, bias, act=_act_name(activation))
+    return y.reshape(tuple(lead) + (units,))
+
+
+def minibatch_stdev(x):
+    """gan.py:204-212: sqrt(mean over (h,w,c) of the population variance over the batch), as a
+    constant feature map (N,4,4,1).  0.26 M elements: torch tensor ops (differentiable twice)."""
+    var = x.var(dim=0, unbiased=False).mean()
+    stdev = torch.sqrt(var)
+    return torch.ones((x.shape[0], 4, 4, 1), dtype=torch.float32, device=x.device) * stdev
+
+
+def discriminator_network(x, filters):
+    """gan.py:149-240.  Returns (conv_layers, logits (N,))."""
+    num_layers = len(filters)
+    with variable_scope("from_image"):
+        x = from_image(x, filters=filters[0], n=num_layers - 1)
+        conv_layers = [x]
+    for l, f in enumerate(filters[1:]):
+        with variable_scope("layer_{0:d}".format(num_layers - l - 1)):
+            conv1 = weighted_conv2d(inputs=conv_layers[-1], filters=f, kernel_size=[3, 3],
+                                    activation=k_leaky_relu_alpha, name='conv1', norm=False)
+            conv2 = weighted_conv2d(inputs=conv1, filters=f, kernel_size=[3, 3],
+                                    activation=k_leaky_relu_alpha, name='conv2', norm=False)
+            conv_layers.append(F.avgpool2x2(conv2))
+    x = conv_layers[-1]
+    with variable_scope('output'):
+        mbstd = minibatch_stdev(x)
+        conv = weighted_conv2d(inputs=x, filters=filters[-1], kernel_size=[3, 3],
+                               activation=k_leaky_relu_alpha, name='conv', norm=False)
+        conv = torch.cat([conv, mbstd], dim=-1)
+        pool_flat = conv.reshape(-1, 4 * 4 * (filters[-1] + 1))
+        hidden = dense(pool_flat, filters[-1], activation=k_leaky_relu_alpha, name='dense')
+        logits = dense(hidden, 1, name='logits')
+    return conv_layers, logits.reshape(-1)
+
+
+def generator_network(z, filters, start_shape=(4, 4)):
+    """gan.py:246-316.  Returns (list of per-level images, last image)."""
+    with variable_scope('latent'):
+        initial_shape = tuple(start_shape) + (filters[0],)
+        num_units = int(np.prod(initial_shape))
+        d = dense(pixel_norm(z), num_units, activation=k_leaky_relu_alpha, name='dense1')
+        reshaped = pixel_norm(d.reshape((-1,) + initial_shape))
+        conv0 = weighted_conv2d(inputs=reshaped, filters=filters[0], kernel_size=[3, 3],
+                                activation=k_leaky_relu_alpha, name='conv', norm=True)
+    conv_layers = [conv0]
+    for l, f in enumerate(filters[1:]):
+        with variable_scope('layer_{0:d}'.format(l)):
+            upscale = double_size(conv_layers[-1])
+            conv1 = weighted_conv2d(inputs=upscale, filters=f, kernel_size=[3, 3],
+                                    activation=k_leaky_relu_alpha, name='conv1', norm=True)
+            conv2 = weighted_conv2d(inputs=conv1, filters=f, kernel_size=[3, 3],
+                                    activation=k_leaky_relu_alpha, name='conv2', norm=True)
+            conv_layers.append(conv2)
+    outputs = []
+    with variable_scope("to_image"):
+        for l, conv in enumerate(conv_layers):
+            output = to_image(conv, filters=2, n=l)
+            outputs.append(output)
+    return outputs, output
+
+
+class GAN2DConfiguration(utils.NetConfiguration):
+    """ defaults of gan.py:418-440 """
+
+    def __init__(self, params=None):
+        utils.NetConfiguration.__init__(self)
+        self.name = 'GAN_competition'
+        self.batch_size = 32
+        self.repeat_batch = 4
+        self.num_outputs = 2
+        self.num_levels = 7
+        self.num_epochs_per_level = 1
+        self.start_size = (4, 4)
+        self.learning_rate = 1e-3
+        self.warm_start = False
+        self.path = ''
+        self.training_data = 'train_GAN.tfrecord'
+
+
+class _Adam(object):
+    """tf.train.AdamOptimizer(lr, beta1=0, beta2=0.99) (gan.py:736-751): per-variable slots, ONE
+    shared beta-power counter per optimiser, advanced by every minimize() that runs."""
+
+    def __init__(self, lr, beta1=0.0, beta2=0.99, eps=1e-8):
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.t = 0
+        self.slots = {}
+
+    def apply(self, named_vars, grads, grad_scale=1.0):
+        self.t += 1
+        for (name, v), g in zip(named_vars, grads):
+            if g is None:
+                continue
+            if name not in self.slots:
+                self.slots[name] = (torch.zeros_like(v), torch.zeros_like(v))
+            m, s = self.slots[name]
+            ops.adam_step(v.detach().view(-1), g.contiguous().view(-1), m.view(-1), s.view(-1), self.lr, self.b1,
+                          self.b2, self.eps, self.t, grad_scale=grad_scale)
+
+
+class GenerativeAdverserialNetwork(object):
+    """ProGAN-style WGAN-GP (gan.py:443-924).
+
+    params: num_outputs, batch_size, repeat_batch, num_levels, num_epochs_per_level, start_size,
+    training_data (``.npy`` (N,H,W,C) stack; None -> synthetic tiles), learning_rate; new keys:
+    device, seed, num_batches_per_epoch (when the data is synthetic)."""
+
+    def __init__(self, params, mode=None, discriminator_fn=discriminator_network,
+                 generator_fn=generator_network):
+        self.__discriminator_fn = discriminator_fn
+        self.__generator_fn = generator_fn
+        self.initialized = False
+        self.__num_channels = params.get('num_outputs', 2)
+        self.batch_size = params.get('batch_size', 32)
+        self.repeat_batch = params.get('repeat_batch', 1)
+        self.num_levels = params.get('num_levels', 3)
+        self.num_epochs_per_level = params.get('num_epochs_per_level', 10)
+        self.start_size = params.get('start_size', (4, 4))
+        self.training_data_filename = params.get('training_data', None)
+        self.learning_rate = params.get('learning_rate', 1e-3)
+        dev = params.get('device', None)
+        self.device = torch.device(dev) if dev is not None else torch.device('cuda', torch.cuda.current_device())
+        if self.device.type != 'cuda':
+            raise RuntimeError('GenerativeAdverserialNetwork runs on the HIP back end only')
+        self.seed = params.get('seed', 0)
+        self.store = scope.VariableStore(self.device, seed=self.seed, trainable=True)
+        self._torch_rng = torch.Generator(device=self.device)
+        self._torch_rng.manual_seed(self.seed)
+        self.group = params.get('process_group', None)
+
+        self.dataset = None
+        self.num_batches_per_epoch = params.get('num_batches_per_epoch', 1)
+        if mode == TRAIN and self.training_data_filename:
+            fn = self.training_data_filename
+            if not (isinstance(fn, str) and fn.endswith('.npy')):
+                raise IOError('training_data must be a .npy stack (TFRecord IO is out of scope): %r' % (fn,))
+            self.dataset = np.load(fn, mmap_mode='r', allow_pickle=False)
+            self.num_batches_per_epoch = max(1, int(len(self.dataset) / self.batch_size))
+
+        self.restore = False
+        self.networks = []
+        self.mode = mode
+        self.__params = params
+        self.__level = 0
+        self.global_step = 0
+        self.output_dir = params.get('output', None)
+        self.filters = utils.filter_doubling(start_filters=8, num_layers=self.num_levels,
+                                             max_filters=512, reverse=True)
+        self.d_opt = self.g_opt = None
+        self.last_losses = None
+
+    # -- properties / helpers, gan.py:542-568 ---------------------------------------------------------
+    @property
+    def num_channels(self):
+        return self.__num_channels
+
+    @property
+    def current_level(self):
+        return self.__level
+
+    @property
+    def num_iterations_this_level(self):
+        return self.num_epochs_per_level * self.num_batches_per_epoch
+
+    def get_size(self, level):
+        return tuple([s * (2 ** level) for s in self.start_size])
+
+    @property
+    def current_size(self):
+        return self.get_size(self.current_level)
+
+    def expand(self):
+        self.__level += 1
+        assert (self.__level <= self.num_levels)
+
+    def set_level(self, level):
+        assert 0 <= level < self.num_levels
+        self.__level = level
+
+    def generator(self, Z, filters, **kwargs):
+        with self.store, variable_scope('GAN'), variable_scope('generator'):
+            return self.__generator_fn(Z, filters, **kwargs)
+
+    def discriminator(self, X, filters, **kwargs):
+        with self.store, variable_scope('GAN'), variable_scope('discriminator'):
+            return self.__discriminator_fn(X, filters, **kwargs)
+
+    # -- variable lists, gan.py:586-614 (including the layer-naming quirk) -----------
+    def get_training_variables(self, current_layer):
+        tv = self.store.trainable_variables
+        d_vars = self.discriminator_training_variables(current_layer)
+        g_vars = self.generator_training_variables(current_layer)
+        d_vars = d_vars + tv('GAN/discriminator/from_image/from_image{0:d}'.format(current_layer))
+        g_vars = g_vars + tv('GAN/generator/to_image/to_image{0:d}'.format(current_layer))
+        return d_vars, g_vars
+
+    def generator_training_variables(self, current_layer):
+        tv = self.store.trainable_variables
+        out = []
+        for layer in range(current_layer):
+            out += tv('GAN/generator/layer_{0:d}'.format(layer))
+        return out + tv('GAN/generator/latent')
+
+    def discriminator_training_variables(self, current_layer):
+        tv = self.store.trainable_variables
+        out = []
+        for layer in range(current_layer):
+            out += tv('GAN/discriminator/layer_{0:d}'.format(layer))
+        return out + tv('GAN/discriminator/output')
+
+    # -- build, gan.py:619-657 -------------------------------------------------------------------------
+    def build(self):
+        """Create every level's variables (one probe batch per level) and the two optimisers."""
+        self.d_opt, self.g_opt = self._build_optimizers()
+        self.networks = []
+        self.__level = 0
+        with torch.no_grad():
+            for i in range(self.num_levels):
+                z = torch.zeros((1, 1, 1, 512), dtype=torch.float32, device=self.device)
+                x = torch.zeros((1,) + self.current_size + (self.num_channels,), dtype=torch.float32, device=self.device)
+                filters = self.filters[:(i + 1)]
+                self.generator(z, filters)
+                self.discriminator(x, filters[::-1])
+                self.networks.append((i, 'd_loss', 'g_loss', 'd_solver', 'g_solver'))
+                self.expand()
+        self.__level = 0
+        self.initialized = True
+
+    def _build_optimizers(self, level=0):
+        return _Adam(self.learning_rate, 0.0, 0.99), _Adam(self.learning_rate, 0.0, 0.99)
+
+    def _mixing_r(self, n):
+        return torch.rand((n,), generator=self._torch_rng, dtype=torch.float32, device=self.device)
+
+    def _prepare(self, X, Z, alpha, need_g_graph):
+        """Forward of gan.py:665-714 up to the three discriminator inputs."""
+        num_layers = self.current_level
+        filters = self.filters[:(num_layers + 1)]
+        g_layers, Gz_raw = self.generator(Z, filters)
+        if tuple(X.shape[1:3]) != tuple(self.current_size):
+            raise ValueError('X must already be at the current size %s (bilinear resize of the real '
+                             'data is host-side IO, gan.py:682-684)' % (self.current_size,))
+        X_resized = X
+        if num_layers > 0:
+            prev_Gz = double_size(g_layers[-2])
+            Gz = F.lerp(Gz_raw, prev_Gz, alpha)
+            prev_X = ops.broadcast2x2(half_size(X_resized), 1.0)
+            X_resized = ops.lerp(X_resized, prev_X, alpha)
+        else:
+            Gz = Gz_raw
+        if not need_g_graph:
+            Gz = Gz.detach()
+        return filters[::-1], Gz_raw, Gz, X_resized
+
+    def _build_network(self, X, Z, alpha, r=None, need_g_graph=True):
+        """Losses of the current level (gan.py:665-732): returns (Gz_raw, d_loss, g_loss) with the
+        autograd graph attached (d_loss w.r.t. the discriminator, g_loss w.r.t. the generator
+        unless need_g_graph is False -- the discriminator step never needs it)."""
+        d_filters, Gz_raw, Gz, X_resized = self._prepare(X, Z, alpha, need_g_graph=need_g_graph)
+        _, Dz = self.discriminator(Gz, d_filters)
+        _, Dx = self.discriminator(X_resized, d_filters)
+        if r is None:
+            r = self._mixing_r(X.shape[0])
+        mix = F.lerp(X_resized, Gz.detach(), r).detach().requires_grad_(True)
+        _, Dmix = self.discriminator(mix, d_filters)
+        grad = torch.autograd.grad(Dmix.sum(), mix, create_graph=True)[0]
+        grad_normed = torch.sqrt(F.dot_per_sample(grad, grad))
+        lipschitz_penalty = torch.square(torch.clamp(grad_normed - 1.0, min=0.0))
+        scaled_penalty = 10.0 * lipschitz_penalty
+        eps_penalty = 0.001 * torch.square(Dx)
+        g_loss = torch.mean(-Dz)
+        d_loss = torch.mean(-Dx + Dz + scaled_penalty + eps_penalty)
+        return Gz_raw, d_loss, g_loss
+
+    def _allreduce(self, grads):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return 1.0
+        live = [g for g in grads if g is not None]
+        flat = torch.cat([g.reshape(-1) for g in live])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)       # ONE collective per solver step
+        o = 0
+        for g in live:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+        return 1.0 / dist.get_world_size(self.group)
+
+    def d_solver(self, X, Z, alpha, r=None):
+        """d_opt.minimize(d_loss, var_list=d_vars) for the current level (gan.py:649)."""
+        level = self.current_level
+        d_vars, _ = self.get_training_variables(level)
+        _, d_loss, g_loss = self._build_network(X, Z, alpha, r=r, need_g_graph=False)
+        grads = torch.autograd.grad(d_loss, [v for _, v in d_vars], allow_unused=True)
+        scale = self._allreduce(grads)
+        self.d_opt.apply(d_vars, grads, grad_scale=scale)
+        self.last_losses = (float(d_loss.detach()), float(g_loss.detach()))
+        return d_loss.detach()
+
+    def g_solver(self, X, Z, alpha):
+        """g_opt.minimize(g_loss, var_list=g_vars, global_step) for the current level (gan.py:650-651)."""
+        level = self.current_level
+        _, g_vars = self.get_training_variables(level)
+        d_filters, _, Gz, _ = self._prepare(X, Z, alpha, need_g_graph=True)
+        _, Dz = self.discriminator(Gz, d_filters)
+        g_loss = torch.mean(-Dz)
+        grads = torch.autograd.grad(g_loss, [v for _, v in g_vars], allow_unused=True)
+        scale = self._allreduce(grads)
+        self.g_opt.apply(g_vars, grads, grad_scale=scale)
+        self.global_step += 1
+        return g_loss.detach()
+
+    # -- data -----------------------------------------------------------------------------------------
+    def build_latent(self):
+        return torch.randn((self.batch_size, 1, 1, 512), generator=self._torch_rng, dtype=torch.float32,
+                           device=self.device)
+
+    def _next_real_batch(self, step):
+        size = self.current_size
+        if self.dataset is None:
+            g = torch.Generator(device=self.device)
+            g.manual_seed(self.seed * 7919 + step)
+            return torch.randn((self.batch_size,) + size + (self.num_channels,), generator=g,
+                               dtype=torch.float32, device=self.device)
+        n = len(self.dataset)
+        idx = [(step * self.batch_size + k) % n for k in range(self.batch_size)]
+        x = torch.from_numpy(np.ascontiguousarray(self.dataset[sorted(idx)], dtype=np.float32)).to(self.device)
+        if tuple(x.shape[1:3]) != size:                      # stored at full size: area-free nearest pick
+            x = ops.resize_nearest(x, size)
+        return x
+
+    # -- train, gan.py:782-870 ---------------------------------------------------------------------------
+    def train(self, max_steps_per_phase=None):
+        if not self.initialized:
+            raise Exception("Networks have not been initialized. Please run .build()")
+        if self.output_dir:
+            utils.check_and_makedir(self.output_dir)
+        step_id = 0
+        for n in range(0, len(self.networks)):
+            self.set_level(n)
+            iters = self.num_iterations_this_level
+            if max_steps_per_phase:
+                iters = min(iters, max_steps_per_phase)
+            for phase in ('fade', 'stabilisation'):
+                for step in range(iters):
+                    fade = float(step + 1) / iters if phase == 'fade' else 1.0
+                    z, x = self.build_latent(), self._next_real_batch(step_id)
+                    step_id += 1
+                    for _ in range(self.repeat_batch):
+                        self.d_solver(x, z, fade)
+                        self.g_solver(x, z, fade)
+                    logger.info('{0} {1} {2} {3}'.format(self.global_step, phase, self.get_size(n), fade))
+            if self.output_dir:
+                sz_fn = str(self.get_size(n)).replace(', ', 'x')
+                np.savez(os.path.join(self.output_dir, "model_{0:s}.npz".format(sz_fn)), **self.store.state_dict())
+
+    def load_checkpoint(self, filename):
+        with np.load(filename, allow_pickle=False) as z:
+            self.store.load_state_dict({k: z[k] for k in z.files})
+        self.initialized = True
+
+    def predict(self, latent=None, level=None, alpha=1.0):
+        """Generate images from latent vectors (N,1,1,512) at `level` (default: the last)."""
+        if latent is None:
+            raise Exception('You must provide latent variables to the model.')
+        level = self.num_levels - 1 if level is None else level
+        z = torch.as_tensor(np.asarray(latent), dtype=torch.float32).to(self.device).reshape(-1, 1, 1, 512)
+        with torch.no_grad():
+            _, out = self.generator(z, self.filters[:(level + 1)])
+        return out

@@ -258,12 +258,13 @@ def broadcast2x2(src, scale=1.0):
     return dst
 
 
-def sumpool2x2(x):
+def sumpool2x2(x, scale=1.0):
+    """scale * (sum of every 2x2 patch); any channel count."""
     _chk(x, "x", ndim=4)
     N, H, W, C = x.shape
     y = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.sq_sumpool2x2_f32(_ptr(x), _ptr(y), N, H, W, C, _stream()), "sq_sumpool2x2_f32")
+    _lib.check(lib.sq_sumpool2x2_f32(_ptr(x), _ptr(y), N, H, W, C, float(scale), _stream()), "sq_sumpool2x2_f32")
     return y
 
 
@@ -337,3 +338,159 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     _lib.check(lib.sq_adam_step_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
                                    float(beta2), float(eps), int(step), float(grad_scale), _stream()),
                "sq_adam_step_f32")
+
+
+# ----------------------------------------------------------------------------------------------
+# GAN-side operators (include/sequitr_hip.h "GAN side")
+# ----------------------------------------------------------------------------------------------
+def pixelnorm_bwd(x, dy, eps=1e-8):
+    _chk(x, "x"), _chk(dy, "dy")
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.sq_pixelnorm_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), x.numel() // C, C, float(eps), _stream()),
+               "sq_pixelnorm_bwd_f32")
+    return dx
+
+
+def pixelnorm_bwd2(x, g, v, eps=1e-8):
+    """second-order: (dL/dg, dL/dx) of dx = pixelnorm_bwd(x, g) given v = dL/d(dx)."""
+    _chk(x, "x"), _chk(g, "g"), _chk(v, "v")
+    C = x.shape[-1]
+    dg, dx2 = torch.empty_like(x), torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.sq_pixelnorm_bwd2_f32(_ptr(x), _ptr(g), _ptr(v), _ptr(dg), _ptr(dx2), x.numel() // C, C,
+                                        float(eps), _stream()), "sq_pixelnorm_bwd2_f32")
+    return dg, dx2
+
+
+def resize_nearest(x, size):
+    """tf.image.resize_nearest_neighbor(x, size, align_corners=True)."""
+    _chk(x, "x", ndim=4)
+    N, Hi, Wi, C = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_resize_nearest_f32(_ptr(x), _ptr(y), N, Hi, Wi, Ho, Wo, C, _stream()), "sq_resize_nearest_f32")
+    return y
+
+
+def lerp(a, b, alpha):
+    """alpha*a + (1-alpha)*b; alpha a python float or a per-sample (N,) device tensor."""
+    _chk(a, "a"), _chk(b, "b")
+    if a.shape != b.shape:
+        raise ValueError("lerp operands differ in shape")
+    y = torch.empty_like(a)
+    per = a.numel() // a.shape[0]
+    lib = _lib.load()
+    if isinstance(alpha, torch.Tensor):
+        _chk(alpha, "alpha")
+        _lib.check(lib.sq_lerp_f32(_ptr(a), _ptr(b), _ptr(y), a.numel(), per, 0.0, _ptr(alpha), _stream()), "sq_lerp_f32")
+    else:
+        _lib.check(lib.sq_lerp_f32(_ptr(a), _ptr(b), _ptr(y), a.numel(), per, float(alpha), None, _stream()), "sq_lerp_f32")
+    return y
+
+
+def scale(x, s, one_minus=False):
+    """s*x (or (1-s)*x); s a python float or a per-sample (N,) device tensor."""
+    _chk(x, "x")
+    y = torch.empty_like(x)
+    per = x.numel() // x.shape[0]
+    lib = _lib.load()
+    if isinstance(s, torch.Tensor):
+        _chk(s, "s")
+        _lib.check(lib.sq_scale_f32(_ptr(x), _ptr(y), x.numel(), per, 0.0, _ptr(s), int(one_minus), _stream()), "sq_scale_f32")
+    else:
+        _lib.check(lib.sq_scale_f32(_ptr(x), _ptr(y), x.numel(), per, float(s), None, int(one_minus), _stream()), "sq_scale_f32")
+    return y
+
+
+def act_fwd(x, act):
+    _chk(x, "x")
+    if ACT[act] == 0:
+        return x
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.sq_act_fwd_f32(_ptr(x), _ptr(y), x.numel(), ACT[act], _stream()), "sq_act_fwd_f32")
+    return y
+
+
+def dot_per_sample(a, b):
+    """(N,) tensor of sum_i a[n,i]*b[n,i]."""
+    _chk(a, "a"), _chk(b, "b")
+    N = a.shape[0]
+    out = torch.empty((N,), dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    ws = _workspace(lib.sq_dot_per_sample_workspace_f32(N), a.device)
+    _lib.check(lib.sq_dot_per_sample_f32(_ptr(a), _ptr(b), _ptr(out), _ptr(ws), N, a.numel() // N, _stream()),
+               "sq_dot_per_sample_f32")
+    return out
+
+
+def mbstd(x):
+    """minibatch stdev scalar (0-d device tensor) of x (N, ...)."""
+    _chk(x, "x")
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    ws = _workspace(1024, x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_mbstd_fwd_f32(_ptr(x), _ptr(out), _ptr(ws), x.shape[0], x.numel() // x.shape[0], _stream()),
+               "sq_mbstd_fwd_f32")
+    return out
+
+
+def wgrad1x1_small(a, b):
+    """(Ca,Cb) = sum_p a[p,:]^T b[p,:]; a (...,Ca<=4), b (...,Cb%4==0) over the same pixels."""
+    _chk(a, "a"), _chk(b, "b")
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    npix = a.numel() // Ca
+    if b.numel() // Cb != npix:
+        raise ValueError("wgrad1x1_small: operands cover different pixel counts")
+    lib = _lib.load()
+    nbytes = lib.sq_wgrad1x1_small_workspace_f32(npix, Ca, Cb)
+    if nbytes < 0:
+        raise _lib.SequitrHipError("wgrad1x1_small: unsupported Ca=%d Cb=%d" % (Ca, Cb))
+    ws = _workspace(nbytes, a.device)
+    m = torch.empty((Ca, Cb), dtype=torch.float32, device=a.device)
+    _lib.check(lib.sq_wgrad1x1_small_f32(_ptr(a), _ptr(b), _ptr(m), _ptr(ws), npix, Ca, Cb, _stream()),
+               "sq_wgrad1x1_small_f32")
+    return m
+
+
+# ---- shape-dispatching raw gradients of conv2d (used by sequitr_amd.functional) -----------------
+_ONES_CACHE = {}
+
+
+def _ones(npix, c, device):
+    key = (device.index, c)
+    t = _ONES_CACHE.get(key)
+    if t is None or t.shape[0] < npix:
+        t = torch.ones((npix, c), dtype=torch.float32, device=device)
+        _ONES_CACHE[key] = t
+    return t[:npix]
+
+
+def conv_dgrad_raw(dy, w, wscale=1.0):
+    """dX (N,H,W,Cin) of y = conv2d(x, w*wscale) given dY (N,H,W,Cout); any supported channel mix."""
+    K, _, Cin, Cout = w.shape
+    if Cin % 4 != 0 and not (K == 1 and Cin <= 4):
+        raise _lib.SequitrHipError("conv dgrad to %d channels with K=%d is not supported" % (Cin, K))
+    return conv2d(dy, conv_weight_transform(w), None, act=None, wscale=wscale)
+
+
+def conv_wgrad_raw(x, dy, K, want_bias=False):
+    """(dW (K,K,Cin,Cout), db or None) for every channel mix the GAN / U-Net graphs use."""
+    Cin, Cout = x.shape[-1], dy.shape[-1]
+    N, H, W = x.shape[0], x.shape[1], x.shape[2]
+    lib = _lib.load()
+    if Cout % 4 == 0 and lib.sq_conv2d_nhwc_wgrad_workspace_f32(N, H, W, Cin, Cout, K) >= 0:
+        return conv2d_wgrad(x, dy, K, want_bias=want_bias)
+    npix = N * H * W
+    if K == 1 and Cin <= 4 and Cout % 4 == 0:                      # from_image: image side is the input
+        dw = wgrad1x1_small(x, dy).view(1, 1, Cin, Cout)
+        db = wgrad1x1_small(_ones(npix, 1, x.device), dy).view(Cout) if want_bias else None
+        return dw, db
+    if K == 1 and Cout <= 4 and Cin % 4 == 0:                      # to_image: image side is the output
+        dw = wgrad1x1_small(dy, x).t().contiguous().view(1, 1, Cin, Cout)
+        db = wgrad1x1_small(dy, _ones(npix, 4, x.device))[:, 0].contiguous() if want_bias else None
+        return dw, db
+    raise _lib.SequitrHipError("conv wgrad: unsupported Cin=%d Cout=%d K=%d" % (Cin, Cout, K))

@@ -1,0 +1,224 @@
+"""GPU: the progressive WGAN-GP (sequitr/networks/gan.py) on the HIP back end vs the fp64 torch
+restatement oracle/torch_gan_ref.py: leaf ops, generator / discriminator forward, the losses with
+the gradient penalty (second-order autograd through the hand-written kernels), the per-level
+variable lists (including the reference's layer-naming quirk) and one D + G optimiser step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import torch_gan_ref as ref
+from sequitr_amd import functional as F
+from sequitr_amd import ops
+from sequitr_amd.networks import gan
+from tests.util import tiles, rand_weights, assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(got, want, tol, what=""):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = float(np.max(np.abs(got - want))) / max(float(np.max(np.abs(want))), 1e-30)
+    assert err <= tol, "%s: rel err %.3g > %.3g" % (what, err, tol)
+
+
+def test_leaf_ops_vs_oracle():
+    x = tiles(1, 2, 8, 8, 16)
+    w = rand_weights(2, (3, 3, 16, 32), 1.0)
+    b = rand_weights(3, (32,), 0.1)
+    ws = float(np.sqrt(np.float32(2.0 / (9 * 32))))
+    assert_bit_exact(ops.conv2d(dev(x), dev(w), dev(b), act="leaky", wscale=ws).cpu().numpy(),
+                     co.conv2d(x, w, b, act="leaky", wscale=ws), "weighted_conv2d core")
+    assert_bit_exact(ops.broadcast2x2(dev(x), 1.0).cpu().numpy(), co.upsample_nn2x(x), "double_size")
+    assert_bit_exact(ops.avgpool2x2(dev(x)).cpu().numpy(), co.avgpool2x2(x), "avg pool")
+    for n in (8, 16, 32):                                          # half_size picks rows 0,2,5,7 for 8 -> 4
+        img = tiles(4, 1, n, n, 2)
+        got = ops.resize_nearest(dev(img), (n // 2, n // 2)).cpu().numpy()
+        assert np.array_equal(got, ref.half_size(torch.as_tensor(img)).numpy())
+    idx = ops.resize_nearest(dev(np.arange(8, dtype=np.float32).reshape(1, 8, 1, 1)), (4, 1)).cpu().numpy().ravel()
+    assert idx.tolist() == [0.0, 2.0, 5.0, 7.0]
+    xs = tiles(5, 6, 4, 4, 32)
+    want = float(np.sqrt(xs.astype(np.float64).var(0).mean()))
+    assert abs(ops.mbstd(dev(xs)).item() - want) <= 1e-6 * want
+    a, b2 = tiles(6, 3, 8, 8, 4), tiles(7, 3, 8, 8, 4)
+    r = np.array([0.25, 0.5, 1.0], np.float32)
+    assert np.allclose(ops.lerp(dev(a), dev(b2), dev(r)).cpu().numpy(), r[:, None, None, None] * a + (1 - r[:, None, None, None]) * b2, atol=1e-6)
+    assert np.allclose(ops.lerp(dev(a), dev(b2), 0.3).cpu().numpy(), 0.3 * a + 0.7 * b2, atol=1e-6)
+    assert np.allclose(ops.dot_per_sample(dev(a), dev(b2)).cpu().numpy(), (a * b2).reshape(3, -1).sum(1), rtol=1e-5)
+    m = ops.wgrad1x1_small(dev(tiles(8, 2, 8, 8, 2)), dev(tiles(9, 2, 8, 8, 16))).cpu().numpy()
+    assert np.allclose(m, tiles(8, 2, 8, 8, 2).reshape(-1, 2).T @ tiles(9, 2, 8, 8, 16).reshape(-1, 16), rtol=1e-5, atol=1e-5)
+
+
+def test_pixelnorm_first_and_second_order():
+    x, g, v = tiles(10, 2, 4, 4, 32), tiles(11, 2, 4, 4, 32), tiles(12, 2, 4, 4, 32)
+    xt = torch.as_tensor(x, dtype=torch.float64).requires_grad_(True)
+    gt = torch.as_tensor(g, dtype=torch.float64).requires_grad_(True)
+    dx = torch.autograd.grad(ref.pixel_norm(xt), xt, gt, create_graph=True)[0]
+    dx2, dg = torch.autograd.grad(dx, [xt, gt], torch.as_tensor(v, dtype=torch.float64))
+    close(ops.pixelnorm_bwd(dev(x), dev(g)).cpu().numpy(), dx.detach().numpy(), 1e-5, "pixelnorm bwd")
+    got_dg, got_dx2 = ops.pixelnorm_bwd2(dev(x), dev(g), dev(v))
+    close(got_dg.cpu().numpy(), dg.numpy(), 1e-5, "pixelnorm bwd2 dg")
+    close(got_dx2.cpu().numpy(), dx2.numpy(), 1e-5, "pixelnorm bwd2 dx")
+
+
+def test_double_backward_through_conv_stack():
+    """grad-of-grad: penalty-style objective through conv(leaky) -> pixel_norm -> avgpool -> conv."""
+    x = tiles(13, 2, 8, 8, 2)
+    p = {"w0": rand_weights(14, (1, 1, 2, 16), 1.0), "b0": rand_weights(15, (16,), 0.1),
+         "w1": rand_weights(16, (3, 3, 16, 16), 1.0), "b1": rand_weights(17, (16,), 0.1)}
+
+    def run(xin, P, conv, pn, pool):
+        h = pn(conv(xin, P["w0"], P["b0"], 0.7))
+        h = pool(conv(h, P["w1"], P["b1"], 0.2))
+        return h
+
+    P = {k: dev(v).requires_grad_(True) for k, v in p.items()}
+    xin = dev(x).requires_grad_(True)
+    out = run(xin, P, lambda t, w, b, s: F.conv2d(t, w, b, act="leaky", wscale=s), F.pixel_norm, F.avgpool2x2)
+    g = torch.autograd.grad(out.sum(), xin, create_graph=True)[0]
+    obj = torch.square(torch.sqrt(F.dot_per_sample(g, g)) - 1.0).sum()
+    got = torch.autograd.grad(obj, [P[k] for k in sorted(P)])
+
+    R = {k: torch.as_tensor(v, dtype=torch.float64).requires_grad_(True) for k, v in p.items()}
+    xr = torch.as_tensor(x, dtype=torch.float64).requires_grad_(True)
+
+    def rconv(t, w, b, s):
+        y = torch.nn.functional.conv2d(t.permute(0, 3, 1, 2), (w * s).permute(3, 2, 0, 1), b, padding=w.shape[0] // 2)
+        return ref.lrelu(y.permute(0, 2, 3, 1))
+
+    outr = run(xr, R, rconv, ref.pixel_norm, ref.avgpool)
+    gr = torch.autograd.grad(outr.sum(), xr, create_graph=True)[0]
+    objr = torch.square(torch.sqrt((gr * gr).sum((1, 2, 3))) - 1.0).sum()
+    want = torch.autograd.grad(objr, [R[k] for k in sorted(R)])
+    close(g.detach().cpu().numpy(), gr.detach().numpy(), 1e-5, "input gradient")
+    assert abs(obj.item() - objr.item()) <= 1e-4 * abs(objr.item())
+    for k, a, b in zip(sorted(P), got, want):
+        close(a.cpu().numpy(), b.numpy(), 2e-4, "d obj / d " + k)
+
+
+PARAMS = {"num_levels": 3, "batch_size": 4, "repeat_batch": 1, "num_epochs_per_level": 1, "learning_rate": 1e-3,
+          "device": "cuda:0", "seed": 3, "num_batches_per_epoch": 2}
+
+
+def make_gan(**kw):
+    g = gan.GenerativeAdverserialNetwork(dict(PARAMS, **kw), mode=None)
+    g.build()
+    return g
+
+
+def test_build_creates_reference_variable_names_and_var_lists():
+    g = make_gan()
+    assert g.filters == [32, 16, 8] and g.get_size(2) == (16, 16)
+    names = list(g.store.vars)
+    for n in ("GAN/generator/latent/dense1/kernel", "GAN/generator/latent/conv/filter", "GAN/generator/layer_0/conv1/filter",
+              "GAN/generator/layer_1/conv2/bias", "GAN/generator/to_image/to_image2/filter",
+              "GAN/discriminator/from_image/from_image0/filter", "GAN/discriminator/from_image/from_image2/bias",
+              "GAN/discriminator/layer_1/conv1/filter", "GAN/discriminator/layer_2/conv2/filter",
+              "GAN/discriminator/output/conv/filter", "GAN/discriminator/output/dense/kernel",
+              "GAN/discriminator/output/logits/bias"):
+        assert n in names, n
+    assert g.store.vars["GAN/generator/latent/dense1/kernel"].shape == (512, 16 * 32)
+    assert g.store.vars["GAN/discriminator/output/dense/kernel"].shape == (16 * 33, 32)
+    assert g.store.vars["GAN/discriminator/from_image/from_image2/filter"].shape == (1, 1, 2, 8)
+    assert not any("discriminator/layer_0" in n for n in names)            # blocks are named layer_L .. layer_1
+    d2, g2 = g.get_training_variables(2)
+    dn, gn = [n for n, _ in d2], [n for n, _ in g2]
+    assert any("discriminator/layer_1/" in n for n in dn) and any("from_image2" in n for n in dn)
+    assert not any("discriminator/layer_2/" in n for n in dn)              # the newest block is NOT trained (a25)
+    assert any("generator/layer_1/" in n for n in gn) and any("to_image2" in n for n in gn) and any("latent" in n for n in gn)
+    assert not any("to_image1" in n for n in gn)
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_generator_discriminator_forward_vs_fp64(level):
+    g = make_gan()
+    W = ref.to_torch(g.store.state_dict(), requires_grad=False)
+    f = g.filters[:level + 1]
+    z = np.random.default_rng(0).standard_normal((4, 1, 1, 512)).astype(np.float32)
+    with torch.no_grad():
+        outs, last = g.generator(dev(z), f)
+    routs, rlast = ref.generator(torch.as_tensor(z, dtype=torch.float64), W, f)
+    assert len(outs) == level + 1 and tuple(last.shape) == (4,) + g.get_size(level) + (2,)
+    for a, b in zip(outs, routs):
+        close(a.cpu().numpy(), b.numpy(), 2e-5, "generator image")
+    x = np.random.default_rng(1).standard_normal((4,) + g.get_size(level) + (2,)).astype(np.float32)
+    with torch.no_grad():
+        layers, logits = g.discriminator(dev(x), f[::-1])
+    close(logits.cpu().numpy(), ref.discriminator(torch.as_tensor(x, dtype=torch.float64), W, f[::-1]).numpy(), 2e-5, "D logits")
+    assert len(layers) == level + 1
+
+
+@pytest.mark.parametrize("level,alpha", [(0, 1.0), (2, 0.4), (2, 1.0)])
+def test_losses_and_gradients_vs_fp64(level, alpha):
+    g = make_gan()
+    g.set_level(level)
+    rng = np.random.default_rng(2)
+    z = rng.standard_normal((4, 1, 1, 512)).astype(np.float32)
+    x = rng.standard_normal((4,) + g.get_size(level) + (2,)).astype(np.float32)
+    r = rng.random(4).astype(np.float32)
+    _, d_loss, g_loss = g._build_network(dev(x), dev(z), alpha, r=dev(r))
+    d_vars, g_vars = g.get_training_variables(level)
+    dg = torch.autograd.grad(d_loss, [v for _, v in d_vars], retain_graph=True, allow_unused=True)
+    gg = torch.autograd.grad(g_loss, [v for _, v in g_vars], allow_unused=True)
+
+    W = ref.to_torch(g.store.state_dict())
+    _, rd, rg = ref.losses(torch.as_tensor(x, dtype=torch.float64), torch.as_tensor(z, dtype=torch.float64), alpha,
+                           torch.as_tensor(r, dtype=torch.float64), W, g.filters, level)
+    assert abs(d_loss.item() - rd.item()) <= 2e-4 * max(1.0, abs(rd.item()))
+    assert abs(g_loss.item() - rg.item()) <= 2e-4 * max(1.0, abs(rg.item()))
+    rdg = torch.autograd.grad(rd, [W[n] for n, _ in d_vars], retain_graph=True, allow_unused=True)
+    rgg = torch.autograd.grad(rg, [W[n] for n, _ in g_vars], allow_unused=True)
+    for (n, _), a, b in zip(d_vars, dg, rdg):
+        close(a.cpu().numpy(), b.numpy(), 2e-3, "d_loss grad " + n)
+    for (n, _), a, b in zip(g_vars, gg, rgg):
+        close(a.cpu().numpy(), b.numpy(), 2e-3, "g_loss grad " + n)
+
+
+def test_one_solver_step_and_training_loop(tmp_path):
+    g = make_gan(output=str(tmp_path / "gan_out"))
+    g.set_level(1)
+    rng = np.random.default_rng(4)
+    z = dev(rng.standard_normal((4, 1, 1, 512)).astype(np.float32))
+    x = dev(rng.standard_normal((4, 8, 8, 2)).astype(np.float32))
+    before = g.store.state_dict()
+    d_vars, g_vars = g.get_training_variables(1)
+    g.d_solver(x, z, 0.5)
+    mid = g.store.state_dict()
+    g.g_solver(x, z, 0.5)
+    after = g.store.state_dict()
+    dn, gn = {n for n, _ in d_vars}, {n for n, _ in g_vars}
+    for k in before:
+        if k in dn:
+            delta = np.abs(mid[k] - before[k])
+            assert delta.max() <= 1.01e-3 and delta.max() > 0, k         # |step| <= lr at t = 1 (beta1 = 0)
+        else:
+            assert np.array_equal(mid[k], before[k]), k
+        if k in gn:
+            assert np.abs(after[k] - mid[k]).max() > 0, k
+        else:
+            assert np.array_equal(after[k], mid[k]), k
+    assert g.global_step == 1 and g.d_opt.t == 1 and g.g_opt.t == 1
+    # the reference's level / phase / repeat loop (gan.py:823-867), 2 steps per phase
+    g.train(max_steps_per_phase=2)
+    assert g.global_step == 1 + 3 * 2 * 2 and all(np.isfinite(v) for v in g.last_losses)
+    import os
+    assert sorted(os.listdir(str(tmp_path / "gan_out"))) == ["model_(16x16).npz", "model_(4x4).npz", "model_(8x8).npz"]
+    img = g.predict(latent=np.zeros((2, 1, 1, 512), np.float32))
+    assert tuple(img.shape) == (2, 16, 16, 2)
+    h = gan.GenerativeAdverserialNetwork(dict(PARAMS), mode=None)
+    h.load_checkpoint(str(tmp_path / "gan_out" / "model_(16x16).npz"))
+    assert torch.equal(h.predict(latent=np.zeros((2, 1, 1, 512), np.float32)), img)
+
+
+def test_configuration_defaults():
+    c = gan.GAN2DConfiguration()
+    p = c.to_params()
+    assert p["name"] == "GAN_competition" and p["batch_size"] == 32 and p["repeat_batch"] == 4
+    assert p["num_levels"] == 7 and p["start_size"] == (4, 4) and p["learning_rate"] == 1e-3
+    from sequitr_amd import utils
+    assert utils.filter_doubling(8, 7, 512, True) == [512, 256, 128, 64, 32, 16, 8]
