@@ -70,6 +70,19 @@ class ConvTimer(object):
         return ms, fl, len(self.records)
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per conv_mfma launch (average over the 17 launches of a step) from the rocprofv3
+    PMC passes of THIS command, collected and corrected as MI355X_MICROARCH.md prescribes
+    (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE x2 on gfx950).  PMC counters cannot
+    be read from inside the timed run, so the committed summary is reported; None if absent."""
+    fn = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        with open(fn) as f:
+            return round(json.load(f)["_summary"]["conv_mfma_hbm_bytes_per_launch_avg"], 1)
+    except Exception:
+        return None
+
+
 def cpu_baseline(weights, params, budget_s=20.0):
     """Bounded CPU sample: time the torch-CPU (oneDNN, fp32, channels_last) restatement on a
     few tiles of the same workload; never the thing shipped, only the reported baseline."""
@@ -238,7 +251,7 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic_per_launch(),
                 "launches_per_step": nlaunch // max(1, args.steps),
                 "kernel_ms_per_step": round(conv_ms / max(1, args.steps), 4),
                 "flops_per_step": conv_flops / max(1, args.steps),
