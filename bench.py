@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = the headline metric (BASELINE configs[1]); train = configs[2]/[3] "
                          "(U-Net training step, batch 16 per GPU) for DESIGN.md, not the driver's line")
@@ -196,7 +197,7 @@ def main():
     from sequitr_amd.networks.unet import UNet2D, init_unet_weights
 
     params = {"shape": (TILE, TILE), "num_inputs": 1, "num_outputs": 2, "filters": FILTERS,
-              "bridge": "eltwise_mul", "device": str(dev)}
+              "bridge": "eltwise_mul", "device": str(dev), "fuse": bool(args.fuse)}
     weights = init_unet_weights(params, seed=0)
     net = UNet2D(params, "infer")
     net.load_state_dict(weights)

@@ -214,6 +214,29 @@ int64_t sq_wgrad1x1_small_workspace_f32(int64_t npix, int Ca, int Cb);
 int sq_wgrad1x1_small_f32(const float *a, const float *b, float *m, float *workspace, int64_t npix, int Ca, int Cb,
                           void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused inference variants of the 3x3 convolution (bit-identical to the unfused sequence).
+ * ---------------------------------------------------------------------------------------- */
+
+/* conv_block tail + max_pool_layer (sequitr/networks/unet.py:241-243,265-277): 3x3 conv + bias + act
+ * that writes y (N,H,W,Cout) AND its 2x2 max-pool (N,H/2,W/2,Cout) from the same accumulators. */
+int sq_conv3x3_pool_fwd_f32(const float *x, const float *w, const float *bias, float *y, float *pooled,
+                            int N, int H, int W, int Cin, int Cout, int act, void *stream);
+
+/* last conv_layer of up0 + conv_layer_1x1 + prediction (unet.py:252-253,321): 3x3 conv Cin -> 16
+ * + bias + act, then the 1x1 head (16 -> head_c <= 4, HWIO head_w (1,1,16,head_c)) and the argmax
+ * mask in the epilogue; the 16-channel activation never reaches HBM.  mask may be NULL. */
+int sq_conv3x3_head_fwd_f32(const float *x, const float *w, const float *bias, const float *head_w,
+                            const float *head_b, float *logits, uint8_t *mask, int N, int H, int W,
+                            int Cin, int head_c, int act, void *stream);
+
+/* conv_block of down0 for a 1-channel input (unet.py:238): conv1 (3x3, 1 -> 16, bias, ReLU) is
+ * evaluated in LDS, conv2 (3x3, 16 -> 16, bias, ReLU) on the matrix cores; writes y (N,H,W,16) and,
+ * when pooled != NULL, its 2x2 max-pool. */
+int sq_conv3x3_first_block_fwd_f32(const float *x, const float *w1, const float *b1, const float *w2,
+                                   const float *b2, float *y, float *pooled, int N, int H, int W,
+                                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,27 @@
 //     written to LDS after it, so their latency hides under ~4.6-18k cycles of MFMA;
 //   * operand fragments are double-buffered in registers: the ds_reads of MFMA step s+1 are
 //     issued before the MFMAs of step s (the compiler otherwise sinks them to just-in-time).
+// Fused variants (all bit-identical to the unfused sequence of kernels):
+//   * epilogue also writes the 2x2 max-pooled activation (conv_block + max_pool_layer,
+//     sequitr/networks/unet.py:241-243): saves re-reading the full-resolution tensor;
+//   * epilogue applies the 1x1 to_image head + argmax (unet.py:252-253) and does not store
+//     the 16-channel activation at all: saves a 512 MiB write + read per 32-tile batch;
+//   * FIRST: the 1 -> 16 channel first convolution of down0 (unet.py:238, conv_block conv1)
+//     is evaluated on the fly for the 18x18 halo of each tile (VALU, hidden under other waves'
+//     MFMAs) and never touches HBM: the level-0 block reads 4 B/pixel instead of 64.
 #include "sq_common.h"
+
+struct SqConvEpi {
+    float *pooled;          // (N,H/2,W/2,Cout) or NULL
+    const float *head_w;    // (Cout, head_c) 1x1 head or NULL (needs Cout == 16)
+    const float *head_b;    // (head_c) or NULL
+    float *logits;          // (N,H,W,head_c)
+    uint8_t *mask;          // (N,H,W) or NULL
+    int head_c;
+    int store_y;
+    const float *first_w;   // FIRST only: (3,3,1,16) and (16)
+    const float *first_b;
+};
 
 namespace {
 
@@ -23,7 +43,13 @@ struct Cfg2 {
     static constexpr int BNS = (BN % 32 == 0) ? BN + 16 : BN;  // weight row stride: conflict-free A reads
     static constexpr int WROWS = KS * KS * KC;
     static constexpr int XS_FLOATS = HP * PS;
-    static constexpr int LDS_BYTES = (XS_FLOATS + WROWS * BNS) * 4;
+    static constexpr int WS_FLOATS = WROWS * BNS;
+    static constexpr int IN_W = TW + 4;                     // FIRST: 20x20 single-channel input patch
+    static constexpr int IN_FLOATS = IN_W * IN_W;           // 400 (16-B multiple)
+    static constexpr int HEAD_PS = 18;                      // head scratch: [16 pixels][16 ch + 2]: conflict-free reads
+    static constexpr int HEAD_FLOATS = 4 * 16 * HEAD_PS;    // one 16x16 image per wave
+    static constexpr int LDS_BYTES = (XS_FLOATS + WS_FLOATS) * 4;
+    static constexpr int LDS_BYTES_FIRST = (XS_FLOATS + WS_FLOATS + IN_FLOATS) * 4;
     static constexpr int QPP = KC / 4;                      // float4 per halo pixel
     static constexpr int XITEMS = HP * QPP;
     static constexpr int XSLOTS = (XITEMS + 255) / 256;
@@ -32,19 +58,23 @@ struct Cfg2 {
     static constexpr int NSTEP = KS * KS * (KC / 4);
     static constexpr int OCC = BN >= 64 ? 2 : (BN >= 32 ? 3 : 4);  // blocks per CU (LDS-limited)
     static_assert((XS_FLOATS * 4) % 16 == 0, "weight slab must start 16-B aligned");
+    static_assert((WS_FLOATS * 4) % 16 == 0, "input patch must start 16-B aligned");
 };
 
-template <int BN, int KS, int KC>
+template <int BN, int KS, int KC, bool FIRST>
 __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
     float *__restrict__ y, int N, int H, int W, int Cin, int Cout, float wscale, int act,
-    int tiles_x, int tiles_y, int ntiles, int tiles_per_block) {
+    int tiles_x, int tiles_y, int ntiles, int tiles_per_block, SqConvEpi epi) {
     using C = Cfg2<BN, KS, KC>;
     constexpr int NR = BN / 16;
     constexpr int PAD = KS / 2;
+    static_assert(!FIRST || (BN == 16 && KS == 3 && KC == 16), "FIRST is the 1->16->16 level-0 block");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xs = smem;
     float *ws = smem + C::XS_FLOATS;
+    float *xin = ws + C::WS_FLOATS;                         // FIRST only
+    float *head_scratch = ws + C::WS_FLOATS + (FIRST ? C::IN_FLOATS : 0);   // only when epi.head_w
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
@@ -53,24 +83,26 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
     const int t_begin = vb * tiles_per_block;
     const int t_end = min(t_begin + tiles_per_block, ntiles);
     if (t_begin >= t_end) return;
-    const int nchunk = Cin / KC;
+    const int nchunk = FIRST ? 1 : Cin / KC;
     const int nitems = (t_end - t_begin) * nchunk;
     const bool restage_w = nchunk > 1;
 
     float4 xr[C::XSLOTS];
     float4 wr[C::WSLOTS];
+    float inr[2];                                           // FIRST: 400 input pixels over 256 threads
 
     // Buffer resources: out-of-range offsets read as 0 / drop the store, so image borders,
     // ragged tiles and the "idx >= items" tail need no branches (hipcc otherwise wraps every
     // predicated load in its own s_cbranch_execz block and the loads stop overlapping).
     // All descriptor inputs are kernel arguments => provably wave-uniform (no waterfall loop).
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(x), 0, (int)((size_t)N * H * W * Cin * 4), 0x00020000);
+        const_cast<float *>(x), 0, (int)((size_t)N * H * W * (FIRST ? 1 : Cin) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(w), 0, KS * KS * Cin * Cout * 4, 0x00020000);
+        const_cast<float *>(w), 0, KS * KS * (FIRST ? 16 : Cin) * Cout * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        y, 0, (int)((size_t)N * H * W * Cout * 4), 0x00020000);
+        y, 0, y ? (int)((size_t)N * H * W * Cout * 4) : 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;   // tensors are < 2 GiB (checked on the host)
+    const int CinW = FIRST ? 16 : Cin;      // input channels of the MFMA convolution
 
     // per-thread, tile-independent part of the halo addresses
     int xrel[C::XSLOTS], xpy[C::XSLOTS], xpx[C::XSLOTS];
@@ -89,21 +121,35 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
         const int r = idx / (BN / 4), q4 = idx % (BN / 4);
         const int tap = r / KC, c = r % KC;
         const int co = n0 + q4 * 4;
-        wrel[sl] = (idx < C::WITEMS && co < Cout) ? ((tap * Cin + c) * Cout + co) * 4 : (int)OOB;
+        wrel[sl] = (idx < C::WITEMS && co < Cout) ? ((tap * CinW + c) * Cout + co) * 4 : (int)OOB;
     }
 
     // ---- issue the global loads of one work item (tile, chunk) into registers -------------
     auto issue = [&](int tile, int cc, bool want_w) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-        const int x0 = tx * TW - PAD, y0 = ty * TH - PAD;
-        const int base = (((n * H + y0) * W + x0) * Cin + cc) * 4;     // may be "negative": wraps back
+        if constexpr (FIRST) {
+            // 20x20 single-channel patch around the tile (halo of the halo)
+            const int x0 = tx * TW - 2, y0 = ty * TH - 2;
 #pragma unroll
-        for (int sl = 0; sl < C::XSLOTS; ++sl) {
-            const bool inb = (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
-                             xrel[sl] != (int)OOB;
-            const unsigned off = inb ? (unsigned)(base + xrel[sl]) : OOB;
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
-            xr[sl] = *reinterpret_cast<const float4 *>(&v);
+            for (int sl = 0; sl < 2; ++sl) {
+                const int idx = tid + sl * 256;
+                const int py = idx / C::IN_W, px = idx % C::IN_W;
+                const bool inb = idx < C::IN_FLOATS && (unsigned)(y0 + py) < (unsigned)H &&
+                                 (unsigned)(x0 + px) < (unsigned)W;
+                const unsigned off = inb ? (unsigned)((((n * H + y0 + py) * W) + x0 + px) * 4) : OOB;
+                inr[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, 0, 0));
+            }
+        } else {
+            const int x0 = tx * TW - PAD, y0 = ty * TH - PAD;
+            const int base = (((n * H + y0) * W + x0) * Cin + cc) * 4;     // may be "negative": wraps back
+#pragma unroll
+            for (int sl = 0; sl < C::XSLOTS; ++sl) {
+                const bool inb = (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
+                                 xrel[sl] != (int)OOB;
+                const unsigned off = inb ? (unsigned)(base + xrel[sl]) : OOB;
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+                xr[sl] = *reinterpret_cast<const float4 *>(&v);
+            }
         }
         if (want_w) {
             const int wbase = cc * Cout * 4;
@@ -117,14 +163,22 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
     };
     // ---- registers -> LDS (same index map) ----------------------------------------------------
     auto commit = [&](bool want_w) {
+        if constexpr (FIRST) {
 #pragma unroll
-        for (int sl = 0; sl < C::XSLOTS; ++sl) {
-            const int idx = tid + sl * 256;
-            if (idx < C::XITEMS) {
-                const int pix = idx / C::QPP, q = idx % C::QPP;
-                float *d = xs + pix * C::PS + q * 4;
-                *reinterpret_cast<float2 *>(d) = make_float2(xr[sl].x, xr[sl].y);
-                *reinterpret_cast<float2 *>(d + 2) = make_float2(xr[sl].z, xr[sl].w);
+            for (int sl = 0; sl < 2; ++sl) {
+                const int idx = tid + sl * 256;
+                if (idx < C::IN_FLOATS) xin[idx] = inr[sl];
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < C::XSLOTS; ++sl) {
+                const int idx = tid + sl * 256;
+                if (idx < C::XITEMS) {
+                    const int pix = idx / C::QPP, q = idx % C::QPP;
+                    float *d = xs + pix * C::PS + q * 4;
+                    *reinterpret_cast<float2 *>(d) = make_float2(xr[sl].x, xr[sl].y);
+                    *reinterpret_cast<float2 *>(d + 2) = make_float2(xr[sl].z, xr[sl].w);
+                }
             }
         }
         if (want_w) {
@@ -137,6 +191,48 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
                     v.x *= wscale; v.y *= wscale; v.z *= wscale; v.w *= wscale;
                     *reinterpret_cast<float4 *>(ws + r * C::BNS + q4 * 4) = v;
                 }
+            }
+        }
+    };
+    // ---- FIRST: conv1 (3x3, 1 -> 16, bias, ReLU) of the 18x18 halo, straight into the halo image,
+    // also on the matrix cores: the 9 taps are the reduction (3 MFMA steps of 4, taps 9..11 carry zero
+    // weights, so the chain is exactly "acc = 0; 9 taps in raster order"), 16 output channels are the
+    // rows and 16 halo pixels the columns.  21 column blocks cover the 324 halo pixels (6/5/5/5 per
+    // wave).  Halo pixels outside the image are conv2's ZERO PADDING, not conv1 evaluated out there.
+    float a1[3] = {0.f, 0.f, 0.f};
+    int toff[3] = {0, 0, 0};
+    float4 b1v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int tap = 4 * s + kk;
+            a1[s] = tap < 9 ? epi.first_w[tap * 16 + li] : 0.f;
+            const int tc = tap < 9 ? tap : 8;
+            toff[s] = (tc / 3) * C::IN_W + tc % 3;
+        }
+        b1v = *reinterpret_cast<const float4 *>(epi.first_b + 4 * kk);
+    }
+    auto first_conv = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+        for (int blk = wv; blk < (C::HP + 15) / 16; blk += 4) {
+            const int pix = blk * 16 + li;
+            const int pc = pix < C::HP ? pix : C::HP - 1;
+            const int py = pc / C::HALO_W, px = pc % C::HALO_W;
+            const float *src = xin + py * C::IN_W + px;
+            f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], src[toff[s]], c1, 0, 0, 0);
+            const int gy = ty * TH - 1 + py, gx = tx * TW - 1 + px;
+            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            float v0 = c1[0] + b1v.x, v1 = c1[1] + b1v.y, v2 = c1[2] + b1v.z, v3 = c1[3] + b1v.w;
+            v0 = (inside && v0 > 0.f) ? v0 : 0.f;
+            v1 = (inside && v1 > 0.f) ? v1 : 0.f;
+            v2 = (inside && v2 > 0.f) ? v2 : 0.f;
+            v3 = (inside && v3 > 0.f) ? v3 : 0.f;
+            if (pix < C::HP) {
+                float *d = xs + pix * C::PS + 4 * kk;
+                *reinterpret_cast<float2 *>(d) = make_float2(v0, v1);
+                *reinterpret_cast<float2 *>(d + 2) = make_float2(v2, v3);
             }
         }
     };
@@ -163,6 +259,18 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
         return v > 0.0f ? v : neg;
     };
 
+    // fused head operands, once per block: A[i = head output][k = channel] = head_w[channel][output]
+    float ah[4] = {0.f, 0.f, 0.f, 0.f};
+    float hb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi.head_w) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) ah[s4] = li < epi.head_c ? epi.head_w[(4 * s4 + kk) * epi.head_c + li] : 0.f;
+        if (epi.head_b) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hb[q] = q < epi.head_c ? epi.head_b[q] : 0.f;
+        }
+    }
+
     auto epilogue = [&](int tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int gx = tx * TW + li;
@@ -171,20 +279,75 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
             const int co = n0 + nb * 16 + 4 * kk;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (bias && co < Cout) bv = *reinterpret_cast<const float4 *>(bias + co);
+            f32x4 o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gy = ty * TH + 4 * wv + r;
-                f32x4 o;
-                o[0] = actf(bias ? acc[r][nb][0] + bv.x : acc[r][nb][0]);
-                o[1] = actf(bias ? acc[r][nb][1] + bv.y : acc[r][nb][1]);
-                o[2] = actf(bias ? acc[r][nb][2] + bv.z : acc[r][nb][2]);
-                o[3] = actf(bias ? acc[r][nb][3] + bv.w : acc[r][nb][3]);
-                const bool ok = gy < H && gx < W && co < Cout;
-                const unsigned off = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 4) : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    *reinterpret_cast<__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned *>(&o),
-                    yrsrc, off, 0, 0);
+                o[r][0] = actf(bias ? acc[r][nb][0] + bv.x : acc[r][nb][0]);
+                o[r][1] = actf(bias ? acc[r][nb][1] + bv.y : acc[r][nb][1]);
+                o[r][2] = actf(bias ? acc[r][nb][2] + bv.z : acc[r][nb][2]);
+                o[r][3] = actf(bias ? acc[r][nb][3] + bv.w : acc[r][nb][3]);
+                if (epi.store_y) {
+                    const bool ok = gy < H && gx < W && co < Cout;
+                    const unsigned off = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 4) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        *reinterpret_cast<__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned *>(&o[r]),
+                        yrsrc, off, 0, 0);
+                }
                 acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};      // ready for the next tile
+            }
+            // ---- fused 2x2 max-pool: rows (0,1) and (2,3) in registers, x-neighbour = lane ^ 1 --------
+            if (epi.pooled) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    float mp[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = o[2 * pr][j], b = o[2 * pr + 1][j];
+                        const float v = b > a ? b : a;
+                        const float u = __shfl_xor(v, 1);
+                        mp[j] = u > v ? u : v;
+                    }
+                    const int py = (ty * TH + 4 * wv) / 2 + pr, px = gx >> 1;
+                    if ((li & 1) == 0 && py < (H >> 1) && px < (W >> 1) && co < Cout)
+                        *reinterpret_cast<float4 *>(epi.pooled + ((size_t)(n * (H >> 1) + py) * (W >> 1) + px) * Cout + co) =
+                            make_float4(mp[0], mp[1], mp[2], mp[3]);
+                }
+            }
+            // ---- fused 1x1 head (Cout == 16 only), also on the matrix cores.  The accumulator layout has
+            // the 16 channels of a pixel spread over 4 lanes; the wave transposes its 16-pixel x 16-channel
+            // row through a private LDS image (no block barrier: same-wave DS operations are ordered) and
+            // runs 4 MFMA steps with A = head_w^T (rows = head outputs), B = [channel][pixel]: one fmaf
+            // chain over c = 0..15 per output, exactly as conv1x1_small / the oracle.  The kk == 0 lanes end
+            // up with the head outputs of pixel li: + bias, store 16 x head_c contiguous floats, argmax.
+            if (epi.head_w) {
+                float *hs = head_scratch + wv * (16 * C::HEAD_PS);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float *d = hs + li * C::HEAD_PS + 4 * kk;
+                    *reinterpret_cast<float2 *>(d) = make_float2(o[r][0], o[r][1]);
+                    *reinterpret_cast<float2 *>(d + 2) = make_float2(o[r][2], o[r][3]);
+                    __builtin_amdgcn_wave_barrier();
+                    f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        z = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[s4], hs[li * C::HEAD_PS + 4 * s4 + kk], z, 0, 0, 0);
+                    __builtin_amdgcn_wave_barrier();
+                    const int gy = ty * TH + 4 * wv + r;
+                    if (kk == 0 && gy < H && gx < W) {
+                        const size_t p = (size_t)(n * H + gy) * W + gx;
+                        float best = 0.f;
+                        int bi = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (q < epi.head_c) {
+                                const float v = epi.head_b ? z[q] + hb[q] : z[q];
+                                epi.logits[p * epi.head_c + q] = v;
+                                if (q == 0 || v > best) { best = v; bi = q; }
+                            }
+                        if (epi.mask) epi.mask[p] = (uint8_t)bi;
+                    }
+                }
             }
         }
     };
@@ -196,6 +359,10 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
 #pragma unroll
         for (int nb = 0; nb < NR; ++nb) acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    if constexpr (FIRST) {
+        first_conv(t_begin);
+        __syncthreads();
+    }
 
     int tile = t_begin, chunk = 0;
     for (int it = 0; it < nitems; ++it) {
@@ -237,6 +404,10 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
         if (has_next) {
             __syncthreads();            // every wave is done reading this item's LDS image
             commit(restage_w);
+            if constexpr (FIRST) {
+                __syncthreads();        // the 20x20 patch is complete
+                first_conv(ntile);
+            }
         }
         if (chunk == nchunk - 1) epilogue(tile);
         if (has_next) __syncthreads();
@@ -245,16 +416,18 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
     }
 }
 
-template <int BN, int KS, int KC>
+template <int BN, int KS, int KC, bool FIRST>
 int launch_v2(const float *x, const float *w, const float *bias, float *y, int N, int H, int W, int Cin,
-              int Cout, float wscale, int act, hipStream_t st) {
+              int Cout, float wscale, int act, const SqConvEpi &epi, hipStream_t st) {
     using C = Cfg2<BN, KS, KC>;
     static bool attr_set = false;
-    auto kern = conv_mfma_f32_v2_kernel<BN, KS, KC>;
+    auto kern = conv_mfma_f32_v2_kernel<BN, KS, KC, FIRST>;
+    constexpr int lds_max = (FIRST ? C::LDS_BYTES_FIRST : C::LDS_BYTES) + C::HEAD_FLOATS * 4;
+    const int lds = (FIRST ? C::LDS_BYTES_FIRST : C::LDS_BYTES) + (epi.head_w ? C::HEAD_FLOATS * 4 : 0);
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
-            sq_set_error("conv_mfma_f32_v2: cannot reserve %d bytes of LDS", C::LDS_BYTES);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) {
+            sq_set_error("conv_mfma_f32_v2: cannot reserve %d bytes of LDS", lds_max);
             return SQ_ELAUNCH;
         }
         attr_set = true;
@@ -268,27 +441,88 @@ int launch_v2(const float *x, const float *w, const float *bias, float *y, int N
     int tpb = (ntiles + want - 1) / want;
     if (tpb < 1) tpb = 1;
     const int gx = (ntiles + tpb - 1) / tpb;
-    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), C::LDS_BYTES, st, x, w, bias, y, N, H, W, Cin, Cout,
-                       wscale, act, tiles_x, tiles_y, ntiles, tpb);
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, st, x, w, bias, y, N, H, W, Cin, Cout,
+                       wscale, act, tiles_x, tiles_y, ntiles, tpb, epi);
     return sq_check_launch("sq_conv2d_nhwc_fwd_f32(v2)");
 }
 
 template <int KS, int KC>
 int dispatch_bn(const float *x, const float *w, const float *bias, float *y, int N, int H, int W, int Cin,
-                int Cout, float wscale, int act, hipStream_t st) {
-    if (Cout >= 64) return launch_v2<64, KS, KC>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st);
-    if (Cout > 16) return launch_v2<32, KS, KC>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st);
-    return launch_v2<16, KS, KC>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st);
+                int Cout, float wscale, int act, const SqConvEpi &epi, hipStream_t st) {
+    if (Cout >= 64) return launch_v2<64, KS, KC, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
+    if (Cout > 16) return launch_v2<32, KS, KC, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
+    return launch_v2<16, KS, KC, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
 }
+
+bool fits32(int N, int H, int W, int C) { return (size_t)N * H * W * (size_t)C * 4 < ((size_t)1 << 31); }
 
 }  // namespace
 
 // internal entry used by sq_conv2d_nhwc_fwd_f32's dispatcher (sq_conv_f32.hip)
 int sq_conv_mfma_v2(const float *x, const float *w, const float *bias, float *y, int N, int H, int W,
                     int Cin, int Cout, int K, float wscale, int act, hipStream_t st) {
+    SqConvEpi epi = {};
+    epi.store_y = 1;
     if (Cin % 16 == 0)
-        return K == 3 ? dispatch_bn<3, 16>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st)
-                      : dispatch_bn<1, 16>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st);
-    return K == 3 ? dispatch_bn<3, 8>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st)
-                  : dispatch_bn<1, 8>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st);
+        return K == 3 ? dispatch_bn<3, 16>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st)
+                      : dispatch_bn<1, 16>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
+    return K == 3 ? dispatch_bn<3, 8>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st)
+                  : dispatch_bn<1, 8>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
+}
+
+// conv_block tail + max_pool_layer (sequitr/networks/unet.py:241-243, 265-277): 3x3 conv + bias + act,
+// writes y (N,H,W,Cout) AND pooled (N,H/2,W/2,Cout).
+extern "C" int sq_conv3x3_pool_fwd_f32(const float *x, const float *w, const float *bias, float *y, float *pooled,
+                                       int N, int H, int W, int Cin, int Cout, int act, void *stream) {
+    SQ_REQUIRE(x && w && y && pooled, "sq_conv3x3_pool_fwd_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "sq_conv3x3_pool_fwd_f32: H, W must be even");
+    SQ_REQUIRE(Cin % 16 == 0 && Cin > 0 && Cout % 4 == 0 && Cout > 0,
+               "sq_conv3x3_pool_fwd_f32: Cin=%d (multiple of 16), Cout=%d (multiple of 4)", Cin, Cout);
+    SQ_REQUIRE(fits32(N, H, W, Cin > Cout ? Cin : Cout), "sq_conv3x3_pool_fwd_f32: tensors must be < 2 GiB");
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_conv3x3_pool_fwd_f32: bad activation %d", act);
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(w); SQ_REQUIRE_ALIGNED(y); SQ_REQUIRE_ALIGNED(pooled);
+    if (bias) SQ_REQUIRE_ALIGNED(bias);
+    SqConvEpi epi = {};
+    epi.store_y = 1;
+    epi.pooled = pooled;
+    return dispatch_bn<3, 16>(x, w, bias, y, N, H, W, Cin, Cout, 1.0f, act, epi, reinterpret_cast<hipStream_t>(stream));
+}
+
+// last conv_layer of up0 + conv_layer_1x1 head + prediction (unet.py:252-253, 321): the 16-channel
+// activation is never stored; logits (N,H,W,head_c) and the uint8 mask come straight from the epilogue.
+extern "C" int sq_conv3x3_head_fwd_f32(const float *x, const float *w, const float *bias, const float *head_w,
+                                       const float *head_b, float *logits, uint8_t *mask, int N, int H, int W,
+                                       int Cin, int head_c, int act, void *stream) {
+    SQ_REQUIRE(x && w && head_w && logits, "sq_conv3x3_head_fwd_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && Cin % 16 == 0 && Cin > 0, "sq_conv3x3_head_fwd_f32: Cin=%d (multiple of 16)", Cin);
+    SQ_REQUIRE(head_c >= 1 && head_c <= 4, "sq_conv3x3_head_fwd_f32: head_c=%d (1..4)", head_c);
+    SQ_REQUIRE(fits32(N, H, W, Cin > 16 ? Cin : 16), "sq_conv3x3_head_fwd_f32: tensors must be < 2 GiB");
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_conv3x3_head_fwd_f32: bad activation %d", act);
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(w);
+    if (bias) SQ_REQUIRE_ALIGNED(bias);
+    SqConvEpi epi = {};
+    epi.store_y = 0;
+    epi.head_w = head_w; epi.head_b = head_b; epi.logits = logits; epi.mask = mask; epi.head_c = head_c;
+    return launch_v2<16, 3, 16, false>(x, w, bias, nullptr, N, H, W, Cin, 16, 1.0f, act, epi,
+                                       reinterpret_cast<hipStream_t>(stream));
+}
+
+// conv_block of down0 (unet.py:238, 265-277) for a single-channel input: conv1 (3x3, 1 -> 16, bias, ReLU)
+// is evaluated in LDS and only conv2's output y (N,H,W,16) -- and optionally its max-pool -- reach HBM.
+extern "C" int sq_conv3x3_first_block_fwd_f32(const float *x, const float *w1, const float *b1, const float *w2,
+                                              const float *b2, float *y, float *pooled, int N, int H, int W,
+                                              void *stream) {
+    SQ_REQUIRE(x && w1 && b1 && w2 && y, "sq_conv3x3_first_block_fwd_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0, "sq_conv3x3_first_block_fwd_f32: bad shape");
+    SQ_REQUIRE(!pooled || (H % 2 == 0 && W % 2 == 0), "sq_conv3x3_first_block_fwd_f32: pooling needs even H, W");
+    SQ_REQUIRE(fits32(N, H, W, 16), "sq_conv3x3_first_block_fwd_f32: tensors must be < 2 GiB");
+    SQ_REQUIRE_ALIGNED(w2); SQ_REQUIRE_ALIGNED(y);
+    if (b2) SQ_REQUIRE_ALIGNED(b2);
+    if (pooled) SQ_REQUIRE_ALIGNED(pooled);
+    SqConvEpi epi = {};
+    epi.store_y = 1;
+    epi.pooled = pooled;
+    epi.first_w = w1; epi.first_b = b1;
+    return launch_v2<16, 3, 16, true>(x, w2, b2, y, N, H, W, 1, 16, 1.0f, SQ_ACT_RELU, epi,
+                                      reinterpret_cast<hipStream_t>(stream));
 }

@@ -258,6 +258,7 @@ class UNet2D(UNet):
         self._vars = {}                                        # scope/name -> device tensor
         self._dropout_calls = 0
         self.dropout_masks = None
+        self.fuse = bool(params.get('fuse', True))          # fused inference kernels (same bits)
         self._mask = None
 
     # -- variables ---------------------------------------------------------------------
@@ -358,7 +359,84 @@ class UNet2D(UNet):
 
     def build(self, features):
         self._mask = None
+        if self.fuse and self._fusable():
+            return self._build_fused(features)
         return UNet.build(self, features)
+
+    # -- fused inference graph ---------------------------------------------------------------
+    _HOOKS = ('conv_layer', 'conv_layer_1x1', 'conv_transpose_layer', 'pool_layer', 'max_pool_layer',
+              'conv_block', 'down_layer', 'up_layer', 'dropout_layer', 'reshape_input')
+
+    def _fusable(self):
+        """The fused kernels replace whole hook sequences, so they are used only when no hook (and
+        not the bridge) has been overridden and the graph is the plain inference graph."""
+        if self.training or tuple(self.kernel) != (3, 3):
+            return False
+        if self.bridge is not self._default_bridge or self.bridge_type not in ('eltwise_add', 'eltwise_mul', 'eltwise_sub'):
+            return False
+        if any(f % 16 for f in self.filters) or len(self.filters) < 2:
+            return False
+        return all(getattr(type(self), h) is getattr(UNet2D, h) for h in self._HOOKS)
+
+    def _v(self, path, kind, shape):
+        scopes = path.split('/')
+        self._scopes.extend(scopes)
+        try:
+            return self._kernel(shape) if kind == 'kernel' else self._bias(shape[0])
+        finally:
+            del self._scopes[-len(scopes):]
+
+    def _build_fused(self, features):
+        """Same graph and the same bits as UNet.build (unet.py:224-262), with the fused kernels:
+        down0 conv1+conv2(+pool) when the input has one channel, conv2+max-pool in every encoder
+        block, transpose-conv+bridge in every decoder block, last conv + 1x1 head + argmax.
+        Variables are created in the same order as the unfused build."""
+        f = list(self.filters)
+        L = len(f)
+        x = self.reshape_input(features)
+        net, pooled = [], None
+        for i in range(L):                                         # encoder
+            s = 'UNet/down%d' % i
+            cin = x.shape[-1] if i == 0 else f[i - 1]
+            w1, b1 = self._v(s + '/conv1', 'kernel', (3, 3, cin, f[i])), self._v(s + '/conv1', 'bias', (f[i],))
+            w2, b2 = self._v(s + '/conv2', 'kernel', (3, 3, f[i], f[i])), self._v(s + '/conv2', 'bias', (f[i],))
+            src = x if i == 0 else pooled
+            last = i == L - 1
+            if i == 0 and cin == 1 and f[0] == 16:
+                y, pooled = ops.conv3x3_first_block(src, w1, b1, w2, b2, want_pool=not last)
+            else:
+                c1 = ops.conv2d(src, w1, b1, act='relu')
+                if last:
+                    y, pooled = ops.conv2d(c1, w2, b2, act='relu'), None
+                else:
+                    y, pooled = ops.conv3x3_pool(c1, w2, b2, act='relu')
+            net.append(y)
+        head_fused = f[0] == 16 and self.n_outputs <= 4
+        logits = None
+        for i in reversed(range(L - 1)):                           # decoder
+            s = 'UNet/up%d' % i
+            wt, bt = self._v(s + '/upscale', 'kernel', (2, 2, f[i], f[i + 1])), self._v(s + '/upscale', 'bias', (f[i],))
+            merged = ops.convT2x2s2(net[-1], wt, bt, skip=net[i], bridge=self.bridge_type)
+            w1, b1 = self._v(s + '/conv1', 'kernel', (3, 3, f[i], f[i])), self._v(s + '/conv1', 'bias', (f[i],))
+            w2, b2 = self._v(s + '/conv2', 'kernel', (3, 3, f[i], f[i])), self._v(s + '/conv2', 'bias', (f[i],))
+            c1 = ops.conv2d(merged, w1, b1, act='relu')
+            if i == 0 and head_fused:
+                wh = self._v('UNet/to_image', 'kernel', (1, 1, f[0], self.n_outputs))
+                bh = self._v('UNet/to_image', 'bias', (self.n_outputs,))
+                logits, self._mask = ops.conv3x3_head(c1, w2, b2, wh, bh, act='relu')
+                net.append(None)                                   # up0's activation is never materialised
+            else:
+                net.append(ops.conv2d(c1, w2, b2, act='relu'))
+        if logits is None:
+            wh = self._v('UNet/to_image', 'kernel', (1, 1, f[0], self.n_outputs))
+            bh = self._v('UNet/to_image', 'bias', (self.n_outputs,))
+            if self.n_outputs <= 4:
+                logits, self._mask = ops.conv1x1_argmax(net[-1], wh, bh)
+            else:
+                logits = ops.conv2d(net[-1], wh, bh, act=None)
+        net.append(logits)
+        self._net = net
+        return logits
 
     # -- prediction ------------------------------------------------------------------------
     def predict(self, features):

@@ -494,3 +494,52 @@ def conv_wgrad_raw(x, dy, K, want_bias=False):
         db = wgrad1x1_small(dy, _ones(npix, 4, x.device))[:, 0].contiguous() if want_bias else None
         return dw, db
     raise _lib.SequitrHipError("conv wgrad: unsupported Cin=%d Cout=%d K=%d" % (Cin, Cout, K))
+
+
+# ----------------------------------------------------------------------------------------------
+# fused inference variants (include/sequitr_hip.h "Fused inference variants")
+# ----------------------------------------------------------------------------------------------
+def conv3x3_pool(x, w, bias, act="relu"):
+    """conv + bias + act -> (y, maxpool2x2(y)) from one kernel."""
+    _chk(x, "x", ndim=4), _chk(w, "w", ndim=4)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    if tuple(w.shape[:3]) != (3, 3, Cin):
+        raise ValueError("conv3x3_pool: weight %s does not match %d input channels" % (tuple(w.shape), Cin))
+    if bias is not None:
+        _chk(bias, "bias")
+    y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device)
+    p = torch.empty((N, H // 2, W // 2, Cout), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_conv3x3_pool_fwd_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(p), N, H, W, Cin, Cout,
+                                          ACT[act], _stream()), "sq_conv3x3_pool_fwd_f32")
+    return y, p
+
+
+def conv3x3_head(x, w, bias, head_w, head_b, act="relu", want_mask=True):
+    """conv (Cin -> 16) + bias + act, then the 1x1 head and argmax: returns (logits, mask)."""
+    _chk(x, "x", ndim=4), _chk(w, "w", ndim=4), _chk(head_w, "head_w", ndim=4)
+    N, H, W, Cin = x.shape
+    if tuple(w.shape) != (3, 3, Cin, 16) or tuple(head_w.shape[:3]) != (1, 1, 16):
+        raise ValueError("conv3x3_head needs w (3,3,%d,16) and head_w (1,1,16,C)" % Cin)
+    hc = head_w.shape[3]
+    logits = torch.empty((N, H, W, hc), dtype=torch.float32, device=x.device)
+    mask = torch.empty((N, H, W), dtype=torch.uint8, device=x.device) if want_mask else None
+    lib = _lib.load()
+    _lib.check(lib.sq_conv3x3_head_fwd_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(head_w), _ptr(head_b), _ptr(logits),
+                                          _ptr(mask), N, H, W, Cin, hc, ACT[act], _stream()), "sq_conv3x3_head_fwd_f32")
+    return logits, mask
+
+
+def conv3x3_first_block(x, w1, b1, w2, b2, want_pool=True):
+    """down0 conv_block for a 1-channel input: relu(conv2(relu(conv1(x)))) -> (y, pooled or None)."""
+    _chk(x, "x", ndim=4), _chk(w1, "w1", ndim=4), _chk(w2, "w2", ndim=4), _chk(b1, "b1"), _chk(b2, "b2")
+    N, H, W, Cin = x.shape
+    if Cin != 1 or tuple(w1.shape) != (3, 3, 1, 16) or tuple(w2.shape) != (3, 3, 16, 16):
+        raise ValueError("conv3x3_first_block is the 1 -> 16 -> 16 level-0 block")
+    y = torch.empty((N, H, W, 16), dtype=torch.float32, device=x.device)
+    p = torch.empty((N, H // 2, W // 2, 16), dtype=torch.float32, device=x.device) if want_pool else None
+    lib = _lib.load()
+    _lib.check(lib.sq_conv3x3_first_block_fwd_f32(_ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(y), _ptr(p),
+                                                 N, H, W, _stream()), "sq_conv3x3_first_block_fwd_f32")
+    return y, p

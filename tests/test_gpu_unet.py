@@ -20,17 +20,50 @@ def make(params, seed=0, cls=UNet2D):
     return net, w
 
 
+@pytest.mark.parametrize("fuse", [False, True])
 @pytest.mark.parametrize("bridge", ["eltwise_mul", "eltwise_add", "eltwise_sub", None])
-def test_forward_64px_every_layer_bit_exact(bridge):
-    params = {"shape": (64, 64), "bridge": bridge}
+def test_forward_64px_every_layer_bit_exact(bridge, fuse):
+    """hook-by-hook graph (fuse=False) and the fused-kernel graph (fuse=True): same bits."""
+    params = {"shape": (64, 64), "bridge": bridge, "fuse": fuse}
     net, w = make(params, seed=3)
     x = tiles(0, 2, 64, 64)
     mask = net.predict(x)
     ref_logits, ref_net = unet_oracle.unet_forward(x, w, params, return_net=True)
     assert len(net._net) == len(ref_net) == 10
     for i, (a, b) in enumerate(zip(net._net, ref_net)):
+        if a is None:                                   # fused head: up0's activation is not materialised
+            assert fuse and i == 8
+            continue
         assert_bit_exact(a.cpu().numpy(), b, "layer %d (%s)" % (i, bridge))
     assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref_logits), "mask")
+
+
+def test_fused_kernels_individually_bit_exact():
+    from oracle import c_oracle as co
+    from tests.util import rand_weights
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    x1 = tiles(20, 2, 48, 40, 1)                          # ragged vs the 16x16 tile, N = 2
+    w1, b1 = rand_weights(21, (3, 3, 1, 16), 0.5), rand_weights(22, (16,), 0.1)
+    w2, b2 = rand_weights(23, (3, 3, 16, 16)), rand_weights(24, (16,), 0.1)
+    ref = co.conv2d(co.conv2d(x1, w1, b1, act="relu"), w2, b2, act="relu")
+    y, p = ops.conv3x3_first_block(dev(x1), dev(w1), dev(b1), dev(w2), dev(b2))
+    assert_bit_exact(y.cpu().numpy(), ref, "first block y")
+    assert_bit_exact(p.cpu().numpy(), co.maxpool2x2(ref), "first block pooled")
+    for cin, cout in ((16, 32), (32, 32), (64, 128)):
+        x = tiles(25, 1, 32, 48, cin)
+        w, b = rand_weights(26, (3, 3, cin, cout)), rand_weights(27, (cout,), 0.1)
+        r = co.conv2d(x, w, b, act="relu")
+        y, p = ops.conv3x3_pool(dev(x), dev(w), dev(b))
+        assert_bit_exact(y.cpu().numpy(), r, "conv+pool y %d->%d" % (cin, cout))
+        assert_bit_exact(p.cpu().numpy(), co.maxpool2x2(r), "conv+pool pooled %d->%d" % (cin, cout))
+    x = tiles(28, 2, 40, 24, 16)
+    w, b = rand_weights(29, (3, 3, 16, 16)), rand_weights(30, (16,), 0.1)
+    for hc in (1, 2, 3):
+        hw, hb = rand_weights(31, (1, 1, 16, hc)), rand_weights(32, (hc,), 0.1)
+        r = co.conv2d(co.conv2d(x, w, b, act="relu"), hw, hb, act=None)
+        logits, mask = ops.conv3x3_head(dev(x), dev(w), dev(b), dev(hw), dev(hb))
+        assert_bit_exact(logits.cpu().numpy(), r, "fused head logits C=%d" % hc)
+        assert_bit_exact(mask.cpu().numpy(), co.argmax_u8(r), "fused head mask C=%d" % hc)
 
 
 def test_lazy_init_equals_host_init():
