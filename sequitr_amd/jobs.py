@@ -129,3 +129,91 @@ def SERVER_test(params, options):
     with open(os.path.join(params['output'], 'test.json'), 'w') as f:
         json.dump({'params': {k: repr(v) for k, v in params.items()},
                    'options': {k: repr(v) for k, v in options.items()}}, f, indent=2)
+
+
+def _onehot(labels, num_outputs):
+    """class-index labels (N,H,W) -> one-hot uint8 (N,H,W,num_outputs); classes >= num_outputs get an
+    all-zero row, as tr_augment's ``concat(...)[..., :outputs]`` does (sequitr/networks/unet.py:396-398)."""
+    labels = np.asarray(labels)
+    if labels.ndim == 4:
+        return np.ascontiguousarray(labels[..., :num_outputs], dtype=np.uint8)
+    return np.stack([(labels == c) for c in range(num_outputs)], -1).astype(np.uint8)
+
+
+def SERVER_train(params, options):
+    """Train the U-Net on a stack of tiles with the weight-map-weighted softmax cross-entropy.
+
+    params: images (.npy (N,H,W[,C]) float), labels (.npy (N,H,W) class indices or one-hot), weights
+    (.npy (N,H,W[,1]); when absent computed with ImageWeightMap(w0, sigma) on the host,
+    sequitr/pipeline.py:455-479), plus the NetConfiguration keys (name, shape, num_outputs,
+    learning_rate, num_epochs, batch_size, dropout, filters, bridge, warm_start ...).
+    Under torchrun (WORLD_SIZE > 1) the tiles shard across ranks and gradients are all-reduced over
+    RCCL once per step.  Rank 0 saves ``weights.npz`` + ``net.config`` into the next numbered folder
+    of MODELDIR/<name>/ (sequitr/utils.py:143-223 layout) and ``train.json`` into params['output'].
+    """
+    import torch
+    from . import utils
+    from .parallel import shard_range
+    from .pipeline import ImageWeightMap
+    from .train import UNetTrainer
+
+    device = _resolve_device(params, options)
+    torch.cuda.set_device(torch.device(device))
+    world, rank = int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('RANK', 0))
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('nccl', device_id=torch.device(device))
+
+    cfg_keys = ('name', 'shape', 'num_inputs', 'num_outputs', 'num_epochs', 'learning_rate', 'warm_start', 'dropout')
+    config = utils.NetConfiguration.from_params({k: params[k] for k in cfg_keys if k in params})
+    x = np.load(params['images'], mmap_mode='r', allow_pickle=False)
+    if x.ndim == 3:
+        x = x[..., np.newaxis]
+    onehot = _onehot(np.load(params['labels'], allow_pickle=False), config.num_outputs)
+    if params.get('weights'):
+        wmap = np.load(params['weights'], allow_pickle=False).reshape(onehot.shape[:3] + (1,)).astype(np.float32)
+    else:
+        pipe = ImageWeightMap(w0=params.get('w0', 10.), sigma=params.get('sigma', 5.))
+        fg = onehot[..., 1:].sum(-1).astype(np.float32)
+        wmap = np.stack([pipe(t.copy()) for t in fg]).astype(np.float32)
+
+    net_p = _net_params(params, device)
+    net_p.setdefault('shape', tuple(x.shape[1:3]))
+    net_p['dropout'] = float(params.get('dropout', 0.4))
+    trainer = UNetTrainer(net_p, learning_rate=config.learning_rate)
+    if config.warm_start:
+        latest = config.warm_start_from()
+        if latest:
+            trainer.load_state_dict(utils.load_model_weights(latest))
+            logger.info('Warm start from {0:s}'.format(latest))
+
+    lo, hi = shard_range(x.shape[0], rank, world)
+    batch = int(params.get('batch_size', 16))
+    steps_per_epoch = max(1, (hi - lo) // batch)
+    epochs = int(params.get('num_epochs', config.num_epochs))
+    max_steps = options.get('max_steps')
+    losses = []
+    t0 = time.time()
+    for epoch in range(epochs):
+        order = np.random.default_rng(epoch).permutation(hi - lo)[:steps_per_epoch * batch] + lo
+        for s in range(steps_per_epoch):
+            idx = np.sort(order[s * batch:(s + 1) * batch])
+            xb = torch.from_numpy(np.ascontiguousarray(x[idx], dtype=np.float32)).to(device)
+            yb = torch.from_numpy(np.ascontiguousarray(onehot[idx])).to(device)
+            wb = torch.from_numpy(np.ascontiguousarray(wmap[idx])).to(device)
+            losses.append(float(trainer.step(xb, yb, wb).item()))
+            if max_steps and len(losses) >= max_steps:
+                break
+        if max_steps and len(losses) >= max_steps:
+            break
+    torch.cuda.synchronize()
+    info = {'steps': len(losses), 'first_loss': losses[0], 'last_loss': losses[-1], 'seconds': time.time() - t0,
+            'world': world, 'device': device}
+    if rank == 0:
+        info['model_dir'] = utils.save_model(trainer.state_dict(), config)
+        with open(os.path.join(params['output'], 'train.json'), 'w') as f:
+            json.dump(dict(info, losses=losses), f, indent=2)
+        logger.info('Trained {steps} steps, loss {first_loss:.4f} -> {last_loss:.4f}, saved {model_dir}'.format(**info))
+    return info

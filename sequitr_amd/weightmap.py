@@ -1,0 +1,108 @@
+"""Offline weight-map creation -- mirror of sequitr/weightmap.py (rows a15-a16 of SURVEY.md 8a).
+
+``ImageLabels`` (weightmap.py:31-73) turns a label image (2-D, or a 3-D stack with one binary plane
+per class) into a uint8 class-index map with at most 5 classes; ``create_weightmaps``
+(weightmap.py:171-205) walks ``<path>/<folder>/label/*.tif``, computes
+``ImageWeightMap2(w0, sigma)`` of the binarised labels and writes float32 TIFFs to
+``weights_w0-%2.2f_sigma-%2.2f/`` with the reference's file-name rule.  The reference's own copy of
+ImageWeightMap2 in this file is broken; the working class lives in pipeline.py.
+
+TIFF IO uses Pillow (the reference's ``tifffile`` is a git-ignored third-party file that is not in
+the tree); ``.npy`` label files are accepted too.
+"""
+import argparse
+import os
+import re
+
+import numpy as np
+
+from . import utils
+from .pipeline import ImageWeightMap2
+
+
+def imread(filename):
+    if filename.endswith('.npy'):
+        return np.load(filename, allow_pickle=False)
+    from PIL import Image, ImageSequence
+    with Image.open(filename) as im:
+        pages = [np.array(p) for p in ImageSequence.Iterator(im)]
+    return pages[0] if len(pages) == 1 else np.stack(pages)
+
+
+def imsave(filename, array):
+    if filename.endswith('.npy'):
+        np.save(filename, array)
+        return
+    from PIL import Image
+    Image.fromarray(np.ascontiguousarray(array)).save(filename, format='TIFF')
+
+
+class ImageLabels(object):
+    """Label image -> class indices 0..n (weightmap.py:31-73)."""
+
+    def __init__(self, filename, thresh_fn=lambda x: x > 0):
+        self._raw_data = filename if isinstance(filename, np.ndarray) else imread(filename)
+        assert (self._raw_data.ndim > 1 and self._raw_data.ndim < 4)
+        if self._raw_data.ndim == 3:
+            l_data = np.zeros(self._raw_data.shape[1:], dtype='uint8')
+            for l in range(self._raw_data.shape[0]):
+                l_data[thresh_fn(self._raw_data[l, ...])] = l + 1
+            raw_labels = list(range(self._raw_data.shape[0] + 1))
+        else:
+            l_data = thresh_fn(self._raw_data).astype('uint8')
+            raw_labels = [0, 1]
+        self._outputs = len(raw_labels)
+        if self.outputs > 5:
+            raise ValueError('More that five output classes!')
+        self._labels = l_data
+
+    def labels(self):
+        return self._labels
+
+    @property
+    def outputs(self):
+        return self._outputs
+
+
+def weights_folder_name(w0, sigma, name_weights_folder=True):
+    base = 'weights'
+    if name_weights_folder:
+        base += '_w0-{0:2.2f}_sigma-{1:2.2f}'.format(w0, sigma)
+    return base
+
+
+def weights_file_name(label_file):
+    """'a_b_label.tif' -> 'a_b_weights.tif' (weightmap.py:198-199)."""
+    return re.match('([a-zA-Z0-9()]+)_([a-zA-Z0-9()]+_)*', label_file).group(0) + 'weights.tif'
+
+
+def create_weightmaps(path, folders, w0=10., sigma=3., thresh_fn=lambda x: x > 0, name_weights_folder=True):
+    """ Generate weightmaps for the images using the binary masks; returns the files written. """
+    w_pipe = ImageWeightMap2(w0=w0, sigma=sigma)
+    written = []
+    for d in folders:
+        r_dir = os.path.join(path, d)
+        f_labels = sorted(l for l in os.listdir(os.path.join(r_dir, 'label')) if l.endswith('.tif'))
+        w_dir = os.path.join(r_dir, weights_folder_name(w0, sigma, name_weights_folder))
+        utils.check_and_makedir(w_dir)
+        for f in f_labels:
+            im_label = ImageLabels(os.path.join(r_dir, 'label', f), thresh_fn=thresh_fn).labels()
+            im_weights = np.squeeze(w_pipe(im_label.astype('bool')))
+            out = os.path.join(w_dir, weights_file_name(f))
+            imsave(out, im_weights.astype('float32'))
+            written.append(out)
+    return written
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description='Sequitr: weightmap calculation')
+    p.add_argument('-p', '--workdir', default="/media/lowe-sn00/TrainingData/", help='Path to the image data')
+    p.add_argument('-f', '--folders', nargs='+', required=True, help='Specify the sub-folders of image data')
+    p.add_argument('--w0', type=float, default=30., help='Specify the amplitude')
+    p.add_argument('--sigma', type=float, default=3., help='Specify the sigma')
+    args = p.parse_args(argv)
+    create_weightmaps(args.workdir, args.folders, w0=args.w0, sigma=args.sigma)
+
+
+if __name__ == '__main__':
+    main()

@@ -52,3 +52,36 @@ def test_segment_job_with_pipeline_and_saved_model(tmp_path, monkeypatch):
     normed = np.stack([ImageNorm()(t.copy()) for t in raw]).astype(np.float32)
     ref = unet_oracle.unet_forward(normed, w, {"shape": (32, 32)})
     assert_bit_exact(np.load(os.path.join(out, "logits.npy")), ref, "job logits (pipeline + saved model)")
+
+
+def test_train_job_then_segment_with_the_saved_model(tmp_path, monkeypatch):
+    """SERVER_train through worker(): loss falls, a numbered model dir appears, SERVER_segment loads it."""
+    from sequitr_amd import core
+    monkeypatch.setattr(core.TensorflowConfiguration, "MODELDIR", str(tmp_path / "models"))
+    os.mkdir(str(tmp_path / "models"))
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:64, 0:64]
+    lab = ((yy - 30) ** 2 + (xx - 34) ** 2 < 180).astype(np.uint8)
+    imgs = (lab[None] * 2.0 + rng.standard_normal((8, 64, 64)) * 0.4).astype(np.float32)
+    np.save(str(tmp_path / "im.npy"), imgs)
+    np.save(str(tmp_path / "lab.npy"), np.broadcast_to(lab, (8, 64, 64)).copy())
+    params = {"images": str(tmp_path / "im.npy"), "labels": str(tmp_path / "lab.npy"), "shape": (64, 64),
+              "num_outputs": 2, "learning_rate": 0.003, "num_epochs": 12, "batch_size": 4, "dropout": 0.0,
+              "filters": (16, 32, 64), "seed": 0}
+    fn = write_job(tmp_path, "JOB_t.job", func="SERVER_train", params=repr(params), options="{'gpu': 0}")
+    out = str(tmp_path / "out_t")
+    worker.worker(argparse.Namespace(job=fn, out=out))
+    logs = open(os.path.join(out, [f for f in os.listdir(out) if f.startswith("LOG_")][0])).read()
+    assert "exception" not in logs, logs
+    info = json.load(open(os.path.join(out, "train.json")))
+    assert info["steps"] == 24 and info["last_loss"] < 0.5 * info["first_loss"]
+    assert info["model_dir"].endswith(os.path.join("UNet2D_test", "0001"))
+    assert os.path.exists(os.path.join(info["model_dir"], "net.config"))
+    seg = {"input": str(tmp_path / "im.npy"), "shape": (64, 64), "filters": (16, 32, 64), "model": "UNet2D_test"}
+    fn2 = write_job(tmp_path, "JOB_s.job", func="SERVER_segment", params=repr(seg), options="{}")
+    out2 = str(tmp_path / "out_s")
+    worker.worker(argparse.Namespace(job=fn2, out=out2))
+    mask = np.load(os.path.join(out2, "mask.npy"))
+    inter = np.logical_and(mask == 1, lab[None] == 1).sum()
+    union = np.logical_or(mask == 1, lab[None] == 1).sum()
+    assert inter / union > 0.8                                  # IoU of the trained model on its own data
