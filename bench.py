@@ -166,6 +166,67 @@ def main_train(args):
         dist.destroy_process_group()
 
 
+def main_gan(args):
+    """BASELINE configs[4]: progressive WGAN-GP at level 6 (256x256x2), batch 32 per GPU, alpha = 1;
+    one iteration = one d_solver + one g_solver (sequitr/networks/gan.py:850-851)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    from sequitr_amd.networks.gan import GenerativeAdverserialNetwork
+    nb, level = 32, 6
+    g = GenerativeAdverserialNetwork({"num_levels": 7, "batch_size": nb, "repeat_batch": 1, "learning_rate": 1e-3,
+                                      "device": str(dev), "seed": 0}, mode=None)
+    g.build()
+    g.set_level(level)
+    rng = np.random.default_rng(3 + rank)
+    X = torch.from_numpy(rng.standard_normal((nb, 256, 256, 2)).astype(np.float32)).to(dev)
+    Z = torch.from_numpy(rng.standard_normal((nb, 1, 1, 512)).astype(np.float32)).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def it():
+        g.d_solver(X, Z, 1.0)
+        g.g_solver(X, Z, 1.0)
+
+    for _ in range(args.warmup):
+        it()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        it()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        samples = float(world) * nb * args.steps
+        print(json.dumps({"metric": "GAN training Mpixels/sec (256x256 samples; one D step + one G step)",
+                          "value": round(samples * 256 * 256 / dt / 1e6, 3), "unit": "Mpixels/s",
+                          "samples_per_s": round(samples / dt, 2), "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic",
+                          "config": {"workload": "progressive WGAN-GP level 6 (256x256x2), filters "
+                                                 "[512,256,128,64,32,16,8], batch 32 per GPU, alpha 1; fp32",
+                                     "d_loss": g.last_losses[0], "g_loss": g.last_losses[1]}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,12 +234,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+    ap.add_argument("--mode", choices=["infer", "train", "gan"], default="infer",
                     help="infer = the headline metric (BASELINE configs[1]); train = configs[2]/[3] "
                          "(U-Net training step, batch 16 per GPU) for DESIGN.md, not the driver's line")
     args = ap.parse_args()
     if args.mode == "train":
         return main_train(args)
+    if args.mode == "gan":
+        return main_gan(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

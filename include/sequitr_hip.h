@@ -237,6 +237,27 @@ int sq_conv3x3_first_block_fwd_f32(const float *x, const float *w1, const float 
                                    const float *b2, float *y, float *pooled, int N, int H, int W,
                                    void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * bf16 path (BASELINE configs 3-5: bf16 compute, fp32 master weights and accumulation).
+ * bf16 tensors are passed as void* (2-byte elements, NHWC); biases / logits / weight grads stay f32.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Packed bf16 filter of the KxK conv Cin -> Cout: [Cin/KC][Cout][KP] with k = tap*KC + c, KC = 32 when
+ * Cin % 32 == 0 else 16, KP = K*K*KC rounded up to 32.  sq_conv_packed_weights_elems_bf16 gives the
+ * element count (-1: unsupported).  transform != 0 packs the dgrad filter of the forward conv
+ * Cout -> Cin whose f32 HWIO weights (K,K,Cout,Cin) are passed in `w`. */
+int64_t sq_conv_packed_weights_elems_bf16(int K, int Cin, int Cout);
+int sq_conv_pack_weights_bf16(const float *w, void *wp, int K, int Cin, int Cout, float wscale, int transform,
+                              void *stream);
+
+/* conv_layer / weighted_conv2d on bf16 activations: y = act(conv(x, wp) + bias), fp32 accumulate. */
+int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H, int W,
+                            int Cin, int Cout, int K, int act, void *stream);
+
+/* first conv of down0 in the bf16 graph: f32 (N,H,W,1) image -> bf16 (N,H,W,Cout), 3x3, f32 HWIO weights. */
+int sq_conv3x3_first_fwd_bf16(const float *x, const float *w, const float *bias, void *y, int N, int H, int W,
+                              int Cout, int act, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

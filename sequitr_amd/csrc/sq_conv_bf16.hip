@@ -1,0 +1,384 @@
+// bf16 NHWC convolution (3x3 / 1x1, SAME, stride 1) for gfx950 on v_mfma_f32_16x16x32_bf16:
+// bf16 activations and weights, fp32 accumulation, + fp32 bias, activation, bf16 output.
+// The training path of BASELINE configs 3-5 ("bf16 compute, fp32 master weights + accumulation").
+//
+// Same structure as sq_conv_f32_v2.hip (persistent blocks over 16x16 pixel tiles, register prefetch of
+// the next work item under the MFMA phase, buffer loads/stores with out-of-range = 0 / dropped), same
+// operand roles (A = weights [cout][k], B = pixels [k][pixel], so a lane ends with 4 consecutive output
+// channels of one pixel -> one 8-byte bf16x4 store), but K = 32 per instruction:
+//   KC = 32 (Cin % 32 == 0): one MFMA step = one tap x 32 channels;
+//   KC = 16 (otherwise)    : one MFMA step = two taps x 16 channels (the 10th half-step has zero weights).
+// Weights are pre-packed once per optimiser step into [chunk][cout][KP] bf16 (k contiguous per output
+// channel), optionally rotated/transposed for dgrad: sq_conv_pack_weights_bf16.
+// At levels 0-1 these kernels are HBM-bound (the matrix pipe is 16x the f32 rate); halving the bytes
+// is the point of the bf16 path.
+#include "sq_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TH = 16, TW = 16;
+
+__host__ __device__ constexpr int kp_for(int KS, int KC) { return ((KS * KS * KC + 31) / 32) * 32; }
+
+template <int BN, int KS, int KC>
+struct CfgB {
+    static constexpr int HALO_W = TW + KS - 1;
+    static constexpr int HP = HALO_W * (TH + KS - 1);
+    static constexpr int PSB = KC == 16 ? 32 : 96;             // pixel stride in BYTES (conflict-free b128 reads)
+    static constexpr int KP = kp_for(KS, KC);                 // padded k per chunk
+    static constexpr int WROWB = KP * 2 + ((KP * 2 / 16) % 16 == 6 ? 0 : ((6 - (KP * 2 / 16) % 16 + 16) % 16) * 16);
+    static constexpr int XS_BYTES = HP * PSB;
+    static constexpr int WS_BYTES = BN * WROWB;
+    static constexpr int LDS_BYTES = XS_BYTES + WS_BYTES;
+    static constexpr int XQ = KC / 8;                          // 16-byte items per halo pixel
+    static constexpr int XITEMS = HP * XQ;
+    static constexpr int XSLOTS = (XITEMS + 255) / 256;
+    static constexpr int WQ = KP / 8;                          // 16-byte items per weight row
+    static constexpr int WITEMS = BN * WQ;
+    static constexpr int WSLOTS = (WITEMS + 255) / 256;
+    static constexpr int NSTEP = KP / 32;
+    static_assert(XS_BYTES % 16 == 0, "weight slab must start 16-B aligned");
+    static_assert((WROWB / 16) % 16 == 6, "weight row stride must be 6 slots mod 16");
+};
+
+// packed weights: wp[chunk][co][k], k = tap*KC + c (zero padded to KP); source HWIO f32 (K,K,Cin,Cout).
+// transform != 0: the dgrad filter, i.e. source element w[K-1-ky][K-1-kx][co][ci] (roles of Cin/Cout
+// swapped: the packed tensor then has `Cin` = original Cout input channels, `Cout` = original Cin).
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float *__restrict__ w, __bf16 *__restrict__ wp,
+                                                                 int K, int Cin, int Cout, int KC, int KP,
+                                                                 float wscale, int transform) {
+    const int64_t total = (int64_t)(Cin / KC) * Cout * KP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % KP);
+        const int co = (int)((i / KP) % Cout);
+        const int chunk = (int)(i / ((int64_t)KP * Cout));
+        float v = 0.f;
+        if (k < K * K * KC) {
+            const int tap = k / KC, c = chunk * KC + k % KC;
+            if (!transform) {
+                v = w[((size_t)tap * Cin + c) * Cout + co];
+            } else {
+                const int ky = tap / K, kx = tap % K;
+                // original tensor is (K,K,Cout_packed_as_in?..): here Cin/Cout are those of the PACKED conv
+                v = w[((size_t)((K - 1 - ky) * K + (K - 1 - kx)) * Cout + co) * Cin + c];
+            }
+            v *= wscale;
+        }
+        wp[i] = (__bf16)v;
+    }
+}
+
+template <int BN, int KS, int KC>
+__global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
+    const __bf16 *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+    __bf16 *__restrict__ y, int N, int H, int W, int Cin, int Cout, int act, int tiles_x, int tiles_y,
+    int ntiles, int tiles_per_block) {
+    using C = CfgB<BN, KS, KC>;
+    constexpr int NR = BN / 16, PAD = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *xs = smem;
+    unsigned char *ws = smem + C::XS_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.y * BN;
+    const int vb = (int)sq_xcd_remap(blockIdx.x, gridDim.x);
+    const int t_begin = vb * tiles_per_block;
+    const int t_end = min(t_begin + tiles_per_block, ntiles);
+    if (t_begin >= t_end) return;
+    const int nchunk = Cin / KC;
+    const int nitems = (t_end - t_begin) * nchunk;
+    const bool restage_w = nchunk > 1;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16 *>(x), 0, (int)((size_t)N * H * W * Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16 *>(wp), 0, (int)((size_t)nchunk * Cout * C::KP * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        y, 0, (int)((size_t)N * H * W * Cout * 2), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    uint4 xr[C::XSLOTS], wr[C::WSLOTS];
+    int xrel[C::XSLOTS], xpy[C::XSLOTS], xpx[C::XSLOTS];
+#pragma unroll
+    for (int sl = 0; sl < C::XSLOTS; ++sl) {
+        const int idx = tid + sl * 256;
+        const int pix = idx / C::XQ, q = idx % C::XQ;
+        xpy[sl] = pix / C::HALO_W;
+        xpx[sl] = pix % C::HALO_W;
+        xrel[sl] = idx < C::XITEMS ? ((xpy[sl] * W + xpx[sl]) * Cin + q * 8) * 2 : (int)OOB;
+    }
+    int wrel[C::WSLOTS];
+#pragma unroll
+    for (int sl = 0; sl < C::WSLOTS; ++sl) {
+        const int idx = tid + sl * 256;
+        const int row = idx / C::WQ, q = idx % C::WQ;
+        wrel[sl] = (idx < C::WITEMS && n0 + row < Cout) ? (((n0 + row) * C::KP) + q * 8) * 2 : (int)OOB;
+    }
+
+    auto issue = [&](int tile, int chunk, bool want_w) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx * TW - PAD, y0 = ty * TH - PAD;
+        const int base = (((n * H + y0) * W + x0) * Cin + chunk * KC) * 2;
+#pragma unroll
+        for (int sl = 0; sl < C::XSLOTS; ++sl) {
+            const bool inb = (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
+                             xrel[sl] != (int)OOB;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? (unsigned)(base + xrel[sl]) : OOB, 0, 0);
+            xr[sl] = *reinterpret_cast<const uint4 *>(&v);
+        }
+        if (want_w) {
+            const int wbase = chunk * Cout * C::KP * 2;
+#pragma unroll
+            for (int sl = 0; sl < C::WSLOTS; ++sl) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(
+                    wrsrc, wrel[sl] != (int)OOB ? (unsigned)(wbase + wrel[sl]) : OOB, 0, 0);
+                wr[sl] = *reinterpret_cast<const uint4 *>(&v);
+            }
+        }
+    };
+    auto commit = [&](bool want_w) {
+#pragma unroll
+        for (int sl = 0; sl < C::XSLOTS; ++sl) {
+            const int idx = tid + sl * 256;
+            if (idx < C::XITEMS)
+                *reinterpret_cast<uint4 *>(xs + (idx / C::XQ) * C::PSB + (idx % C::XQ) * 16) = xr[sl];
+        }
+        if (want_w) {
+#pragma unroll
+            for (int sl = 0; sl < C::WSLOTS; ++sl) {
+                const int idx = tid + sl * 256;
+                if (idx < C::WITEMS)
+                    *reinterpret_cast<uint4 *>(ws + (idx / C::WQ) * C::WROWB + (idx % C::WQ) * 16) = wr[sl];
+            }
+        }
+    };
+
+    // per-lane fragment addressing
+    //   KC = 32: step = tap, the lane's 8 channels are 8*kg .. 8*kg+7
+    //   KC = 16: step s covers taps 2s (kg 0,1) and 2s+1 (kg 2,3), channels 8*(kg&1) ..
+    const unsigned char *xb = xs + ((4 * wv) * C::HALO_W + li) * C::PSB + (KC == 32 ? kg * 16 : (kg & 1) * 16);
+    const unsigned char *wa = ws + li * C::WROWB + kg * 16;
+    int toff[C::NSTEP];
+#pragma unroll
+    for (int s = 0; s < C::NSTEP; ++s) {
+        int tap = KC == 32 ? s : 2 * s + (kg >> 1);
+        if (tap > KS * KS - 1) tap = KS * KS - 1;                  // zero-weight padding step: any valid address
+        toff[s] = ((tap / KS) * C::HALO_W + tap % KS) * C::PSB;
+    }
+
+    f32x4 acc[4][NR];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NR; ++nb) acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float slope = act == SQ_ACT_LEAKY ? 0.2f : 1.0f;
+    const bool is_relu = act == SQ_ACT_RELU;
+    auto actf = [&](float v) {
+        const float neg = is_relu ? 0.0f : v * slope;
+        return v > 0.0f ? v : neg;
+    };
+    auto epilogue = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int gx = tx * TW + li;
+#pragma unroll
+        for (int nb = 0; nb < NR; ++nb) {
+            const int co = n0 + nb * 16 + 4 * kg;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias && co < Cout) bv = *reinterpret_cast<const float4 *>(bias + co);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gy = ty * TH + 4 * wv + r;
+                bf16x4 o;
+                o[0] = (__bf16)actf(acc[r][nb][0] + bv.x);
+                o[1] = (__bf16)actf(acc[r][nb][1] + bv.y);
+                o[2] = (__bf16)actf(acc[r][nb][2] + bv.z);
+                o[3] = (__bf16)actf(acc[r][nb][3] + bv.w);
+                const bool ok = gy < H && gx < W && co < Cout;
+                const unsigned off = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 2) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
+                    __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, o), yrsrc, off, 0, 0);
+                acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+
+    issue(t_begin, 0, true);
+    commit(true);
+    __syncthreads();
+    int tile = t_begin, chunk = 0;
+    for (int it = 0; it < nitems; ++it) {
+        int ntile = tile, nchk = chunk + 1;
+        if (nchk == nchunk) { nchk = 0; ntile = tile + 1; }
+        const bool has_next = it + 1 < nitems;
+        if (has_next) issue(ntile, nchk, restage_w);
+#pragma unroll
+        for (int s = 0; s < C::NSTEP; ++s) {
+            bf16x8 a[NR], b[4];
+#pragma unroll
+            for (int nb = 0; nb < NR; ++nb)
+                a[nb] = *reinterpret_cast<const bf16x8 *>(wa + nb * 16 * C::WROWB + s * 64);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                b[r] = *reinterpret_cast<const bf16x8 *>(xb + r * C::HALO_W * C::PSB + toff[s]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NR; ++nb)
+                    acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nb], b[r], acc[r][nb], 0, 0, 0);
+        }
+        if (has_next) {
+            __syncthreads();
+            commit(restage_w);
+        }
+        if (chunk == nchunk - 1) epilogue(tile);
+        if (has_next) __syncthreads();
+        tile = ntile;
+        chunk = nchk;
+    }
+}
+
+// first layer (Cin = 1, f32 image in): direct 3x3 conv, 16 output channels per thread, bf16 out
+__global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                               const float *__restrict__ bias, __bf16 *__restrict__ y,
+                                                               int N, int H, int W, int Cout, int act, int tiles_x,
+                                                               int tiles_y) {
+    constexpr int HW = TW + 2;
+    __shared__ float xs[HW * HW];
+    __shared__ float wsh[9 * 16];
+    const int tid = threadIdx.x, sp = blockIdx.x;
+    const int tx = sp % tiles_x, ty = (sp / tiles_x) % tiles_y, n = sp / (tiles_x * tiles_y);
+    const int x0 = tx * TW, y0 = ty * TH, n0 = blockIdx.y * 16;
+    for (int idx = tid; idx < HW * HW; idx += 256) {
+        const int gy = y0 - 1 + idx / HW, gx = x0 - 1 + idx % HW;
+        xs[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)n * H + gy) * W + gx] : 0.f;
+    }
+    for (int idx = tid; idx < 144; idx += 256) wsh[idx] = (n0 + idx % 16 < Cout) ? w[(idx / 16) * Cout + n0 + idx % 16] : 0.f;
+    __syncthreads();
+    const int py = tid >> 4, px = tid & 15;
+    float a[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) a[o] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float xv = xs[(py + t / 3) * HW + px + t % 3];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) a[o] = __builtin_fmaf(wsh[t * 16 + o], xv, a[o]);
+    }
+    const int gy = y0 + py, gx = x0 + px;
+    if (gy < H && gx < W) {
+        __bf16 *yo = y + ((size_t)(n * H + gy) * W + gx) * Cout + n0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (n0 + q * 8 >= Cout) break;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = a[q * 8 + j] + (bias ? bias[n0 + q * 8 + j] : 0.f);
+                o[j] = (__bf16)sq_act(v, act);
+            }
+            *reinterpret_cast<bf16x8 *>(yo + q * 8) = o;
+        }
+    }
+}
+
+template <int BN, int KS, int KC>
+int launch(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int N, int H, int W, int Cin, int Cout,
+           int act, hipStream_t st) {
+    using C = CfgB<BN, KS, KC>;
+    static bool attr_set = false;
+    auto kern = conv_mfma_bf16_kernel<BN, KS, KC>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess) {
+            sq_set_error("conv_mfma_bf16: cannot reserve %d bytes of LDS", C::LDS_BYTES);
+            return SQ_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * N;
+    const int gy = (Cout + BN - 1) / BN;
+    int want = (256 * 2 + gy - 1) / gy;
+    if (want < 1) want = 1;
+    int tpb = (ntiles + want - 1) / want;
+    if (tpb < 1) tpb = 1;
+    const int gx = (ntiles + tpb - 1) / tpb;
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), C::LDS_BYTES, st, x, wp, bias, y, N, H, W, Cin, Cout, act,
+                       tiles_x, tiles_y, ntiles, tpb);
+    return sq_check_launch("sq_conv2d_nhwc_fwd_bf16");
+}
+
+template <int KS, int KC>
+int dispatch_bn(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int N, int H, int W, int Cin,
+                int Cout, int act, hipStream_t st) {
+    if (Cout >= 64) return launch<64, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st);
+    if (Cout > 16) return launch<32, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st);
+    return launch<16, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st);
+}
+
+inline int kc_for(int Cin) { return Cin % 32 == 0 ? 32 : 16; }
+
+}  // namespace
+
+extern "C" int64_t sq_conv_packed_weights_elems_bf16(int K, int Cin, int Cout) {
+    if ((K != 1 && K != 3) || Cin <= 0 || Cin % 16 || Cout <= 0) return -1;
+    const int KC = kc_for(Cin);
+    return (int64_t)(Cin / KC) * Cout * kp_for(K, KC);
+}
+
+// f32 HWIO (K,K,Cin,Cout) [* wscale] -> packed bf16 filter of the conv Cin -> Cout.
+// transform != 0: `w` is the filter of the FORWARD conv Cout -> Cin, i.e. stored (K,K,Cout,Cin); the packed
+// result is its dgrad filter (taps rotated by 180 degrees, channel roles swapped).
+extern "C" int sq_conv_pack_weights_bf16(const float *w, void *wp, int K, int Cin, int Cout, float wscale,
+                                         int transform, void *stream) {
+    SQ_REQUIRE(w && wp, "sq_conv_pack_weights_bf16: null pointer");
+    const int64_t n = sq_conv_packed_weights_elems_bf16(K, Cin, Cout);
+    SQ_REQUIRE(n > 0, "sq_conv_pack_weights_bf16: unsupported K=%d Cin=%d Cout=%d (Cin %% 16 == 0)", K, Cin, Cout);
+    const int KC = kc_for(Cin);
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       w, reinterpret_cast<__bf16 *>(wp), K, Cin, Cout, KC, kp_for(K, KC), wscale, transform);
+    return sq_check_launch("sq_conv_pack_weights_bf16");
+}
+
+// conv_layer / weighted_conv2d on bf16 tensors: x (N,H,W,Cin) bf16, wp from sq_conv_pack_weights_bf16,
+// bias f32 or NULL, y (N,H,W,Cout) bf16.  Cin % 16 == 0, Cout % 4 == 0.
+extern "C" int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H,
+                                       int W, int Cin, int Cout, int K, int act, void *stream) {
+    SQ_REQUIRE(x && wp && y, "sq_conv2d_nhwc_fwd_bf16: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && (K == 1 || K == 3), "sq_conv2d_nhwc_fwd_bf16: bad shape / K");
+    SQ_REQUIRE(Cin % 16 == 0 && Cin > 0 && Cout % 4 == 0 && Cout > 0,
+               "sq_conv2d_nhwc_fwd_bf16: Cin=%d (multiple of 16), Cout=%d (multiple of 4)", Cin, Cout);
+    SQ_REQUIRE((size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 2 < ((size_t)1 << 31),
+               "sq_conv2d_nhwc_fwd_bf16: tensors must be < 2 GiB");
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_conv2d_nhwc_fwd_bf16: bad activation %d", act);
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(wp); SQ_REQUIRE_ALIGNED(y);
+    if (bias) SQ_REQUIRE_ALIGNED(bias);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *wb = reinterpret_cast<const __bf16 *>(wp);
+    __bf16 *yb = reinterpret_cast<__bf16 *>(y);
+    if (kc_for(Cin) == 32)
+        return K == 3 ? dispatch_bn<3, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st)
+                      : dispatch_bn<1, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st);
+    return K == 3 ? dispatch_bn<3, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st)
+                  : dispatch_bn<1, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st);
+}
+
+// first conv of down0 in the bf16 graph: f32 single-channel image in, bf16 activation out.
+extern "C" int sq_conv3x3_first_fwd_bf16(const float *x, const float *w, const float *bias, void *y, int N, int H,
+                                         int W, int Cout, int act, void *stream) {
+    SQ_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0,
+               "sq_conv3x3_first_fwd_bf16: bad arguments (Cout %% 8 == 0)");
+    SQ_REQUIRE_ALIGNED(y);
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    hipLaunchKernelGGL(conv_first_bf16_kernel, dim3((unsigned)(tiles_x * tiles_y) * N, (Cout + 15) / 16), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, w, bias, reinterpret_cast<__bf16 *>(y), N, H, W, Cout,
+                       act, tiles_x, tiles_y);
+    return sq_check_launch("sq_conv3x3_first_fwd_bf16");
+}
