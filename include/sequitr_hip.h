@@ -258,6 +258,12 @@ int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, vo
 int sq_conv3x3_first_fwd_bf16(const float *x, const float *w, const float *bias, void *y, int N, int H, int W,
                               int Cout, int act, void *stream);
 
+/* dW (K,K,Cin,Cout) f32 and db (Cout, may be NULL) f32 from bf16 X (N,H,W,Cin) and bf16 dY (N,H,W,Cout);
+ * Cin % 16 == 0, Cout % 16 == 0.  Transposing LDS reads (ds_read_b64_tr_b16) feed the MFMA. */
+int64_t sq_conv2d_nhwc_wgrad_workspace_bf16(int N, int H, int W, int Cin, int Cout, int K);
+int sq_conv2d_nhwc_wgrad_bf16(const void *x, const void *dy, float *dw, float *db, float *workspace, int N,
+                              int H, int W, int Cin, int Cout, int K, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

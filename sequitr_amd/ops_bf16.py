@@ -59,3 +59,20 @@ def conv3x3_first(x, w, bias, act="relu"):
     _lib.check(lib.sq_conv3x3_first_fwd_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), N, H, W, Cout, ACT[act], _stream()),
                "sq_conv3x3_first_fwd_bf16")
     return y
+
+
+def conv2d_wgrad(x, dy, K, want_bias=True):
+    """(dW (K,K,Cin,Cout) f32, db f32 or None) from bf16 X and bf16 dY."""
+    _chk(x, "x", ndim=4), _chk(dy, "dy", ndim=4)
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    lib = _lib.load()
+    nbytes = lib.sq_conv2d_nhwc_wgrad_workspace_bf16(N, H, W, Cin, Cout, K)
+    if nbytes < 0:
+        raise _lib.SequitrHipError("conv2d_wgrad(bf16): unsupported Cin=%d Cout=%d K=%d" % (Cin, Cout, K))
+    ws = _workspace(nbytes, x.device)
+    dw = torch.empty((K, K, Cin, Cout), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    _lib.check(lib.sq_conv2d_nhwc_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout, K,
+                                            _stream()), "sq_conv2d_nhwc_wgrad_bf16")
+    return dw, db

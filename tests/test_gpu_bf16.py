@@ -70,3 +70,20 @@ def test_first_conv_bf16():
                             torch.as_tensor(w, dtype=torch.float64).permute(3, 2, 0, 1),
                             torch.as_tensor(b, dtype=torch.float64), padding=1)).permute(0, 2, 3, 1)
     check_bf16(ob.conv3x3_first(dev(x), dev(w), dev(b)), ref, "first conv")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,K", [(2, 32, 48, 16, 16, 3), (1, 32, 32, 32, 64, 3), (2, 21, 19, 16, 32, 3),
+                                              (1, 16, 16, 64, 256, 1), (1, 16, 16, 128, 128, 3)])
+def test_wgrad_bf16(N, H, W, Cin, Cout, K):
+    x, dy = tiles(9, N, H, W, Cin), tiles(10, N, H, W, Cout)
+    xb, dyb = bf16_round(x), bf16_round(dy)
+    wt = torch.zeros((Cout, Cin, K, K), dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    TF.conv2d(xb.permute(0, 3, 1, 2), wt, bt, padding=K // 2).backward(dyb.permute(0, 3, 1, 2))
+    dw, db = ob.conv2d_wgrad(dev(x, torch.bfloat16), dev(dy, torch.bfloat16), K)
+    ref_w = wt.grad.permute(2, 3, 1, 0).numpy()                          # OIHW -> HWIO
+    scale = np.abs(ref_w).max()
+    assert np.abs(dw.cpu().numpy() - ref_w).max() <= 2e-6 * scale        # f32 accumulation of exact products
+    assert np.abs(db.cpu().numpy() - bt.grad.numpy()).max() <= 2e-6 * np.abs(bt.grad.numpy()).max()
+    dw2, _ = ob.conv2d_wgrad(dev(x, torch.bfloat16), dev(dy, torch.bfloat16), K)
+    assert torch.equal(dw, dw2)
