@@ -264,6 +264,39 @@ int64_t sq_conv2d_nhwc_wgrad_workspace_bf16(int N, int H, int W, int Cin, int Co
 int sq_conv2d_nhwc_wgrad_bf16(const void *x, const void *dy, float *dw, float *db, float *workspace, int N,
                               int H, int W, int Cin, int Cout, int K, void *stream);
 
+/* bf16 <-> f32 casts (RNE), n % 4 == 0 */
+int sq_cast_f32_to_bf16(const float *x, void *y, int64_t n, void *stream);
+int sq_cast_bf16_to_f32(const void *x, float *y, int64_t n, void *stream);
+
+/* bf16 variants of the streaming ops (C % 8 == 0 / n % 8 == 0): same semantics as the f32 entries */
+int sq_maxpool2x2_fwd_bf16(const void *x, void *y, int N, int H, int W, int C, void *stream);
+int sq_maxpool2x2_bwd_bf16(const void *x, const void *dy, void *dx, int N, int H, int W, int C, void *stream);
+int sq_act_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, int act, void *stream);
+int sq_bridge_fwd_bf16(const void *a, const void *b, void *y, int64_t n, int bridge, void *stream);
+int sq_bridge_bwd_bf16(const void *dy, const void *a, const void *b, void *da, void *db, int64_t n, int bridge,
+                       void *stream);
+int sq_dropout_fwd_bf16(const void *x, void *y, uint8_t *mask, int64_t n, float rate, uint32_t seed,
+                        int mask_given, void *stream);
+int sq_dropout_bwd_bf16(const void *dy, const uint8_t *mask, void *dx, int64_t n, float rate, void *stream);
+
+/* conv_transpose_layer + bridge on bf16 tensors; w = bf16 copy of the (2,2,Cout,Cin) kernel, bias f32.
+ * Cin % 32 == 0, Cout % 16 == 0.  The up-scaled value is rounded to bf16 before the bridge. */
+int sq_convT2x2s2_nhwc_fwd_bf16(const void *x, const void *w, const float *bias, const void *skip, void *y,
+                                int N, int H, int W, int Cin, int Cout, int bridge, void *stream);
+
+/* to_image head on a bf16 activation: f32 (Cin,Cout<=4) weights, f32 logits + uint8 mask (may be NULL);
+ * backward: dz f32 -> dx bf16 (may be NULL), dw (Cin,Cout) f32, db f32; Cin in {16,32}, Cout <= 2. */
+int sq_conv1x1_head_fwd_bf16(const void *x, const float *w, const float *bias, float *logits, uint8_t *mask,
+                             int64_t npix, int Cin, int Cout, void *stream);
+int64_t sq_conv1x1_head_bwd_workspace_bf16(int64_t npix, int Cin, int Cout);
+int sq_conv1x1_head_bwd_bf16(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db,
+                             float *workspace, int64_t npix, int Cin, int Cout, void *stream);
+
+/* weight gradient of the first (1 -> Cout) 3x3 convolution from the f32 image and a bf16 dY */
+int64_t sq_conv3x3_first_wgrad_workspace_bf16(int N, int H, int Cout);
+int sq_conv3x3_first_wgrad_bf16(const float *x, const void *dy, float *dw, float *db, float *workspace, int N,
+                                int H, int W, int Cout, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,21 @@ SIGNATURES = {
     "sq_conv3x3_first_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "sq_conv2d_nhwc_wgrad_workspace_bf16": (c_int64, [c_int] * 6),
     "sq_conv2d_nhwc_wgrad_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "sq_cast_f32_to_bf16": (c_int, [c_void_p] * 2 + [c_int64, c_void_p]),
+    "sq_cast_bf16_to_f32": (c_int, [c_void_p] * 2 + [c_int64, c_void_p]),
+    "sq_maxpool2x2_fwd_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "sq_maxpool2x2_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "sq_act_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
+    "sq_bridge_fwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
+    "sq_bridge_bwd_bf16": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_void_p]),
+    "sq_dropout_fwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_float, ctypes.c_uint32, c_int, c_void_p]),
+    "sq_dropout_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_float, c_void_p]),
+    "sq_convT2x2s2_nhwc_fwd_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "sq_conv1x1_head_fwd_bf16": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
+    "sq_conv1x1_head_bwd_workspace_bf16": (c_int64, [c_int64, c_int, c_int]),
+    "sq_conv1x1_head_bwd_bf16": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]),
+    "sq_conv3x3_first_wgrad_workspace_bf16": (c_int64, [c_int] * 3),
+    "sq_conv3x3_first_wgrad_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
 }
 
 _lib = None

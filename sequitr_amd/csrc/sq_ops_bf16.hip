@@ -1,0 +1,524 @@
+// bf16-activation variants of the HBM-bound ops and of the transpose convolution / head, gfx950.
+// 16 B per lane = 8 bf16; arithmetic in f32 registers, one rounding (RNE) when a value is stored.
+#include "sq_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+inline unsigned grid_for(int64_t items) {
+    int64_t b = (items + 255) / 256;
+    if (b > 2048) b = 2048;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+#define SQ_GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n); i += (int64_t)gridDim.x * 256)
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float4 *__restrict__ x, bf16x4 *__restrict__ y, int64_t n4) {
+    SQ_GRID_STRIDE(i, n4) {
+        const float4 v = x[i];
+        y[i] = (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16x4 *__restrict__ x, float4 *__restrict__ y, int64_t n4) {
+    SQ_GRID_STRIDE(i, n4) {
+        const bf16x4 v = x[i];
+        y[i] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bf16_kernel(const bf16x8 *__restrict__ x, bf16x8 *__restrict__ y, int N,
+                                                            int H, int W, int C8) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int64_t total = (int64_t)N * Ho * Wo * C8;
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C8);
+        int64_t t = i / C8;
+        const int xo = (int)(t % Wo);
+        t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int64_t b = (((int64_t)n * H + 2 * yo) * W + 2 * xo) * C8 + c;
+        const bf16x8 a = x[b], bb = x[b + C8], d = x[b + (int64_t)W * C8], e = x[b + (int64_t)W * C8 + C8];
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float m = (float)a[j];
+            const float f1 = (float)bb[j], f2 = (float)d[j], f3 = (float)e[j];
+            m = f1 > m ? f1 : m; m = f2 > m ? f2 : m; m = f3 > m ? f3 : m;
+            r[j] = (__bf16)m;
+        }
+        y[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const bf16x8 *__restrict__ x, const bf16x8 *__restrict__ dy,
+                                                                bf16x8 *__restrict__ dx, int N, int H, int W, int C8) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int64_t total = (int64_t)N * Ho * Wo * C8;
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C8);
+        int64_t t = i / C8;
+        const int xo = (int)(t % Wo);
+        t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int64_t b00 = (((int64_t)n * H + 2 * yo) * W + 2 * xo) * C8 + c;
+        const int64_t b01 = b00 + C8, b10 = b00 + (int64_t)W * C8, b11 = b10 + C8;
+        const bf16x8 a = x[b00], b = x[b01], d = x[b10], e = x[b11], g = dy[i];
+        bf16x8 ra, rb, rd, re;
+        const __bf16 z = (__bf16)0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float m = (float)a[j];
+            int k = 0;
+            if ((float)b[j] > m) { m = (float)b[j]; k = 1; }
+            if ((float)d[j] > m) { m = (float)d[j]; k = 2; }
+            if ((float)e[j] > m) { m = (float)e[j]; k = 3; }
+            ra[j] = k == 0 ? g[j] : z; rb[j] = k == 1 ? g[j] : z; rd[j] = k == 2 ? g[j] : z; re[j] = k == 3 ? g[j] : z;
+        }
+        dx[b00] = ra; dx[b01] = rb; dx[b10] = rd; dx[b11] = re;
+    }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_bf16_kernel(const bf16x8 *__restrict__ dy, const bf16x8 *__restrict__ y,
+                                                            bf16x8 *__restrict__ dx, int64_t n8, int act) {
+    const float slope = act == SQ_ACT_LEAKY ? 0.2f : (act == SQ_ACT_RELU ? 0.0f : 1.0f);
+    SQ_GRID_STRIDE(i, n8) {
+        const bf16x8 g = dy[i], v = y[i];
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (float)v[j] > 0.f ? g[j] : (__bf16)((float)g[j] * slope);
+        dx[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void bridge_bf16_kernel(const bf16x8 *__restrict__ a, const bf16x8 *__restrict__ b,
+                                                           bf16x8 *__restrict__ y, int64_t n8, int op) {
+    SQ_GRID_STRIDE(i, n8) {
+        const bf16x8 u = a[i], v = b[i];
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = (float)u[j], q = (float)v[j];
+            r[j] = (__bf16)(op == SQ_BRIDGE_ADD ? p + q : (op == SQ_BRIDGE_MUL ? p * q : (op == SQ_BRIDGE_SUB ? p - q : p)));
+        }
+        y[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void bridge_bwd_bf16_kernel(const bf16x8 *__restrict__ dy, const bf16x8 *__restrict__ a,
+                                                               const bf16x8 *__restrict__ b, bf16x8 *__restrict__ da,
+                                                               bf16x8 *__restrict__ db, int64_t n8, int op) {
+    SQ_GRID_STRIDE(i, n8) {
+        const bf16x8 g = dy[i];
+        if (op == SQ_BRIDGE_MUL) {
+            const bf16x8 u = a[i], v = b[i];
+            bf16x8 ra, rb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ra[j] = (__bf16)((float)g[j] * (float)v[j]);
+                rb[j] = (__bf16)((float)g[j] * (float)u[j]);
+            }
+            da[i] = ra; db[i] = rb;
+        } else {
+            da[i] = g;
+            if (op == SQ_BRIDGE_SUB) {
+                bf16x8 r;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (__bf16)(-(float)g[j]);
+                db[i] = r;
+            } else {
+                db[i] = g;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned hash32(unsigned a, unsigned b) {          // same hash as the f32 dropout
+    unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    h += b * 0x27D4EB2Fu; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void dropout_fwd_bf16_kernel(const __bf16 *__restrict__ x, __bf16 *__restrict__ y,
+                                                                uint8_t *__restrict__ mask, int64_t n, float rate,
+                                                                unsigned seed, int mask_given) {
+    const unsigned thr = (unsigned)(rate * 4294967296.0);
+    const float inv = 1.0f / (1.0f - rate);
+    SQ_GRID_STRIDE(i, n) {
+        uint8_t keep;
+        if (mask_given) keep = mask[i];
+        else { keep = hash32(seed, (unsigned)i) >= thr ? 1 : 0; mask[i] = keep; }
+        y[i] = keep ? (__bf16)((float)x[i] * inv) : (__bf16)0.f;
+    }
+}
+__global__ __launch_bounds__(256) void dropout_bwd_bf16_kernel(const __bf16 *__restrict__ dy, const uint8_t *__restrict__ mask,
+                                                                __bf16 *__restrict__ dx, int64_t n, float rate) {
+    const float inv = 1.0f / (1.0f - rate);
+    SQ_GRID_STRIDE(i, n) dx[i] = mask[i] ? (__bf16)((float)dy[i] * inv) : (__bf16)0.f;
+}
+
+// ---- 2x2/s2 transpose conv + bias + bridge on v_mfma_f32_16x16x32_bf16 ------------------------------------
+// D[rho][p] = sum_c Wt[rho][c] X[p][c], rho = (2a+b)*Cout + o; Wt = the (2,2,Cout,Cin) kernel read flat (k = c is
+// contiguous for both operands: 16-byte fragment reads).  Block = 64 rows x 64 input pixels, 32-channel chunks.
+constexpr int CT_ROWB = 96;                                   // 64 B of data + pad: conflict-free b128 reads
+__global__ __launch_bounds__(256) void convT_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
+                                                          const float *__restrict__ bias, const __bf16 *__restrict__ skip,
+                                                          __bf16 *__restrict__ y, int64_t P, int H, int W, int Cin, int Cout,
+                                                          int bridge) {
+    __shared__ __attribute__((aligned(16))) unsigned char as[64 * CT_ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char xs[64 * CT_ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int r0 = blockIdx.y * 64;
+    f32x4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int srow = tid >> 2, sq = tid & 3;                  // 64 rows x 4 sixteen-byte pieces
+    for (int cc = 0; cc < Cin; cc += 32) {
+        *reinterpret_cast<uint4 *>(as + srow * CT_ROWB + sq * 16) =
+            *reinterpret_cast<const uint4 *>(w + (size_t)(r0 + srow) * Cin + cc + sq * 8);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (p0 + srow < P) v = *reinterpret_cast<const uint4 *>(x + (size_t)(p0 + srow) * Cin + cc + sq * 8);
+        *reinterpret_cast<uint4 *>(xs + srow * CT_ROWB + sq * 16) = v;
+        __syncthreads();
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(as + (16 * wv + li) * CT_ROWB + kg * 16);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(xs + (cb * 16 + li) * CT_ROWB + kg * 16);
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[cb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int rho = r0 + 16 * wv + 4 * kg;
+    const int ab = rho / Cout, o = rho % Cout;
+    const int a2 = ab >> 1, b2 = ab & 1;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4 *>(bias + o);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int64_t p = p0 + cb * 16 + li;
+        if (p >= P) continue;
+        const int j = (int)(p % W);
+        const int64_t t = p / W;
+        const int i = (int)(t % H);
+        const int64_t n = t / H;
+        const size_t off = ((size_t)(n * 2 * H + 2 * i + a2) * (2 * W) + 2 * j + b2) * Cout + o;
+        float v[4] = {acc[cb][0] + bv.x, acc[cb][1] + bv.y, acc[cb][2] + bv.z, acc[cb][3] + bv.w};
+        if (bridge != SQ_BRIDGE_NONE) {
+            const bf16x4 k = *reinterpret_cast<const bf16x4 *>(skip + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // the up-scaled value is rounded to bf16 first: bit-identical to the unfused convT -> bridge pair
+                const float u = (float)(__bf16)v[e], s = (float)k[e];
+                v[e] = bridge == SQ_BRIDGE_ADD ? u + s : (bridge == SQ_BRIDGE_MUL ? u * s : u - s);
+            }
+        }
+        *reinterpret_cast<bf16x4 *>(y + off) = (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+}
+
+// to_image head on a bf16 activation: f32 logits (+ uint8 argmax mask), f32 (Cin, COUT) weights
+template <int COUT>
+__global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
+                                                             const float *__restrict__ bias, float *__restrict__ logits,
+                                                             uint8_t *__restrict__ mask, int64_t npix, int Cin) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+    for (int c8 = 0; c8 < Cin / 8; ++c8) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + p * Cin + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) acc[o] = __builtin_fmaf(w[(c8 * 8 + j) * COUT + o], (float)v[j], acc[o]);
+    }
+    int best = 0;
+    float bestv = 0.f;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+        const float v = acc[o] + (bias ? bias[o] : 0.f);
+        logits[p * COUT + o] = v;
+        if (o == 0 || v > bestv) { bestv = v; best = o; }
+    }
+    if (mask) mask[p] = (uint8_t)best;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);  v += __shfl_xor(v, 2);  v += __shfl_xor(v, 1);
+    return v;
+}
+
+// head backward: x bf16 (CIN ch), dz f32 (COUT ch) -> dx bf16, block partials of dW (CIN,COUT) and db
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
+                                                             const float *__restrict__ dz, __bf16 *__restrict__ dx,
+                                                             float *__restrict__ partials, int64_t npix) {
+    constexpr int NVAL = CIN * COUT + COUT;
+    __shared__ float red[4][NVAL];
+    float gw[CIN][COUT], gb[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) gb[o] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) gw[c][o] = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < npix; base += stride) {
+        const int64_t p = base + threadIdx.x;
+        if (p < npix) {
+            float g[COUT];
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) { g[o] = dz[p * COUT + o]; gb[o] += g[o]; }
+#pragma unroll
+            for (int c8 = 0; c8 < CIN / 8; ++c8) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + p * CIN + c8 * 8);
+                bf16x8 r;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int o = 0; o < COUT; ++o) {
+                        s = __builtin_fmaf(g[o], w[(c8 * 8 + j) * COUT + o], s);
+                        gw[c8 * 8 + j][o] = __builtin_fmaf((float)v[j], g[o], gw[c8 * 8 + j][o]);
+                    }
+                    r[j] = (__bf16)s;
+                }
+                if (dx) *reinterpret_cast<bf16x8 *>(dx + p * CIN + c8 * 8) = r;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            const float v = wave_sum(gw[c][o]);
+            if (lane == 0) red[wv][c * COUT + o] = v;
+        }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+        const float v = wave_sum(gb[o]);
+        if (lane == 0) red[wv][CIN * COUT + o] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NVAL)
+        partials[(size_t)blockIdx.x * NVAL + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void head_finish2_kernel(const float *__restrict__ partials, float *__restrict__ dw,
+                                                            float *__restrict__ db, int nblk, int nw, int nb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nw + nb) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * (nw + nb) + i];
+    if (i < nw) dw[i] = s;
+    else if (db) db[i - nw] = s;
+}
+
+// first-layer weight gradient with a bf16 dY: dW[tap][0][co] = sum_p x[p+tap] dY[p][co] (x f32, 1 channel).
+// One thread per (tap, co) pair and pixel slice; block partials [grid][10][Cout]; fixed-order finish.
+__global__ __launch_bounds__(256) void wgrad_first_bf16_kernel(const float *__restrict__ x, const __bf16 *__restrict__ dy,
+                                                                float *__restrict__ partials, int N, int H, int W, int Cout,
+                                                                int rows_per_block) {
+    // thread = (co, tap-or-bias) : 16 co x 10 -> 160 active threads; loops over the block's image rows
+    const int co = threadIdx.x & 15, t = threadIdx.x >> 4;              // t in 0..15, 0..8 taps, 9 bias
+    const int co0 = blockIdx.y * 16;
+    const int64_t row0 = (int64_t)blockIdx.x * rows_per_block, row1 = min(row0 + rows_per_block, (int64_t)N * H);
+    float s = 0.f;
+    if (t < 10 && co0 + co < Cout) {
+        const int ky = t / 3 - 1, kx = t % 3 - 1;
+        for (int64_t r = row0; r < row1; ++r) {
+            const int n = (int)(r / H), yy = (int)(r % H);
+            const int sy = yy + ky;
+            const bool rowok = t == 9 || (sy >= 0 && sy < H);
+            if (!rowok) continue;
+            const __bf16 *dyr = dy + (r * W) * Cout + co0 + co;
+            const float *xr = x + ((int64_t)n * H + (t == 9 ? yy : sy)) * W;
+            for (int xx = 0; xx < W; ++xx) {
+                const float g = (float)dyr[(int64_t)xx * Cout];
+                if (t == 9) s += g;
+                else {
+                    const int sx = xx + kx;
+                    if (sx >= 0 && sx < W) s = __builtin_fmaf(xr[sx], g, s);
+                }
+            }
+        }
+    }
+    if (t < 10 && co0 + co < Cout) partials[((size_t)blockIdx.x * 10 + t) * Cout + co0 + co] = s;
+}
+__global__ __launch_bounds__(256) void wgrad_first_finish_kernel(const float *__restrict__ partials, float *__restrict__ dw,
+                                                                  float *__restrict__ db, int nblk, int Cout) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 10 * Cout) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * 10 * Cout + i];
+    if (i < 9 * Cout) dw[i] = s;
+    else if (db) db[i - 9 * Cout] = s;
+}
+
+inline int head_blocks(int64_t npix) {
+    int64_t b = (npix + 255) / 256;
+    return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+#define SQ_ST(s) reinterpret_cast<hipStream_t>(s)
+#define BF(p) reinterpret_cast<const __bf16 *>(p)
+#define BFM(p) reinterpret_cast<__bf16 *>(p)
+
+extern "C" int sq_cast_f32_to_bf16(const float *x, void *y, int64_t n, void *stream) {
+    SQ_REQUIRE(x && y && n > 0 && n % 4 == 0, "sq_cast_f32_to_bf16: bad arguments (n %% 4 == 0)");
+    SQ_REQUIRE_ALIGNED(x);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<bf16x4 *>(y), n / 4);
+    return sq_check_launch("sq_cast_f32_to_bf16");
+}
+extern "C" int sq_cast_bf16_to_f32(const void *x, float *y, int64_t n, void *stream) {
+    SQ_REQUIRE(x && y && n > 0 && n % 4 == 0, "sq_cast_bf16_to_f32: bad arguments (n %% 4 == 0)");
+    SQ_REQUIRE_ALIGNED(y);
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const bf16x4 *>(x), reinterpret_cast<float4 *>(y), n / 4);
+    return sq_check_launch("sq_cast_bf16_to_f32");
+}
+
+extern "C" int sq_maxpool2x2_fwd_bf16(const void *x, void *y, int N, int H, int W, int C, void *stream) {
+    SQ_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0,
+               "sq_maxpool2x2_fwd_bf16: need even H,W and C %% 8 == 0");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(y);
+    hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0,
+                       SQ_ST(stream), reinterpret_cast<const bf16x8 *>(x), reinterpret_cast<bf16x8 *>(y), N, H, W, C / 8);
+    return sq_check_launch("sq_maxpool2x2_fwd_bf16");
+}
+extern "C" int sq_maxpool2x2_bwd_bf16(const void *x, const void *dy, void *dx, int N, int H, int W, int C, void *stream) {
+    SQ_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0,
+               "sq_maxpool2x2_bwd_bf16: need even H,W and C %% 8 == 0");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(dx);
+    hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0,
+                       SQ_ST(stream), reinterpret_cast<const bf16x8 *>(x), reinterpret_cast<const bf16x8 *>(dy),
+                       reinterpret_cast<bf16x8 *>(dx), N, H, W, C / 8);
+    return sq_check_launch("sq_maxpool2x2_bwd_bf16");
+}
+extern "C" int sq_act_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, int act, void *stream) {
+    SQ_REQUIRE(dy && y && dx && n > 0 && n % 8 == 0, "sq_act_bwd_bf16: bad arguments (n %% 8 == 0)");
+    SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(y); SQ_REQUIRE_ALIGNED(dx);
+    hipLaunchKernelGGL(act_bwd_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const bf16x8 *>(dy), reinterpret_cast<const bf16x8 *>(y),
+                       reinterpret_cast<bf16x8 *>(dx), n / 8, act);
+    return sq_check_launch("sq_act_bwd_bf16");
+}
+extern "C" int sq_bridge_fwd_bf16(const void *a, const void *b, void *y, int64_t n, int bridge, void *stream) {
+    SQ_REQUIRE(a && b && y && n > 0 && n % 8 == 0, "sq_bridge_fwd_bf16: bad arguments (n %% 8 == 0)");
+    SQ_REQUIRE_ALIGNED(a); SQ_REQUIRE_ALIGNED(b); SQ_REQUIRE_ALIGNED(y);
+    hipLaunchKernelGGL(bridge_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const bf16x8 *>(a), reinterpret_cast<const bf16x8 *>(b),
+                       reinterpret_cast<bf16x8 *>(y), n / 8, bridge);
+    return sq_check_launch("sq_bridge_fwd_bf16");
+}
+extern "C" int sq_bridge_bwd_bf16(const void *dy, const void *a, const void *b, void *da, void *db, int64_t n, int bridge,
+                                  void *stream) {
+    SQ_REQUIRE(dy && da && db && n > 0 && n % 8 == 0, "sq_bridge_bwd_bf16: bad arguments (n %% 8 == 0)");
+    SQ_REQUIRE(bridge >= SQ_BRIDGE_ADD && bridge <= SQ_BRIDGE_SUB, "sq_bridge_bwd_bf16: bad bridge %d", bridge);
+    SQ_REQUIRE(bridge != SQ_BRIDGE_MUL || (a && b), "sq_bridge_bwd_bf16: eltwise_mul needs both forward operands");
+    hipLaunchKernelGGL(bridge_bwd_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const bf16x8 *>(dy), reinterpret_cast<const bf16x8 *>(a),
+                       reinterpret_cast<const bf16x8 *>(b), reinterpret_cast<bf16x8 *>(da), reinterpret_cast<bf16x8 *>(db),
+                       n / 8, bridge);
+    return sq_check_launch("sq_bridge_bwd_bf16");
+}
+extern "C" int sq_dropout_fwd_bf16(const void *x, void *y, uint8_t *mask, int64_t n, float rate, uint32_t seed,
+                                   int mask_given, void *stream) {
+    SQ_REQUIRE(x && y && mask && n > 0 && rate >= 0.f && rate < 1.f, "sq_dropout_fwd_bf16: bad arguments");
+    hipLaunchKernelGGL(dropout_fwd_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), BF(x), BFM(y), mask, n,
+                       rate, seed, mask_given);
+    return sq_check_launch("sq_dropout_fwd_bf16");
+}
+extern "C" int sq_dropout_bwd_bf16(const void *dy, const uint8_t *mask, void *dx, int64_t n, float rate, void *stream) {
+    SQ_REQUIRE(dy && mask && dx && n > 0 && rate >= 0.f && rate < 1.f, "sq_dropout_bwd_bf16: bad arguments");
+    hipLaunchKernelGGL(dropout_bwd_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), BF(dy), mask, BFM(dx), n, rate);
+    return sq_check_launch("sq_dropout_bwd_bf16");
+}
+
+extern "C" int sq_convT2x2s2_nhwc_fwd_bf16(const void *x, const void *w, const float *bias, const void *skip, void *y,
+                                           int N, int H, int W, int Cin, int Cout, int bridge, void *stream) {
+    SQ_REQUIRE(x && w && y, "sq_convT2x2s2_nhwc_fwd_bf16: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cin > 0 && Cout % 16 == 0 && Cout > 0,
+               "sq_convT2x2s2_nhwc_fwd_bf16: Cin=%d (multiple of 32), Cout=%d (multiple of 16)", Cin, Cout);
+    SQ_REQUIRE(bridge >= SQ_BRIDGE_NONE && bridge <= SQ_BRIDGE_SUB, "sq_convT2x2s2_nhwc_fwd_bf16: bad bridge %d", bridge);
+    SQ_REQUIRE(bridge == SQ_BRIDGE_NONE || skip, "sq_convT2x2s2_nhwc_fwd_bf16: bridge needs a skip tensor");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(w); SQ_REQUIRE_ALIGNED(y);
+    const int64_t P = (int64_t)N * H * W;
+    dim3 grid((unsigned)((P + 63) / 64), (unsigned)(4 * Cout / 64));
+    hipLaunchKernelGGL(convT_bf16_kernel, grid, dim3(256), 0, SQ_ST(stream), BF(x), BF(w), bias, BF(skip), BFM(y), P, H, W,
+                       Cin, Cout, bridge);
+    return sq_check_launch("sq_convT2x2s2_nhwc_fwd_bf16");
+}
+
+extern "C" int sq_conv1x1_head_fwd_bf16(const void *x, const float *w, const float *bias, float *logits, uint8_t *mask,
+                                        int64_t npix, int Cin, int Cout, void *stream) {
+    SQ_REQUIRE(x && w && logits && npix > 0 && Cin > 0 && Cin % 8 == 0, "sq_conv1x1_head_fwd_bf16: bad arguments (Cin %% 8)");
+    SQ_REQUIRE_ALIGNED(x);
+    const unsigned nb = (unsigned)((npix + 255) / 256);
+    hipStream_t st = SQ_ST(stream);
+    switch (Cout) {
+    case 1: hipLaunchKernelGGL(head_fwd_bf16_kernel<1>, dim3(nb), dim3(256), 0, st, BF(x), w, bias, logits, mask, npix, Cin); break;
+    case 2: hipLaunchKernelGGL(head_fwd_bf16_kernel<2>, dim3(nb), dim3(256), 0, st, BF(x), w, bias, logits, mask, npix, Cin); break;
+    case 3: hipLaunchKernelGGL(head_fwd_bf16_kernel<3>, dim3(nb), dim3(256), 0, st, BF(x), w, bias, logits, mask, npix, Cin); break;
+    case 4: hipLaunchKernelGGL(head_fwd_bf16_kernel<4>, dim3(nb), dim3(256), 0, st, BF(x), w, bias, logits, mask, npix, Cin); break;
+    default: sq_set_error("sq_conv1x1_head_fwd_bf16: Cout=%d unsupported (1..4)", Cout); return SQ_EINVAL;
+    }
+    return sq_check_launch("sq_conv1x1_head_fwd_bf16");
+}
+
+extern "C" int64_t sq_conv1x1_head_bwd_workspace_bf16(int64_t npix, int Cin, int Cout) {
+    if (npix <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    return (int64_t)head_blocks(npix) * (Cin * Cout + Cout) * 4;
+}
+
+extern "C" int sq_conv1x1_head_bwd_bf16(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db,
+                                        float *workspace, int64_t npix, int Cin, int Cout, void *stream) {
+    SQ_REQUIRE(x && w && dz && dw && workspace && npix > 0, "sq_conv1x1_head_bwd_bf16: null pointer");
+    SQ_REQUIRE((Cin == 16 || Cin == 32) && Cout >= 1 && Cout <= 2, "sq_conv1x1_head_bwd_bf16: Cin=%d (16|32), Cout=%d (1..2)", Cin, Cout);
+    const int nb = head_blocks(npix);
+    hipStream_t st = SQ_ST(stream);
+    if (Cin == 16 && Cout == 1) hipLaunchKernelGGL((head_bwd_bf16_kernel<16, 1>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix);
+    else if (Cin == 16) hipLaunchKernelGGL((head_bwd_bf16_kernel<16, 2>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix);
+    else if (Cout == 1) hipLaunchKernelGGL((head_bwd_bf16_kernel<32, 1>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix);
+    else hipLaunchKernelGGL((head_bwd_bf16_kernel<32, 2>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix);
+    int rc = sq_check_launch("sq_conv1x1_head_bwd_bf16");
+    if (rc) return rc;
+    const int nw = Cin * Cout;
+    hipLaunchKernelGGL(head_finish2_kernel, dim3((nw + Cout + 255) / 256), dim3(256), 0, st, workspace, dw, db, nb, nw, Cout);
+    return sq_check_launch("sq_conv1x1_head_bwd_bf16(finish)");
+}
+
+extern "C" int64_t sq_conv3x3_first_wgrad_workspace_bf16(int N, int H, int Cout) {
+    if (N <= 0 || H <= 0 || Cout <= 0) return -1;
+    const int64_t rows = (int64_t)N * H;
+    const int64_t nblk = rows < 1024 ? rows : 1024;
+    return nblk * 10 * Cout * 4;
+}
+
+extern "C" int sq_conv3x3_first_wgrad_bf16(const float *x, const void *dy, float *dw, float *db, float *workspace, int N,
+                                           int H, int W, int Cout, void *stream) {
+    SQ_REQUIRE(x && dy && dw && workspace && N > 0 && H > 0 && W > 0 && Cout > 0, "sq_conv3x3_first_wgrad_bf16: bad arguments");
+    const int64_t rows = (int64_t)N * H;
+    const int nblk = (int)(rows < 1024 ? rows : 1024);
+    const int rpb = (int)((rows + nblk - 1) / nblk);
+    const int gx = (int)((rows + rpb - 1) / rpb);
+    hipStream_t st = SQ_ST(stream);
+    hipLaunchKernelGGL(wgrad_first_bf16_kernel, dim3(gx, (Cout + 15) / 16), dim3(256), 0, st, x, BF(dy), workspace, N, H, W,
+                       Cout, rpb);
+    int rc = sq_check_launch("sq_conv3x3_first_wgrad_bf16");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_first_finish_kernel, dim3((10 * Cout + 255) / 256), dim3(256), 0, st, workspace, dw, db, gx, Cout);
+    return sq_check_launch("sq_conv3x3_first_wgrad_bf16(finish)");
+}

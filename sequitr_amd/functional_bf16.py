@@ -1,0 +1,165 @@
+"""Differentiable wrappers for the bf16 path (BASELINE configs 3-5): bf16 activations, fp32 master
+weights / biases / gradients-of-weights.  First order only (the U-Net training graph); torch.autograd
+is the tape, every forward and gradient is a HIP kernel of ops_bf16.py."""
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import ops
+from . import ops_bf16 as ob
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, act):
+        K, _, Cin, Cout = w.shape
+        y = ob.conv2d(x, ob.pack_weights(w), bias, K, Cout, act=act)
+        ctx.act, ctx.has_bias = act, bias is not None
+        ctx.save_for_backward(x, w, y if ops.ACT[act] else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        K, _, Cin, Cout = w.shape
+        dpre = ob.act_bwd(dy.contiguous(), y, ctx.act) if y is not None else dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ob.conv2d(dpre, ob.pack_weights(w, transform=True), None, K, Cin)
+        if ctx.needs_input_grad[1] or ctx.has_bias:
+            dw, db = ob.conv2d_wgrad(x, dpre, K, want_bias=ctx.has_bias)
+        return dx, dw, db, None
+
+
+def conv2d(x, w, bias=None, act=None):
+    return _Conv2d.apply(x, w, bias, act)
+
+
+class _ConvFirst(torch.autograd.Function):
+    """first conv of down0: f32 single-channel image -> bf16 activation."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, act):
+        y = ob.conv3x3_first(x, w, bias, act=act)
+        ctx.act = act
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        dpre = ob.act_bwd(dy.contiguous(), y, ctx.act)
+        dw, db = ob.conv3x3_first_wgrad(x, dpre)
+        return None, dw, db, None
+
+
+def conv3x3_first(x, w, bias, act='relu'):
+    return _ConvFirst.apply(x, w, bias, act)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ob.maxpool2x2(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ob.maxpool2x2_bwd(x, dy.contiguous())
+
+
+def maxpool2x2(x):
+    return _MaxPool.apply(x)
+
+
+class _ConvT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return ob.convT2x2s2(x, ob.to_bf16(w), bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        Cout, Cin = w.shape[2], w.shape[3]
+        g = ob.space_to_depth2(dy.contiguous())                              # (N,H,W,4*Cout) bf16
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp = ob.pack_weights(w.reshape(1, 1, 4 * Cout, Cin))              # 1x1 conv 4Cout -> Cin
+            dx = ob.conv2d(g, wp, None, 1, Cin)
+        dwp, dbp = ob.conv2d_wgrad(x, g, 1, want_bias=ctx.has_bias)           # (1,1,Cin,4Cout)
+        dw = dwp.reshape(Cin, 2, 2, Cout).permute(1, 2, 3, 0).contiguous()
+        if ctx.has_bias:
+            db = dbp.reshape(4, Cout).sum(0)
+        return dx, dw, db
+
+
+def convT2x2s2(x, w, bias=None):
+    return _ConvT.apply(x, w, bias)
+
+
+class _Bridge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, kind):
+        ctx.kind = kind
+        ctx.save_for_backward(*((a, b) if kind == 'eltwise_mul' else ()))
+        return ob.bridge(a, b, kind)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors if ctx.kind == 'eltwise_mul' else (None, None)
+        da, db = ob.bridge_bwd(dy.contiguous(), a, b, ctx.kind)
+        return da, db, None
+
+
+def bridge(a, b, kind):
+    return _Bridge.apply(a, b, kind)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rate, seed, mask):
+        y, m = ob.dropout_fwd(x, rate, seed=seed, mask=mask)
+        ctx.rate = rate
+        ctx.save_for_backward(m)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (m,) = ctx.saved_tensors
+        return ob.dropout_bwd(dy.contiguous(), m, ctx.rate), None, None, None
+
+
+def dropout(x, rate, seed=0, mask=None):
+    if rate <= 0.0:
+        return x
+    return _Dropout.apply(x, float(rate), int(seed), mask)
+
+
+class _Head(torch.autograd.Function):
+    """to_image on a bf16 activation: f32 logits out, f32 dlogits in."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        logits, _ = ob.head_fwd(x, w, bias, want_mask=False)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return logits
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        dx, dw, db = ob.head_bwd(x, w, dz.contiguous(), want_dx=ctx.needs_input_grad[0])
+        return dx, dw, (db if ctx.has_bias else None)
+
+
+def conv1x1_head(x, w, bias=None):
+    return _Head.apply(x, w, bias)

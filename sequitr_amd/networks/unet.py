@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from .. import functional as F
+from .. import functional_bf16 as FB
 from .. import ops
 
 DEFAULT_FILTERS = (16, 32, 64, 128, 256)                       # unet.py:40
@@ -445,3 +446,50 @@ class UNet2D(UNet):
         if self._mask is None or self._mask.shape != logits.shape[:-1]:
             self._mask = ops.argmax_u8(logits)
         return self._mask
+
+
+class UNet2DBf16(UNet2D):
+    """The same graph with bf16 activations in HBM (BASELINE configs 3-5: bf16 compute, fp32 master
+    weights and fp32 accumulation).  The image enters as f32 (one channel), every activation between
+    the layers is bfloat16, the logits leave as f32.  Leaf ops: sequitr_amd.functional_bf16 /
+    ops_bf16 (bf16 MFMA convolutions, transposing-LDS-read weight gradients)."""
+
+    def __init__(self, params, mode=PREDICT):
+        UNet2D.__init__(self, dict(params, fuse=False), mode)
+        if self.n_inputs != 1:
+            raise ValueError('the bf16 graph takes a single-channel f32 image (num_inputs == 1)')
+        if any(f % 16 for f in self.filters) or self.bridge_type == 'concat':
+            raise ValueError('the bf16 graph needs filter counts that are multiples of 16 and an eltwise bridge')
+        k = self.bridge_type
+        self.bridge = (lambda x, y, _k=k: FB.bridge(x, y, _k)) if k else (lambda x, y: x)
+        self._default_bridge = self.bridge
+
+    def conv_layer(self, x, filters):
+        w, b = self._kernel((3, 3, x.shape[-1], filters)), self._bias(filters)
+        if x.dtype == torch.float32:
+            return FB.conv3x3_first(x, w, b, act='relu')
+        return FB.conv2d(x, w, b, act='relu')
+
+    def conv_layer_1x1(self, x, filters):
+        w, b = self._kernel((1, 1, x.shape[-1], filters)), self._bias(filters)
+        if self.training:
+            return FB.conv1x1_head(x, w, b)
+        from .. import ops_bf16 as ob
+        logits, self._mask = ob.head_fwd(x, w, b)
+        return logits
+
+    def conv_transpose_layer(self, x, filters):
+        return FB.convT2x2s2(x, self._kernel((2, 2, filters, x.shape[-1])), self._bias(filters))
+
+    def pool_layer(self, x):
+        return FB.maxpool2x2(x)
+
+    def dropout_layer(self, x):
+        if not self.training or self.dropout <= 0.0:
+            return x
+        mask = self.dropout_masks.pop(0) if getattr(self, 'dropout_masks', None) else None
+        self._dropout_calls += 1
+        return FB.dropout(x, self.dropout, seed=self._seed * 1000003 + self._dropout_calls, mask=mask)
+
+    def up_layer(self, x, filters, bridge, name=None):
+        return UNet.up_layer(self, x, filters, bridge, name=name)

@@ -76,3 +76,151 @@ def conv2d_wgrad(x, dy, K, want_bias=True):
     _lib.check(lib.sq_conv2d_nhwc_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout, K,
                                             _stream()), "sq_conv2d_nhwc_wgrad_bf16")
     return dw, db
+
+
+def to_bf16(x):
+    _chk(x, "x", dtype=torch.float32)
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_cast_f32_to_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "sq_cast_f32_to_bf16")
+    return y
+
+
+def to_f32(x):
+    _chk(x, "x")
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_cast_bf16_to_f32(_ptr(x), _ptr(y), x.numel(), _stream()), "sq_cast_bf16_to_f32")
+    return y
+
+
+def maxpool2x2(x):
+    _chk(x, "x", ndim=4)
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=BF16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_maxpool2x2_fwd_bf16(_ptr(x), _ptr(y), N, H, W, C, _stream()), "sq_maxpool2x2_fwd_bf16")
+    return y
+
+
+def maxpool2x2_bwd(x, dy):
+    _chk(x, "x", ndim=4), _chk(dy, "dy", ndim=4)
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.sq_maxpool2x2_bwd_bf16(_ptr(x), _ptr(dy), _ptr(dx), N, H, W, C, _stream()), "sq_maxpool2x2_bwd_bf16")
+    return dx
+
+
+def act_bwd(dy, y, act):
+    _chk(dy, "dy"), _chk(y, "y")
+    if ACT[act] == 0:
+        return dy
+    dx = torch.empty_like(dy)
+    lib = _lib.load()
+    _lib.check(lib.sq_act_bwd_bf16(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), ACT[act], _stream()), "sq_act_bwd_bf16")
+    return dx
+
+
+def bridge(a, b, kind):
+    _chk(a, "a"), _chk(b, "b")
+    y = torch.empty_like(a)
+    lib = _lib.load()
+    _lib.check(lib.sq_bridge_fwd_bf16(_ptr(a), _ptr(b), _ptr(y), a.numel(), BRIDGE[kind], _stream()), "sq_bridge_fwd_bf16")
+    return y
+
+
+def bridge_bwd(dy, a, b, kind):
+    _chk(dy, "dy")
+    da, db = torch.empty_like(dy), torch.empty_like(dy)
+    lib = _lib.load()
+    _lib.check(lib.sq_bridge_bwd_bf16(_ptr(dy), _ptr(a), _ptr(b), _ptr(da), _ptr(db), dy.numel(), BRIDGE[kind], _stream()),
+               "sq_bridge_bwd_bf16")
+    return da, db
+
+
+def dropout_fwd(x, rate, seed=0, mask=None):
+    _chk(x, "x")
+    y = torch.empty_like(x)
+    given = mask is not None
+    if not given:
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_dropout_fwd_bf16(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(rate), int(seed) & 0xFFFFFFFF,
+                                      1 if given else 0, _stream()), "sq_dropout_fwd_bf16")
+    return y, mask
+
+
+def dropout_bwd(dy, mask, rate):
+    _chk(dy, "dy")
+    dx = torch.empty_like(dy)
+    lib = _lib.load()
+    _lib.check(lib.sq_dropout_bwd_bf16(_ptr(dy), _ptr(mask), _ptr(dx), dy.numel(), float(rate), _stream()), "sq_dropout_bwd_bf16")
+    return dx
+
+
+def convT2x2s2(x, w_bf16, bias, skip=None, bridge_kind=None):
+    """x (N,H,W,Cin) bf16, w_bf16 = bf16 copy of the (2,2,Cout,Cin) kernel, bias f32."""
+    _chk(x, "x", ndim=4), _chk(w_bf16, "w", ndim=4)
+    N, H, W, Cin = x.shape
+    Cout = w_bf16.shape[2]
+    b = BRIDGE[bridge_kind]
+    if b:
+        _chk(skip, "skip", ndim=4)
+    y = torch.empty((N, 2 * H, 2 * W, Cout), dtype=BF16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_convT2x2s2_nhwc_fwd_bf16(_ptr(x), _ptr(w_bf16), _ptr(bias), _ptr(skip) if b else None, _ptr(y),
+                                              N, H, W, Cin, Cout, b, _stream()), "sq_convT2x2s2_nhwc_fwd_bf16")
+    return y
+
+
+def space_to_depth2(dy):
+    """(N,2H,2W,C) bf16 -> (N,H,W,4C): a pure permutation, run by the f32 kernel on bf16 pairs."""
+    _chk(dy, "dy", ndim=4)
+    N, H2, W2, C = dy.shape
+    g = torch.empty((N, H2 // 2, W2 // 2, 4 * C), dtype=BF16, device=dy.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_space_to_depth2_f32(_ptr(dy), _ptr(g), N, H2 // 2, W2 // 2, C // 2, _stream()), "sq_space_to_depth2_f32")
+    return g
+
+
+def head_fwd(x, w, bias, want_mask=True):
+    """bf16 (N,H,W,Cin) -> f32 logits (N,H,W,Cout), uint8 mask."""
+    _chk(x, "x", ndim=4), _chk(w, "w", dtype=torch.float32, ndim=4)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    logits = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device)
+    mask = torch.empty((N, H, W), dtype=torch.uint8, device=x.device) if want_mask else None
+    lib = _lib.load()
+    _lib.check(lib.sq_conv1x1_head_fwd_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(logits), _ptr(mask), N * H * W, Cin, Cout,
+                                           _stream()), "sq_conv1x1_head_fwd_bf16")
+    return logits, mask
+
+
+def head_bwd(x, w, dz, want_dx=True):
+    _chk(x, "x", ndim=4), _chk(dz, "dz", dtype=torch.float32)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    npix = N * H * W
+    lib = _lib.load()
+    ws = _workspace(lib.sq_conv1x1_head_bwd_workspace_bf16(npix, Cin, Cout), x.device)
+    dx = torch.empty_like(x) if want_dx else None
+    dw = torch.empty((1, 1, Cin, Cout), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.sq_conv1x1_head_bwd_bf16(_ptr(x), _ptr(w), _ptr(dz), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), npix, Cin,
+                                           Cout, _stream()), "sq_conv1x1_head_bwd_bf16")
+    return dx, dw, db
+
+
+def conv3x3_first_wgrad(x, dy):
+    """x f32 (N,H,W,1), dy bf16 (N,H,W,Cout) -> (dW (3,3,1,Cout) f32, db f32)."""
+    _chk(x, "x", dtype=torch.float32, ndim=4), _chk(dy, "dy", ndim=4)
+    N, H, W, _ = x.shape
+    Cout = dy.shape[3]
+    lib = _lib.load()
+    ws = _workspace(lib.sq_conv3x3_first_wgrad_workspace_bf16(N, H, Cout), x.device)
+    dw = torch.empty((3, 3, 1, Cout), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.sq_conv3x3_first_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cout, _stream()),
+               "sq_conv3x3_first_wgrad_bf16")
+    return dw, db

@@ -10,13 +10,16 @@ import torch
 
 from . import functional as F
 from . import ops
-from .networks.unet import UNet2D, unet_variable_shapes, TRAIN
+from .networks.unet import UNet2D, UNet2DBf16, unet_variable_shapes, TRAIN
 from .parallel import FlatBucket, allreduce_sum_
 
 
 class UNetTrainer(object):
     def __init__(self, params, learning_rate=0.01, beta1=0.9, beta2=0.999, epsilon=1e-8, group=None,
-                 net_cls=UNet2D):
+                 net_cls=None):
+        # params['dtype'] == 'bf16': bf16 activations + bf16 MFMA, fp32 master weights / Adam (configs 3-4)
+        if net_cls is None:
+            net_cls = UNet2DBf16 if str(params.get('dtype', 'f32')).lower() in ('bf16', 'bfloat16') else UNet2D
         self.net = net_cls(params, TRAIN)
         self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
         self.group = group

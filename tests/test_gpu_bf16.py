@@ -87,3 +87,141 @@ def test_wgrad_bf16(N, H, W, Cin, Cout, K):
     assert np.abs(db.cpu().numpy() - bt.grad.numpy()).max() <= 2e-6 * np.abs(bt.grad.numpy()).max()
     dw2, _ = ob.conv2d_wgrad(dev(x, torch.bfloat16), dev(dy, torch.bfloat16), K)
     assert torch.equal(dw, dw2)
+
+
+def test_streaming_ops_bf16():
+    x = tiles(11, 2, 8, 12, 16)
+    xb = bf16_round(x)
+    got = ob.maxpool2x2(dev(x, torch.bfloat16)).float().cpu().double()
+    assert torch.equal(got, TF.max_pool2d(xb.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1))
+    dy = tiles(12, 2, 4, 6, 16)
+    xt = xb.clone().permute(0, 3, 1, 2).requires_grad_(True)
+    TF.max_pool2d(xt, 2, 2).backward(bf16_round(dy).permute(0, 3, 1, 2))
+    got = ob.maxpool2x2_bwd(dev(x, torch.bfloat16), dev(dy, torch.bfloat16)).float().cpu().double()
+    assert torch.equal(got, xt.grad.permute(0, 2, 3, 1))
+    a, b, g = tiles(13, 1, 4, 4, 16), tiles(14, 1, 4, 4, 16), tiles(15, 1, 4, 4, 16)
+    ab, bb, gb = bf16_round(a), bf16_round(b), bf16_round(g)
+    for kind, f in (("eltwise_add", lambda p, q: p + q), ("eltwise_mul", lambda p, q: p * q), ("eltwise_sub", lambda p, q: p - q)):
+        check_bf16(ob.bridge(dev(a, torch.bfloat16), dev(b, torch.bfloat16), kind), f(ab, bb), kind)
+    da, db = ob.bridge_bwd(dev(g, torch.bfloat16), dev(a, torch.bfloat16), dev(b, torch.bfloat16), "eltwise_mul")
+    check_bf16(da, gb * bb, "bridge bwd da")
+    check_bf16(db, gb * ab, "bridge bwd db")
+    y = tiles(16, 1, 4, 4, 16)
+    got = ob.act_bwd(dev(g, torch.bfloat16), dev(y, torch.bfloat16), "relu").float().cpu().double()
+    assert torch.equal(got, torch.where(bf16_round(y) > 0, gb, torch.zeros_like(gb)))
+    xd = dev(np.ones((1, 32, 32, 16), np.float32), torch.bfloat16)
+    y1, m1 = ob.dropout_fwd(xd, 0.4, seed=3)
+    assert abs(m1.float().mean().item() - 0.6) < 0.02
+    assert torch.equal(y1.float(), (m1.float() / 0.6).to(torch.bfloat16).float())
+    assert torch.equal(ob.dropout_bwd(xd, m1, 0.4).float(), y1.float())
+    f = dev(tiles(17, 1, 4, 4, 8))
+    assert torch.equal(ob.to_f32(ob.to_bf16(f)), f.to(torch.bfloat16).float())
+    s2d = ob.space_to_depth2(dev(tiles(18, 1, 4, 6, 8), torch.bfloat16)).float().cpu().numpy()
+    ref = bf16_round(tiles(18, 1, 4, 6, 8)).numpy().reshape(1, 2, 2, 3, 2, 8).transpose(0, 1, 3, 2, 4, 5).reshape(1, 2, 3, 32)
+    assert np.array_equal(s2d, ref)
+
+
+@pytest.mark.parametrize("Cin,Cout", [(32, 16), (64, 32), (256, 128)])
+@pytest.mark.parametrize("bridge", [None, "eltwise_mul", "eltwise_add"])
+def test_convT_bf16(Cin, Cout, bridge):
+    x, w, b = tiles(19, 2, 9, 13, Cin), rand_weights(20, (2, 2, Cout, Cin), 0.2), rand_weights(21, (Cout,), 0.1)
+    skip = tiles(22, 2, 18, 26, Cout)
+    up = TF.conv_transpose2d(bf16_round(x).permute(0, 3, 1, 2), bf16_round(w).permute(3, 2, 0, 1),
+                             torch.as_tensor(b, dtype=torch.float64), stride=2).permute(0, 2, 3, 1)
+    if bridge:
+        u = up.to(torch.bfloat16).double()                         # the up-scaled value is stored as bf16 first
+        s = bf16_round(skip)
+        ref = u * s if bridge == "eltwise_mul" else u + s
+    else:
+        ref = up
+    got = ob.convT2x2s2(dev(x, torch.bfloat16), ob.to_bf16(dev(w)), dev(b), skip=dev(skip, torch.bfloat16), bridge_kind=bridge)
+    g = got.float().cpu().double()
+    r = ref.to(torch.bfloat16).double()
+    # a 1-ulp difference in the rounded up-scaled value can move the product by 1 ulp as well
+    assert ((g - ref).abs() <= 2 * torch.clamp(ref.abs(), min=1e-30) * 2.0 ** -7 + 1e-6).all()
+    assert (g == r).double().mean().item() > 0.97
+
+
+def test_head_and_first_wgrad_bf16():
+    x, w, b = tiles(23, 2, 24, 24, 16), rand_weights(24, (1, 1, 16, 2)), rand_weights(25, (2,), 0.1)
+    xb = bf16_round(x)
+    ref = (xb.reshape(-1, 16) @ torch.as_tensor(w, dtype=torch.float64).reshape(16, 2) + torch.as_tensor(b, dtype=torch.float64)).reshape(2, 24, 24, 2)
+    logits, mask = ob.head_fwd(dev(x, torch.bfloat16), dev(w), dev(b))
+    assert (logits.cpu().double() - ref).abs().max() < 1e-5
+    assert torch.equal(mask.cpu(), ref.argmax(-1).to(torch.uint8)) or ((logits[..., 0] - logits[..., 1]).abs().cpu()[mask.cpu() != ref.argmax(-1).to(torch.uint8)] < 1e-5).all()
+    dz = tiles(26, 2, 24, 24, 2)
+    dx, dw, db = ob.head_bwd(dev(x, torch.bfloat16), dev(w), dev(dz))
+    dzt = torch.as_tensor(dz, dtype=torch.float64).reshape(-1, 2)
+    check_bf16(dx, (dzt @ torch.as_tensor(w, dtype=torch.float64).reshape(16, 2).T).reshape(2, 24, 24, 16), "head dx")
+    assert np.allclose(dw.cpu().numpy().reshape(16, 2), (xb.reshape(-1, 16).T @ dzt).numpy(), rtol=1e-5, atol=1e-4)
+    assert np.allclose(db.cpu().numpy(), dzt.sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    # first-layer weight gradient: f32 image, bf16 dY
+    xi, dy = tiles(27, 2, 20, 28, 1), tiles(28, 2, 20, 28, 16)
+    wt = torch.zeros((16, 1, 3, 3), dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(16, dtype=torch.float64, requires_grad=True)
+    TF.conv2d(torch.as_tensor(xi, dtype=torch.float64).permute(0, 3, 1, 2), wt, bt, padding=1).backward(bf16_round(dy).permute(0, 3, 1, 2))
+    dw, db = ob.conv3x3_first_wgrad(dev(xi), dev(dy, torch.bfloat16))
+    assert np.allclose(dw.cpu().numpy(), wt.grad.permute(2, 3, 1, 0).numpy(), rtol=1e-5, atol=1e-4)
+    assert np.allclose(db.cpu().numpy(), bt.grad.numpy(), rtol=1e-5, atol=1e-4)
+
+
+def _batch(seed, n, size):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, size, size, 1)).astype(np.float32)
+    lab = (rng.random((n, size, size)) < 0.3)
+    return x, np.stack([~lab, lab], -1).astype(np.uint8), (1 + 9 * rng.random((n, size, size, 1))).astype(np.float32)
+
+
+def test_unet_bf16_training_step_vs_cpu_emulation_and_f32():
+    """The bf16 step against (a) oracle/bf16_ref.py, an fp64 emulation that rounds to bf16 at the same
+    points (activations, filter copies, activation gradients), and (b) the fp64 graph without rounding.
+
+    Forward: logits within 2 bf16 ulps of the emulation, loss within 1e-3 of it and 2 % of full precision.
+    Backward: at random initialisation this 23-layer graph with multiplicative bridges is ill-conditioned
+    for 8-bit mantissas -- activation gradients shrink by 1e4 and the emulation itself is 12-20 % away from
+    the fp64 gradients, chaotically (two faithful bf16 evaluations differ by ~10 %).  The parity
+    criterion is therefore: every weight gradient of the HIP path is as close to the fp64 truth as the
+    reference emulation is (<= 1.25x its error + 0.5 %), with cosine > 0.98.  Each kernel alone is pinned
+    to 1 ulp / 2e-6 by the tests above."""
+    from oracle import bf16_ref
+    from oracle import torch_ref as tr
+    from sequitr_amd.train import UNetTrainer
+    x, onehot, wmap = _batch(0, 2, 64)
+    base = {"shape": (64, 64), "dropout": 0.0, "device": "cuda:0", "seed": 4}
+    tb16 = UNetTrainer(dict(base, dtype="bf16"))
+    assert type(tb16.net).__name__ == "UNet2DBf16"
+    w0 = tb16.state_dict()
+    l16 = tb16.forward_backward(dev(x), dev(onehot), dev(wmap)).item()
+    rl, rg, rlogits = bf16_ref.unet_loss_and_grads_bf16(x, onehot, wmap, w0, base)
+    l64, g64, _ = tr.unet_loss_and_grads(x, onehot, wmap, w0, base)
+    logits = tb16.net.logits().detach().cpu().numpy()
+    assert np.abs(logits - rlogits).max() <= 2 * 2.0 ** -7 * np.abs(rlogits).max()
+    assert abs(l16 - rl) <= 1e-3 * abs(rl)
+    assert abs(l16 - l64) <= 0.02 * abs(l64)
+    g16 = tb16.grads()
+    for k in g64:
+        t, b, r = g64[k].ravel(), g16[k].ravel().astype(np.float64), rg[k].ravel()
+        nt = max(np.linalg.norm(t), 1e-30)
+        e_hip, e_emul = np.linalg.norm(b - t) / nt, np.linalg.norm(r - t) / nt
+        cos = float(t @ b / max(nt * np.linalg.norm(b), 1e-30))
+        assert e_hip <= 1.25 * e_emul + 0.005 and cos > 0.98, (k, e_hip, e_emul, cos)
+
+
+def test_unet_bf16_trains_and_predicts():
+    from sequitr_amd.train import UNetTrainer
+    params = {"shape": (64, 64), "dropout": 0.2, "device": "cuda:0", "seed": 0, "filters": (16, 32, 64), "dtype": "bf16"}
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:64, 0:64]
+    lab = ((yy - 32) ** 2 + (xx - 30) ** 2 < 200)
+    x = (lab[None, ..., None] * 2.0 + rng.standard_normal((4, 64, 64, 1)) * 0.5).astype(np.float32)
+    onehot = np.broadcast_to(np.stack([~lab, lab], -1)[None], (4, 64, 64, 2)).astype(np.uint8).copy()
+    wmap = np.ones((4, 64, 64, 1), np.float32)
+    t = UNetTrainer(params, learning_rate=0.003)
+    losses = [t.step(dev(x), dev(onehot), dev(wmap)).item() for _ in range(30)]
+    assert losses[-1] < 0.5 * losses[0], losses
+    from sequitr_amd.networks.unet import UNet2DBf16
+    net = UNet2DBf16(dict(params), "infer")
+    net.load_state_dict(t.state_dict())
+    mask = net.predict(x).cpu().numpy()
+    iou = np.logical_and(mask == 1, lab[None]).sum() / np.logical_or(mask == 1, lab[None]).sum()
+    assert iou > 0.8
