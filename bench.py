@@ -127,7 +127,7 @@ def main_train(args):
     from sequitr_amd.train import UNetTrainer
     nb = 16
     params = {"shape": (TILE, TILE), "num_inputs": 1, "num_outputs": 2, "filters": FILTERS,
-              "bridge": "eltwise_mul", "dropout": 0.4, "device": str(dev), "seed": 0}
+              "bridge": "eltwise_mul", "dropout": 0.4, "device": str(dev), "seed": 0, "dtype": args.dtype}
     tr = UNetTrainer(params, learning_rate=0.01)
     rng = np.random.default_rng(2 + rank)
     x = torch.from_numpy(rng.standard_normal((nb, TILE, TILE, 1)).astype(np.float32)).to(dev)
@@ -140,6 +140,8 @@ def main_train(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.graph:                     # hipGraph replay; step() still copies the batch into the static buffers
+        tr.capture(x, onehot, wmap, warmup=2)
     for _ in range(args.warmup):
         tr.step(x, onehot, wmap)
     barrier()
@@ -157,10 +159,11 @@ def main_train(args):
         print(json.dumps({"metric": "trained Mpixels/sec on 512x512 tiles (fwd+loss+bwd+allreduce+Adam)",
                           "value": round(pix / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                           "data": "synthetic",
                           "config": {"workload": "U-Net training, weighted softmax-CE, batch=16 512x512x1 tiles per "
-                                                 "GPU, dropout 0.4, Adam; fp32 (bf16 variant not built yet)",
+                                                 "GPU, dropout 0.4, Adam (fp32 master weights); activations " + args.dtype
+                                                 + ("; hipGraph replay" if args.graph else "; eager launches"),
                                      "loss": float(tr.last_loss.item())}}))
     if dist is not None:
         dist.destroy_process_group()
@@ -233,6 +236,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="training dtype (--mode train)")
+    ap.add_argument("--graph", type=int, default=1, help="--mode train: replay the step as hipGraphs (1) or eager (0)")
     ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
     ap.add_argument("--mode", choices=["infer", "train", "gan"], default="infer",
                     help="infer = the headline metric (BASELINE configs[1]); train = configs[2]/[3] "

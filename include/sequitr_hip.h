@@ -164,15 +164,21 @@ int sq_conv1x1_small_bwd_f32(const float *x, const float *w, const float *dz, fl
                              float *workspace, int64_t npix, int Cin, int Cout, void *stream);
 
 /* tf.layers.dropout (sequitr/networks/unet.py:274-276): y = x * keep / (1 - rate).  mask (u8, n) is
- * written from a counter-based hash of (seed, index), or read when mask_given != 0. */
+ * written from a counter-based hash of (seed, index), or read when mask_given != 0.  step_dev (may be
+ * NULL): device int32 whose value is folded into the seed, so a captured hipGraph draws a new mask on
+ * every replay. */
 int sq_dropout_fwd_f32(const float *x, float *y, uint8_t *mask, int64_t n, float rate, uint32_t seed,
-                       int mask_given, void *stream);
+                       int mask_given, const int32_t *step_dev, void *stream);
 int sq_dropout_bwd_f32(const float *dy, const uint8_t *mask, float *dx, int64_t n, float rate, void *stream);
 
 /* tf.train.AdamOptimizer update over a flat parameter buffer (sequitr/networks/gan.py:736-751):
  * g is first multiplied by grad_scale (1/world for data-parallel averaging); step counts from 1. */
 int sq_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
                      float beta2, float eps, int step, float grad_scale, void *stream);
+/* hipGraph-safe form: state = 2 x int32 in device memory {step counter, lr_t bits}; the call increments
+ * the counter on the device, so a captured step replays with the right bias correction. */
+int sq_adam_step_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
+                         float beta2, float eps, int32_t *state, float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * GAN side (sequitr/networks/gan.py).  weighted_conv2d / to_image / from_image are
@@ -276,7 +282,7 @@ int sq_bridge_fwd_bf16(const void *a, const void *b, void *y, int64_t n, int bri
 int sq_bridge_bwd_bf16(const void *dy, const void *a, const void *b, void *da, void *db, int64_t n, int bridge,
                        void *stream);
 int sq_dropout_fwd_bf16(const void *x, void *y, uint8_t *mask, int64_t n, float rate, uint32_t seed,
-                        int mask_given, void *stream);
+                        int mask_given, const int32_t *step_dev, void *stream);
 int sq_dropout_bwd_bf16(const void *dy, const uint8_t *mask, void *dx, int64_t n, float rate, void *stream);
 
 /* conv_transpose_layer + bridge on bf16 tensors; w = bf16 copy of the (2,2,Cout,Cin) kernel, bias f32.
@@ -293,7 +299,7 @@ int sq_conv1x1_head_bwd_bf16(const void *x, const float *w, const float *dz, voi
                              float *workspace, int64_t npix, int Cin, int Cout, void *stream);
 
 /* weight gradient of the first (1 -> Cout) 3x3 convolution from the f32 image and a bf16 dY */
-int64_t sq_conv3x3_first_wgrad_workspace_bf16(int N, int H, int Cout);
+int64_t sq_conv3x3_first_wgrad_workspace_bf16(int N, int H, int W, int Cout);
 int sq_conv3x3_first_wgrad_bf16(const float *x, const void *dy, float *dw, float *db, float *workspace, int N,
                                 int H, int W, int Cout, void *stream);
 

@@ -38,9 +38,10 @@ SIGNATURES = {
     "sq_space_to_depth2_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "sq_conv1x1_small_bwd_workspace_f32": (c_int64, [c_int64, c_int, c_int]),
     "sq_conv1x1_small_bwd_f32": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]),
-    "sq_dropout_fwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_float, ctypes.c_uint32, c_int, c_void_p]),
+    "sq_dropout_fwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_float, ctypes.c_uint32, c_int, c_void_p, c_void_p]),
     "sq_dropout_bwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_float, c_void_p]),
     "sq_adam_step_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 4 + [c_int, c_float, c_void_p]),
+    "sq_adam_step_dev_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 4 + [c_void_p, c_float, c_void_p]),
     "sq_pixelnorm_bwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_float, c_void_p]),
     "sq_pixelnorm_bwd2_f32": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_float, c_void_p]),
     "sq_resize_nearest_f32": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
@@ -68,13 +69,13 @@ SIGNATURES = {
     "sq_act_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
     "sq_bridge_fwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
     "sq_bridge_bwd_bf16": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_void_p]),
-    "sq_dropout_fwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_float, ctypes.c_uint32, c_int, c_void_p]),
+    "sq_dropout_fwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_float, ctypes.c_uint32, c_int, c_void_p, c_void_p]),
     "sq_dropout_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_float, c_void_p]),
     "sq_convT2x2s2_nhwc_fwd_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "sq_conv1x1_head_fwd_bf16": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
     "sq_conv1x1_head_bwd_workspace_bf16": (c_int64, [c_int64, c_int, c_int]),
     "sq_conv1x1_head_bwd_bf16": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]),
-    "sq_conv3x3_first_wgrad_workspace_bf16": (c_int64, [c_int] * 3),
+    "sq_conv3x3_first_wgrad_workspace_bf16": (c_int64, [c_int] * 4),
     "sq_conv3x3_first_wgrad_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
 }
 

@@ -211,11 +211,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
 }
 
 __global__ __launch_bounds__(256) void head_finish_kernel(const float *__restrict__ partials, float *__restrict__ dw,
-                                                           float *__restrict__ db, int nblk, int nw, int nb) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                           float *__restrict__ db, int nblk, int nw, int nb, int G) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t / G, g = t % G;
     if (i >= nw + nb) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * (nw + nb) + i];
+    const float s = sq_group_reduce(partials + i, (size_t)(nw + nb), nblk, g, G);
+    if (g != 0) return;
     if (i < nw) dw[i] = s;
     else if (db) db[i - nw] = s;
 }
@@ -228,29 +229,54 @@ __device__ __forceinline__ unsigned hash32(unsigned a, unsigned b) {
     return h;
 }
 
-__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                           uint8_t *__restrict__ mask, int64_t n, float rate,
-                                                           unsigned seed, int mask_given) {
+// 4 elements per thread (16 B of data, 4 B of mask); n % 4 == 0 is required by the entry points
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y,
+                                                           uchar4 *__restrict__ mask, int64_t n4, float rate,
+                                                           unsigned seed, int mask_given, const int *__restrict__ step) {
+    if (step) seed += (unsigned)step[0] * 0x9E3779B9u;          // a fresh mask on every replayed step
     const unsigned thr = (unsigned)(rate * 4294967296.0);
     const float inv = 1.0f / (1.0f - rate);
-    SQ_GRID_STRIDE(i, n) {
-        uint8_t keep;
-        if (mask_given) keep = mask[i];
-        else { keep = hash32(seed, (unsigned)i) >= thr ? 1 : 0; mask[i] = keep; }
-        y[i] = keep ? x[i] * inv : 0.f;
+    SQ_GRID_STRIDE(i, n4) {
+        uchar4 k;
+        if (mask_given) k = mask[i];
+        else {
+            const unsigned e = (unsigned)(i * 4);
+            k = make_uchar4(hash32(seed, e) >= thr, hash32(seed, e + 1) >= thr, hash32(seed, e + 2) >= thr,
+                            hash32(seed, e + 3) >= thr);
+            mask[i] = k;
+        }
+        const float4 v = x[i];
+        y[i] = make_float4(k.x ? v.x * inv : 0.f, k.y ? v.y * inv : 0.f, k.z ? v.z * inv : 0.f, k.w ? v.w * inv : 0.f);
     }
 }
 
-__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ mask,
-                                                           float *__restrict__ dx, int64_t n, float rate) {
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float4 *__restrict__ dy, const uchar4 *__restrict__ mask,
+                                                           float4 *__restrict__ dx, int64_t n4, float rate) {
     const float inv = 1.0f / (1.0f - rate);
-    SQ_GRID_STRIDE(i, n) dx[i] = mask[i] ? dy[i] * inv : 0.f;
+    SQ_GRID_STRIDE(i, n4) {
+        const uchar4 k = mask[i];
+        const float4 v = dy[i];
+        dx[i] = make_float4(k.x ? v.x * inv : 0.f, k.y ? v.y * inv : 0.f, k.z ? v.z * inv : 0.f, k.w ? v.w * inv : 0.f);
+    }
 }
 
 // Adam (tf.train.AdamOptimizer form): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps)
+// graph-safe step bookkeeping: the step counter lives in device memory, so a captured hipGraph
+// replays with the right bias correction.  state[0] = step (int32), state[1] = lr_t (float bits).
+__global__ void adam_prepare_kernel(int *__restrict__ state, float lr, float b1, float b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int t = state[0] + 1;
+        state[0] = t;
+        const double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
+        reinterpret_cast<float *>(state)[1] = (float)lr_t;
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                     float *__restrict__ m, float *__restrict__ v, int64_t n,
-                                                    float lr_t, float b1, float b2, float eps, float gscale) {
+                                                    float lr_t_host, const int *__restrict__ state, float b1, float b2,
+                                                    float eps, float gscale) {
+    const float lr_t = state ? reinterpret_cast<const float *>(state)[1] : lr_t_host;
     SQ_GRID_STRIDE(i, n) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -382,23 +408,28 @@ extern "C" int sq_conv1x1_small_bwd_f32(const float *x, const float *w, const fl
     int rc = sq_check_launch("sq_conv1x1_small_bwd_f32");
     if (rc) return rc;
     const int nw = Cin * Cout;
-    hipLaunchKernelGGL(head_finish_kernel, dim3((nw + Cout + 255) / 256), dim3(256), 0, st, workspace, dw, db, nb, nw, Cout);
+    { const int G = sq_group_size(nb); hipLaunchKernelGGL(head_finish_kernel, dim3(((nw + Cout) * G + 255) / 256), dim3(256), 0, st, workspace, dw, db, nb, nw, Cout, G); }
     return sq_check_launch("sq_conv1x1_small_bwd_f32(finish)");
 }
 
 extern "C" int sq_dropout_fwd_f32(const float *x, float *y, uint8_t *mask, int64_t n, float rate, uint32_t seed,
-                                  int mask_given, void *stream) {
-    SQ_REQUIRE(x && y && mask && n > 0, "sq_dropout_fwd_f32: bad arguments");
+                                  int mask_given, const int32_t *step_dev, void *stream) {
+    SQ_REQUIRE(x && y && mask && n > 0 && n % 4 == 0, "sq_dropout_fwd_f32: bad arguments (n %% 4 == 0)");
     SQ_REQUIRE(rate >= 0.f && rate < 1.f, "sq_dropout_fwd_f32: rate must be in [0,1)");
-    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), x, y, mask, n, rate, seed,
-                       mask_given);
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(y);
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y),
+                       reinterpret_cast<uchar4 *>(mask), n / 4, rate, seed, mask_given, step_dev);
     return sq_check_launch("sq_dropout_fwd_f32");
 }
 
 extern "C" int sq_dropout_bwd_f32(const float *dy, const uint8_t *mask, float *dx, int64_t n, float rate, void *stream) {
-    SQ_REQUIRE(dy && mask && dx && n > 0, "sq_dropout_bwd_f32: bad arguments");
+    SQ_REQUIRE(dy && mask && dx && n > 0 && n % 4 == 0, "sq_dropout_bwd_f32: bad arguments (n %% 4 == 0)");
     SQ_REQUIRE(rate >= 0.f && rate < 1.f, "sq_dropout_bwd_f32: rate must be in [0,1)");
-    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), dy, mask, dx, n, rate);
+    SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(dx);
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(dy), reinterpret_cast<const uchar4 *>(mask),
+                       reinterpret_cast<float4 *>(dx), n / 4, rate);
     return sq_check_launch("sq_dropout_bwd_f32");
 }
 
@@ -406,7 +437,18 @@ extern "C" int sq_adam_step_f32(float *p, const float *g, float *m, float *v, in
                                 float beta2, float eps, int step, float grad_scale, void *stream) {
     SQ_REQUIRE(p && g && m && v && n > 0 && step >= 1, "sq_adam_step_f32: bad arguments");
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), p, g, m, v, n, (float)lr_t, beta1,
-                       beta2, eps, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), p, g, m, v, n, (float)lr_t,
+                       (const int *)nullptr, beta1, beta2, eps, grad_scale);
     return sq_check_launch("sq_adam_step_f32");
+}
+
+extern "C" int sq_adam_step_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
+                                    float beta2, float eps, int32_t *state, float grad_scale, void *stream) {
+    SQ_REQUIRE(p && g && m && v && state && n > 0, "sq_adam_step_dev_f32: bad arguments");
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, SQ_ST(stream), state, lr, beta1, beta2);
+    int rc = sq_check_launch("sq_adam_step_dev_f32(prepare)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), p, g, m, v, n, 0.f, state, beta1,
+                       beta2, eps, grad_scale);
+    return sq_check_launch("sq_adam_step_dev_f32");
 }

@@ -50,3 +50,18 @@ __device__ __forceinline__ unsigned sq_xcd_remap(unsigned bid, unsigned nblk) {
     const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + k;
 }
+
+// Fixed-order reduction of `nblk` block partials per output by a group of G lanes (G a power of two
+// <= 64, the same for a given problem size, so results are run-to-run reproducible): lane g sums
+// partials g, g+G, ... in order, then an xor butterfly folds the group.
+__device__ __forceinline__ float sq_group_reduce(const float *__restrict__ p, size_t stride, int nblk, int g, int G) {
+    float s = 0.f;
+    for (int b = g; b < nblk; b += G) s += p[(size_t)b * stride];
+    for (int m = G >> 1; m > 0; m >>= 1) s += __shfl_xor(s, m);
+    return s;
+}
+static inline int sq_group_size(int nblk) {
+    int G = 1;
+    while (G < 64 && G * 2 <= nblk) G *= 2;
+    return G;
+}

@@ -176,23 +176,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(
 template <int KS>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float *__restrict__ partials,
                                                                       float *__restrict__ dw, float *__restrict__ db,
-                                                                      int nblk, int Cin, int Cout) {
+                                                                      int nblk, int Cin, int Cout, int G) {
     using C = WB<KS>;
     const int nco = Cout / 16, npairs = (Cin / 16) * nco;
     const int total = C::NTAP * Cin * Cout;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t / G, g = t % G;
+    const size_t stride = (size_t)npairs * C::RED_FLOATS;
     if (i < total) {
         const int co = i % Cout, ci = (i / Cout) % Cin, tap = i / (Cout * Cin);
         const size_t off = (size_t)((ci / 16) * nco + co / 16) * C::RED_FLOATS + (tap * 16 + ci % 16) * 16 + co % 16;
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * npairs * C::RED_FLOATS + off];
-        dw[i] = s;
-    } else if (db && i < total + Cout) {
+        const float s = sq_group_reduce(partials + off, stride, nblk, g, G);
+        if (g == 0) dw[i] = s;
+    } else if (i < total + Cout) {
         const int co = i - total;
         const size_t off = (size_t)(co / 16) * C::RED_FLOATS + (C::NTAP * 16) * 16 + co % 16;
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * npairs * C::RED_FLOATS + off];
-        db[co] = s;
+        const float s = sq_group_reduce(partials + off, stride, nblk, g, G);
+        if (g == 0 && db) db[co] = s;
     }
 }
 
@@ -222,9 +222,10 @@ int launch(const __bf16 *x, const __bf16 *dy, float *dw, float *db, float *ws, i
                        Cin, Cout, tiles_x, tiles_y, tiles_x * tiles_y * N, tpb);
     int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_bf16");
     if (rc) return rc;
-    const int total = KS * KS * Cin * Cout + (db ? Cout : 0);
-    hipLaunchKernelGGL(conv_wgrad_bf16_finish_kernel<KS>, dim3((total + 255) / 256), dim3(256), 0, st, ws, dw, db, gx,
-                       Cin, Cout);
+    const int G = sq_group_size(gx);
+    const int64_t total = ((int64_t)KS * KS * Cin * Cout + Cout) * G;
+    hipLaunchKernelGGL(conv_wgrad_bf16_finish_kernel<KS>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, dw,
+                       db, gx, Cin, Cout, G);
     return sq_check_launch("sq_conv2d_nhwc_wgrad_bf16(finish)");
 }
 

@@ -219,25 +219,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
 template <int BN, int KS, int KC>
 __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const float *__restrict__ partials,
                                                                  float *__restrict__ dw, float *__restrict__ db,
-                                                                 int nblk, int Cin, int Cout) {
+                                                                 int nblk, int Cin, int Cout, int G) {
     using C = WCfg<BN, KS, KC>;
     const int nco = (Cout + BN - 1) / BN, npairs = (Cin / KC) * nco;
     const int total = C::NTAP * Cin * Cout;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t / G, g = t % G;
+    const size_t stride = (size_t)npairs * C::RED_FLOATS;
     if (i < total) {
         const int co = i % Cout, ci = (i / Cout) % Cin, tap = i / (Cout * Cin);
         const int pair = (ci / KC) * nco + co / BN;
         const size_t off = (size_t)pair * C::RED_FLOATS + (tap * 16 + ci % KC) * BN + co % BN;
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * npairs * C::RED_FLOATS + off];
-        dw[i] = s;
-    } else if (db && i < total + Cout) {
+        const float s = sq_group_reduce(partials + off, stride, nblk, g, G);
+        if (g == 0) dw[i] = s;
+    } else if (i < total + Cout) {
         const int co = i - total;
-        const int pair = co / BN;                              // ci chunk 0
-        const size_t off = (size_t)pair * C::RED_FLOATS + (C::NTAP * 16) * BN + co % BN;
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * npairs * C::RED_FLOATS + off];
-        db[co] = s;
+        const size_t off = (size_t)(co / BN) * C::RED_FLOATS + (C::NTAP * 16) * BN + co % BN;
+        const float s = sq_group_reduce(partials + off, stride, nblk, g, G);
+        if (g == 0 && db) db[co] = s;
     }
 }
 
@@ -279,9 +278,10 @@ int launch(const float *x, const float *dy, float *dw, float *db, float *ws, int
                        tiles_x, tiles_y, tiles_x * tiles_y * N, tpb);
     int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_f32");
     if (rc) return rc;
-    const int total = KS * KS * Cin * Cout + (db ? Cout : 0);
-    hipLaunchKernelGGL((conv_wgrad_finish_kernel<BN, KS, KC>), dim3((total + 255) / 256), dim3(256), 0, st, ws, dw,
-                       db, gx, Cin, Cout);
+    const int G = sq_group_size(gx);
+    const int64_t total = ((int64_t)KS * KS * Cin * Cout + Cout) * G;
+    hipLaunchKernelGGL((conv_wgrad_finish_kernel<BN, KS, KC>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws,
+                       dw, db, gx, Cin, Cout, G);
     return sq_check_launch("sq_conv2d_nhwc_wgrad_f32(finish)");
 }
 
@@ -308,8 +308,9 @@ int launch_dispatch(const float *x, const float *dy, float *dw, float *db, float
 // ---- first layer (Cin == 1, 3x3): the 9 taps ride the 16 MFMA rows ---------------------------------
 //   A[i = tap][k = pixel] = X[pixel + tap] (rows 9..15 zero), B[k][j = co] = dY[pixel][co]
 // partials: [gridDim.x][10][Cout]  (9 taps + the bias row); blockIdx.y = 16-channel co group.
+template <typename TY>
 __global__ __launch_bounds__(256) void conv_wgrad_cin1_f32_kernel(
-    const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ partials, int N, int H, int W,
+    const float *__restrict__ x, const TY *__restrict__ dy, float *__restrict__ partials, int N, int H, int W,
     int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block) {
     constexpr int HW = TW + 2;
     __shared__ float xs[HW * HW + 8];
@@ -334,8 +335,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_cin1_f32_kernel(
             const int pix = idx >> 2, q = idx & 3;
             const int gy = y0 + pix / TW, gx = x0 + pix % TW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < H && gx < W && co0 + q * 4 < Cout)
-                v = *reinterpret_cast<const float4 *>(dy + (((size_t)n * H + gy) * W + gx) * Cout + co0 + q * 4);
+            if (gy < H && gx < W && co0 + q * 4 < Cout) {
+                const TY *src = dy + (((size_t)n * H + gy) * W + gx) * Cout + co0 + q * 4;
+                if constexpr (sizeof(TY) == 4) {
+                    v = *reinterpret_cast<const float4 *>(src);
+                } else {                                          // bf16 dY: 4 values = 8 bytes
+                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                    const bf16x4_t h = *reinterpret_cast<const bf16x4_t *>(src);
+                    v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                }
+            }
             *reinterpret_cast<float4 *>(ys + pix * 16 + q * 4) = v;
         }
         __syncthreads();
@@ -367,11 +376,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_cin1_f32_kernel(
 
 __global__ __launch_bounds__(256) void conv_wgrad_cin1_finish_kernel(const float *__restrict__ partials,
                                                                       float *__restrict__ dw, float *__restrict__ db,
-                                                                      int nblk, int Cout) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                                      int nblk, int Cout, int G) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t / G, g = t % G;
     if (i >= 10 * Cout) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * 10 * Cout + i];
+    const float s = sq_group_reduce(partials + i, (size_t)10 * Cout, nblk, g, G);
+    if (g != 0) return;
     if (i < 9 * Cout) dw[i] = s;
     else if (db) db[i - 9 * Cout] = s;
 }
@@ -411,13 +421,39 @@ extern "C" int sq_conv2d_nhwc_wgrad_f32(const float *x, const float *dy, float *
         int tpb;
         const int gx = cin1_grid(N, H, W, &tpb);
         const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-        hipLaunchKernelGGL(conv_wgrad_cin1_f32_kernel, dim3(gx, (Cout + 15) / 16), dim3(256), 0, st, x, dy, workspace,
+        hipLaunchKernelGGL(conv_wgrad_cin1_f32_kernel<float>, dim3(gx, (Cout + 15) / 16), dim3(256), 0, st, x, dy, workspace,
                            N, H, W, Cout, tiles_x, tiles_y, tiles_x * tiles_y * N, tpb);
         int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_f32(cin1)");
         if (rc) return rc;
-        hipLaunchKernelGGL(conv_wgrad_cin1_finish_kernel, dim3((10 * Cout + 255) / 256), dim3(256), 0, st, workspace,
-                           dw, db, gx, Cout);
+        const int G = sq_group_size(gx);
+        hipLaunchKernelGGL(conv_wgrad_cin1_finish_kernel, dim3((10 * Cout * G + 255) / 256), dim3(256), 0, st, workspace,
+                           dw, db, gx, Cout, G);
         return sq_check_launch("sq_conv2d_nhwc_wgrad_f32(cin1 finish)");
     }
     return launch_dispatch(x, dy, dw, db, workspace, N, H, W, Cin, Cout, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+// first-layer weight gradient with a bf16 dY (the bf16 training graph): same MFMA-over-taps kernel
+extern "C" int64_t sq_conv3x3_first_wgrad_workspace_bf16(int N, int H, int W, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4) return -1;
+    return (int64_t)cin1_grid(N, H, W, nullptr) * 10 * Cout * 4;
+}
+
+extern "C" int sq_conv3x3_first_wgrad_bf16(const float *x, const void *dy, float *dw, float *db, float *workspace,
+                                           int N, int H, int W, int Cout, void *stream) {
+    SQ_REQUIRE(x && dy && dw && workspace && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 4 == 0,
+               "sq_conv3x3_first_wgrad_bf16: bad arguments (Cout %% 4 == 0)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int tpb;
+    const int gx = cin1_grid(N, H, W, &tpb);
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    hipLaunchKernelGGL(conv_wgrad_cin1_f32_kernel<__bf16>, dim3(gx, (Cout + 15) / 16), dim3(256), 0, st, x,
+                       reinterpret_cast<const __bf16 *>(dy), workspace, N, H, W, Cout, tiles_x, tiles_y,
+                       tiles_x * tiles_y * N, tpb);
+    int rc = sq_check_launch("sq_conv3x3_first_wgrad_bf16");
+    if (rc) return rc;
+    const int G = sq_group_size(gx);
+    hipLaunchKernelGGL(conv_wgrad_cin1_finish_kernel, dim3((10 * Cout * G + 255) / 256), dim3(256), 0, st, workspace, dw, db,
+                       gx, Cout, G);
+    return sq_check_launch("sq_conv3x3_first_wgrad_bf16(finish)");
 }

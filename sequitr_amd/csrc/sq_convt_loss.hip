@@ -131,13 +131,18 @@ __global__ __launch_bounds__(256) void wsoftmax_ce_f32_kernel(
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
 }
 
-__global__ void ce_finish_kernel(const double *__restrict__ partials, int n, double inv_npix,
-                                 double *__restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += partials[i];
-        *loss = s * inv_npix;
+__global__ __launch_bounds__(256) void ce_finish_kernel(const double *__restrict__ partials, int n, double inv_npix,
+                                                        double *__restrict__ loss) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];      // fixed assignment, fixed tree
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) *loss = red[0] * inv_npix;
 }
 
 inline int64_t ce_blocks(int64_t npix) {
@@ -179,6 +184,6 @@ extern "C" int sq_wsoftmax_ce_fwd_bwd_f32(const float *logits, const uint8_t *on
                        grad_scale / (float)npix, partials, dlogits);
     int rc = sq_check_launch("sq_wsoftmax_ce_fwd_bwd_f32");
     if (rc) return rc;
-    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, partials, nb, 1.0 / (double)npix, loss);
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, 1.0 / (double)npix, loss);
     return sq_check_launch("sq_wsoftmax_ce_fwd_bwd_f32(finish)");
 }

@@ -240,12 +240,12 @@ __global__ __launch_bounds__(256) void wgrad1x1_small_kernel(const float *__rest
     }
 }
 __global__ __launch_bounds__(256) void wgrad1x1_small_finish_kernel(const float *__restrict__ partials,
-                                                                     float *__restrict__ m, int nblk, int total) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                                     float *__restrict__ m, int nblk, int total, int G) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t / G, g = t % G;
     if (i >= total) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * total + i];
-    m[i] = s;
+    const float s = sq_group_reduce(partials + i, (size_t)total, nblk, g, G);
+    if (g == 0) m[i] = s;
 }
 
 inline int small_blocks(int64_t npix) {
@@ -367,6 +367,7 @@ extern "C" int sq_wgrad1x1_small_f32(const float *a, const float *b, float *m, f
     int rc = sq_check_launch("sq_wgrad1x1_small_f32");
     if (rc) return rc;
     const int total = Ca * Cb;
-    hipLaunchKernelGGL(wgrad1x1_small_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, m, nb, total);
+    const int G = sq_group_size(nb);
+    hipLaunchKernelGGL(wgrad1x1_small_finish_kernel, dim3((total * G + 255) / 256), dim3(256), 0, st, workspace, m, nb, total, G);
     return sq_check_launch("sq_wgrad1x1_small_f32(finish)");
 }

@@ -143,22 +143,48 @@ __device__ __forceinline__ unsigned hash32(unsigned a, unsigned b) {          //
     return h;
 }
 
-__global__ __launch_bounds__(256) void dropout_fwd_bf16_kernel(const __bf16 *__restrict__ x, __bf16 *__restrict__ y,
-                                                                uint8_t *__restrict__ mask, int64_t n, float rate,
-                                                                unsigned seed, int mask_given) {
+// 8 elements per thread (16 B of data, 8 B of mask); element e uses hash(seed, e) as the f32 kernel does
+__global__ __launch_bounds__(256) void dropout_fwd_bf16_kernel(const bf16x8 *__restrict__ x, bf16x8 *__restrict__ y,
+                                                                uint2 *__restrict__ mask, int64_t n8, float rate,
+                                                                unsigned seed, int mask_given, const int *__restrict__ step) {
+    if (step) seed += (unsigned)step[0] * 0x9E3779B9u;
     const unsigned thr = (unsigned)(rate * 4294967296.0);
     const float inv = 1.0f / (1.0f - rate);
-    SQ_GRID_STRIDE(i, n) {
-        uint8_t keep;
-        if (mask_given) keep = mask[i];
-        else { keep = hash32(seed, (unsigned)i) >= thr ? 1 : 0; mask[i] = keep; }
-        y[i] = keep ? (__bf16)((float)x[i] * inv) : (__bf16)0.f;
+    SQ_GRID_STRIDE(i, n8) {
+        uint2 m;
+        if (mask_given) m = mask[i];
+        else {
+            const unsigned e = (unsigned)(i * 8);
+            m.x = (hash32(seed, e) >= thr) | ((hash32(seed, e + 1) >= thr) << 8) | ((hash32(seed, e + 2) >= thr) << 16) |
+                  ((hash32(seed, e + 3) >= thr) << 24);
+            m.y = (hash32(seed, e + 4) >= thr) | ((hash32(seed, e + 5) >= thr) << 8) | ((hash32(seed, e + 6) >= thr) << 16) |
+                  ((hash32(seed, e + 7) >= thr) << 24);
+            mask[i] = m;
+        }
+        const bf16x8 v = x[i];
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned keep = ((j < 4 ? m.x : m.y) >> (8 * (j & 3))) & 0xFFu;
+            r[j] = keep ? (__bf16)((float)v[j] * inv) : (__bf16)0.f;
+        }
+        y[i] = r;
     }
 }
-__global__ __launch_bounds__(256) void dropout_bwd_bf16_kernel(const __bf16 *__restrict__ dy, const uint8_t *__restrict__ mask,
-                                                                __bf16 *__restrict__ dx, int64_t n, float rate) {
+__global__ __launch_bounds__(256) void dropout_bwd_bf16_kernel(const bf16x8 *__restrict__ dy, const uint2 *__restrict__ mask,
+                                                                bf16x8 *__restrict__ dx, int64_t n8, float rate) {
     const float inv = 1.0f / (1.0f - rate);
-    SQ_GRID_STRIDE(i, n) dx[i] = mask[i] ? (__bf16)((float)dy[i] * inv) : (__bf16)0.f;
+    SQ_GRID_STRIDE(i, n8) {
+        const uint2 m = mask[i];
+        const bf16x8 v = dy[i];
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned keep = ((j < 4 ? m.x : m.y) >> (8 * (j & 3))) & 0xFFu;
+            r[j] = keep ? (__bf16)((float)v[j] * inv) : (__bf16)0.f;
+        }
+        dx[i] = r;
+    }
 }
 
 // ---- 2x2/s2 transpose conv + bias + bridge on v_mfma_f32_16x16x32_bf16 ------------------------------------
@@ -314,54 +340,14 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const __bf16 *__rest
             ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 __global__ __launch_bounds__(256) void head_finish2_kernel(const float *__restrict__ partials, float *__restrict__ dw,
-                                                            float *__restrict__ db, int nblk, int nw, int nb) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                           float *__restrict__ db, int nblk, int nw, int nb, int G) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t / G, g = t % G;
     if (i >= nw + nb) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * (nw + nb) + i];
+    const float s = sq_group_reduce(partials + i, (size_t)(nw + nb), nblk, g, G);
+    if (g != 0) return;
     if (i < nw) dw[i] = s;
     else if (db) db[i - nw] = s;
-}
-
-// first-layer weight gradient with a bf16 dY: dW[tap][0][co] = sum_p x[p+tap] dY[p][co] (x f32, 1 channel).
-// One thread per (tap, co) pair and pixel slice; block partials [grid][10][Cout]; fixed-order finish.
-__global__ __launch_bounds__(256) void wgrad_first_bf16_kernel(const float *__restrict__ x, const __bf16 *__restrict__ dy,
-                                                                float *__restrict__ partials, int N, int H, int W, int Cout,
-                                                                int rows_per_block) {
-    // thread = (co, tap-or-bias) : 16 co x 10 -> 160 active threads; loops over the block's image rows
-    const int co = threadIdx.x & 15, t = threadIdx.x >> 4;              // t in 0..15, 0..8 taps, 9 bias
-    const int co0 = blockIdx.y * 16;
-    const int64_t row0 = (int64_t)blockIdx.x * rows_per_block, row1 = min(row0 + rows_per_block, (int64_t)N * H);
-    float s = 0.f;
-    if (t < 10 && co0 + co < Cout) {
-        const int ky = t / 3 - 1, kx = t % 3 - 1;
-        for (int64_t r = row0; r < row1; ++r) {
-            const int n = (int)(r / H), yy = (int)(r % H);
-            const int sy = yy + ky;
-            const bool rowok = t == 9 || (sy >= 0 && sy < H);
-            if (!rowok) continue;
-            const __bf16 *dyr = dy + (r * W) * Cout + co0 + co;
-            const float *xr = x + ((int64_t)n * H + (t == 9 ? yy : sy)) * W;
-            for (int xx = 0; xx < W; ++xx) {
-                const float g = (float)dyr[(int64_t)xx * Cout];
-                if (t == 9) s += g;
-                else {
-                    const int sx = xx + kx;
-                    if (sx >= 0 && sx < W) s = __builtin_fmaf(xr[sx], g, s);
-                }
-            }
-        }
-    }
-    if (t < 10 && co0 + co < Cout) partials[((size_t)blockIdx.x * 10 + t) * Cout + co0 + co] = s;
-}
-__global__ __launch_bounds__(256) void wgrad_first_finish_kernel(const float *__restrict__ partials, float *__restrict__ dw,
-                                                                  float *__restrict__ db, int nblk, int Cout) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 10 * Cout) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * 10 * Cout + i];
-    if (i < 9 * Cout) dw[i] = s;
-    else if (db) db[i - 9 * Cout] = s;
 }
 
 inline int head_blocks(int64_t npix) {
@@ -435,15 +421,20 @@ extern "C" int sq_bridge_bwd_bf16(const void *dy, const void *a, const void *b, 
     return sq_check_launch("sq_bridge_bwd_bf16");
 }
 extern "C" int sq_dropout_fwd_bf16(const void *x, void *y, uint8_t *mask, int64_t n, float rate, uint32_t seed,
-                                   int mask_given, void *stream) {
-    SQ_REQUIRE(x && y && mask && n > 0 && rate >= 0.f && rate < 1.f, "sq_dropout_fwd_bf16: bad arguments");
-    hipLaunchKernelGGL(dropout_fwd_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), BF(x), BFM(y), mask, n,
-                       rate, seed, mask_given);
+                                   int mask_given, const int32_t *step_dev, void *stream) {
+    SQ_REQUIRE(x && y && mask && n > 0 && n % 8 == 0 && rate >= 0.f && rate < 1.f, "sq_dropout_fwd_bf16: bad arguments (n %% 8 == 0)");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(y);
+    hipLaunchKernelGGL(dropout_fwd_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const bf16x8 *>(x), reinterpret_cast<bf16x8 *>(y), reinterpret_cast<uint2 *>(mask),
+                       n / 8, rate, seed, mask_given, step_dev);
     return sq_check_launch("sq_dropout_fwd_bf16");
 }
 extern "C" int sq_dropout_bwd_bf16(const void *dy, const uint8_t *mask, void *dx, int64_t n, float rate, void *stream) {
-    SQ_REQUIRE(dy && mask && dx && n > 0 && rate >= 0.f && rate < 1.f, "sq_dropout_bwd_bf16: bad arguments");
-    hipLaunchKernelGGL(dropout_bwd_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), BF(dy), mask, BFM(dx), n, rate);
+    SQ_REQUIRE(dy && mask && dx && n > 0 && n % 8 == 0 && rate >= 0.f && rate < 1.f, "sq_dropout_bwd_bf16: bad arguments (n %% 8 == 0)");
+    SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(dx);
+    hipLaunchKernelGGL(dropout_bwd_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const bf16x8 *>(dy), reinterpret_cast<const uint2 *>(mask),
+                       reinterpret_cast<bf16x8 *>(dx), n / 8, rate);
     return sq_check_launch("sq_dropout_bwd_bf16");
 }
 
@@ -496,29 +487,6 @@ extern "C" int sq_conv1x1_head_bwd_bf16(const void *x, const float *w, const flo
     int rc = sq_check_launch("sq_conv1x1_head_bwd_bf16");
     if (rc) return rc;
     const int nw = Cin * Cout;
-    hipLaunchKernelGGL(head_finish2_kernel, dim3((nw + Cout + 255) / 256), dim3(256), 0, st, workspace, dw, db, nb, nw, Cout);
+    { const int G = sq_group_size(nb); hipLaunchKernelGGL(head_finish2_kernel, dim3(((nw + Cout) * G + 255) / 256), dim3(256), 0, st, workspace, dw, db, nb, nw, Cout, G); }
     return sq_check_launch("sq_conv1x1_head_bwd_bf16(finish)");
-}
-
-extern "C" int64_t sq_conv3x3_first_wgrad_workspace_bf16(int N, int H, int Cout) {
-    if (N <= 0 || H <= 0 || Cout <= 0) return -1;
-    const int64_t rows = (int64_t)N * H;
-    const int64_t nblk = rows < 1024 ? rows : 1024;
-    return nblk * 10 * Cout * 4;
-}
-
-extern "C" int sq_conv3x3_first_wgrad_bf16(const float *x, const void *dy, float *dw, float *db, float *workspace, int N,
-                                           int H, int W, int Cout, void *stream) {
-    SQ_REQUIRE(x && dy && dw && workspace && N > 0 && H > 0 && W > 0 && Cout > 0, "sq_conv3x3_first_wgrad_bf16: bad arguments");
-    const int64_t rows = (int64_t)N * H;
-    const int nblk = (int)(rows < 1024 ? rows : 1024);
-    const int rpb = (int)((rows + nblk - 1) / nblk);
-    const int gx = (int)((rows + rpb - 1) / rpb);
-    hipStream_t st = SQ_ST(stream);
-    hipLaunchKernelGGL(wgrad_first_bf16_kernel, dim3(gx, (Cout + 15) / 16), dim3(256), 0, st, x, BF(dy), workspace, N, H, W,
-                       Cout, rpb);
-    int rc = sq_check_launch("sq_conv3x3_first_wgrad_bf16");
-    if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_first_finish_kernel, dim3((10 * Cout + 255) / 256), dim3(256), 0, st, workspace, dw, db, gx, Cout);
-    return sq_check_launch("sq_conv3x3_first_wgrad_bf16(finish)");
 }

@@ -124,8 +124,8 @@ def bridge(a, b, kind):
 
 class _Dropout(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, rate, seed, mask):
-        y, m = ob.dropout_fwd(x, rate, seed=seed, mask=mask)
+    def forward(ctx, x, rate, seed, mask, step_dev):
+        y, m = ob.dropout_fwd(x, rate, seed=seed, mask=mask, step_dev=step_dev)
         ctx.rate = rate
         ctx.save_for_backward(m)
         return y
@@ -134,13 +134,13 @@ class _Dropout(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, dy):
         (m,) = ctx.saved_tensors
-        return ob.dropout_bwd(dy.contiguous(), m, ctx.rate), None, None, None
+        return ob.dropout_bwd(dy.contiguous(), m, ctx.rate), None, None, None, None
 
 
-def dropout(x, rate, seed=0, mask=None):
+def dropout(x, rate, seed=0, mask=None, step_dev=None):
     if rate <= 0.0:
         return x
-    return _Dropout.apply(x, float(rate), int(seed), mask)
+    return _Dropout.apply(x, float(rate), int(seed), mask, step_dev)
 
 
 class _Head(torch.autograd.Function):

@@ -257,7 +257,8 @@ class UNet2D(UNet):
         self._seed = params.get('seed', 0)
         self._rng = np.random.default_rng(self._seed)
         self._vars = {}                                        # scope/name -> device tensor
-        self._dropout_calls = 0
+        self._dropout_calls = 0                               # dropout layer index within one build()
+        self._builds = 0                                      # host-side step salt when no device counter is set
         self.dropout_masks = None
         self.fuse = bool(params.get('fuse', True))          # fused inference kernels (same bits)
         self._mask = None
@@ -338,8 +339,8 @@ class UNet2D(UNet):
         if not self.training or self.dropout <= 0.0:
             return x
         mask = self.dropout_masks.pop(0) if getattr(self, 'dropout_masks', None) else None
-        self._dropout_calls += 1
-        return F.dropout(x, self.dropout, seed=self._seed * 1000003 + self._dropout_calls, mask=mask)
+        step_dev = None if mask is not None else getattr(self, '_step_dev', None)
+        return F.dropout(x, self.dropout, seed=self._dropout_seed(step_dev), mask=mask, step_dev=step_dev)
 
     def up_layer(self, x, filters, bridge, name=None):
         """Same wiring as the base class, but when neither conv_transpose_layer nor the
@@ -358,8 +359,19 @@ class UNet2D(UNet):
             out = self.conv_block(merged, filters)
         return out
 
+    def _dropout_seed(self, step_dev):
+        """Seed of this dropout layer: (net seed, layer index) - and, when no device step counter salts
+        it inside the kernel, the host build count folded in the same way (seed + step * 0x9E3779B9)."""
+        self._dropout_calls += 1
+        s = self._seed * 1000003 + self._dropout_calls
+        if step_dev is None:
+            s += (self._builds - 1) * 0x9E3779B9
+        return s & 0xFFFFFFFF
+
     def build(self, features):
         self._mask = None
+        self._dropout_calls = 0
+        self._builds += 1
         if self.fuse and self._fusable():
             return self._build_fused(features)
         return UNet.build(self, features)
@@ -488,8 +500,8 @@ class UNet2DBf16(UNet2D):
         if not self.training or self.dropout <= 0.0:
             return x
         mask = self.dropout_masks.pop(0) if getattr(self, 'dropout_masks', None) else None
-        self._dropout_calls += 1
-        return FB.dropout(x, self.dropout, seed=self._seed * 1000003 + self._dropout_calls, mask=mask)
+        step_dev = None if mask is not None else getattr(self, '_step_dev', None)
+        return FB.dropout(x, self.dropout, seed=self._dropout_seed(step_dev), mask=mask, step_dev=step_dev)
 
     def up_layer(self, x, filters, bridge, name=None):
         return UNet.up_layer(self, x, filters, bridge, name=name)

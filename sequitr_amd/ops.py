@@ -304,7 +304,7 @@ def conv1x1_small_bwd(x, w, dz, want_dx=True):
     return dx, dw, db
 
 
-def dropout_fwd(x, rate, seed=0, mask=None):
+def dropout_fwd(x, rate, seed=0, mask=None, step_dev=None):
     """returns (y, mask u8).  A supplied mask is used as-is (parity tests)."""
     _chk(x, "x")
     y = torch.empty_like(x)
@@ -315,7 +315,7 @@ def dropout_fwd(x, rate, seed=0, mask=None):
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     lib = _lib.load()
     _lib.check(lib.sq_dropout_fwd_f32(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(rate), int(seed) & 0xFFFFFFFF,
-                                     1 if given else 0, _stream()), "sq_dropout_fwd_f32")
+                                     1 if given else 0, _ptr(step_dev), _stream()), "sq_dropout_fwd_f32")
     return y, mask
 
 
@@ -543,3 +543,14 @@ def conv3x3_first_block(x, w1, b1, w2, b2, want_pool=True):
     _lib.check(lib.sq_conv3x3_first_block_fwd_f32(_ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(y), _ptr(p),
                                                  N, H, W, _stream()), "sq_conv3x3_first_block_fwd_f32")
     return y, p
+
+
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, state, grad_scale=1.0):
+    """hipGraph-safe Adam: `state` = int32[2] device tensor {step, lr_t bits}; incremented on the device."""
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, n)
+    _chk(state, "state", dtype=torch.int32)
+    lib = _lib.load()
+    _lib.check(lib.sq_adam_step_dev_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
+                                       float(beta2), float(eps), _ptr(state), float(grad_scale), _stream()),
+               "sq_adam_step_dev_f32")

@@ -139,7 +139,7 @@ def bridge_bwd(dy, a, b, kind):
     return da, db
 
 
-def dropout_fwd(x, rate, seed=0, mask=None):
+def dropout_fwd(x, rate, seed=0, mask=None, step_dev=None):
     _chk(x, "x")
     y = torch.empty_like(x)
     given = mask is not None
@@ -147,7 +147,7 @@ def dropout_fwd(x, rate, seed=0, mask=None):
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     lib = _lib.load()
     _lib.check(lib.sq_dropout_fwd_bf16(_ptr(x), _ptr(y), _ptr(mask), x.numel(), float(rate), int(seed) & 0xFFFFFFFF,
-                                      1 if given else 0, _stream()), "sq_dropout_fwd_bf16")
+                                      1 if given else 0, _ptr(step_dev), _stream()), "sq_dropout_fwd_bf16")
     return y, mask
 
 
@@ -218,7 +218,7 @@ def conv3x3_first_wgrad(x, dy):
     N, H, W, _ = x.shape
     Cout = dy.shape[3]
     lib = _lib.load()
-    ws = _workspace(lib.sq_conv3x3_first_wgrad_workspace_bf16(N, H, Cout), x.device)
+    ws = _workspace(lib.sq_conv3x3_first_wgrad_workspace_bf16(N, H, W, Cout), x.device)
     dw = torch.empty((3, 3, 1, Cout), dtype=torch.float32, device=x.device)
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
     _lib.check(lib.sq_conv3x3_first_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cout, _stream()),

@@ -38,6 +38,11 @@ class UNetTrainer(object):
             leaf.grad = self.gbucket.view(name)                 # autograd accumulates in place
             self.net._vars[name] = leaf
         self.last_loss = None
+        # Adam's step counter lives on the device ({step, lr_t bits}) so a captured step replays correctly;
+        # the same counter salts the dropout seeds.
+        self.step_state = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.net._step_dev = self.step_state
+        self._graphs = None
 
     def load_state_dict(self, weights):
         with torch.no_grad():
@@ -59,11 +64,64 @@ class UNetTrainer(object):
         self.last_loss = loss.detach()
         return self.last_loss
 
+    def _world(self):
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _adam(self, world):
+        ops.adam_step_dev(self.pbucket.flat, self.gbucket.flat, self.m, self.v, self.lr, self.b1, self.b2, self.eps,
+                          self.step_state, grad_scale=1.0 / world)
+
     def step(self, x, onehot, weights):
         """One optimiser step on this rank's shard of the global batch."""
+        if self._graphs is not None:
+            return self._step_graphed(x, onehot, weights)
         loss = self.forward_backward(x, onehot, weights)
         world = allreduce_sum_(self.gbucket.flat, self.group)   # ONE collective per step
         self.step_count += 1
-        ops.adam_step(self.pbucket.flat, self.gbucket.flat, self.m, self.v, self.lr, self.b1, self.b2, self.eps,
-                      self.step_count, grad_scale=1.0 / world)
+        self._adam(world)
         return loss
+
+    # ---- hipGraph replay: the step is ~200 short launches, host-bound when issued from Python ----------
+    def capture(self, x, onehot, weights, warmup=2):
+        """Capture the step for inputs of this shape as two hipGraphs: (zero grads, forward, loss,
+        backward) and (Adam).  The gradient all-reduce stays between them, outside any graph, so the
+        RCCL call is an ordinary stream operation.  `warmup` eager steps run first on the capture
+        stream (they ARE optimiser steps).  Later step() calls copy their inputs into the static
+        buffers and replay."""
+        if self._graphs is not None:
+            raise RuntimeError("UNetTrainer.capture: already captured")
+        sx, so, sw = x.clone(), onehot.clone(), weights.clone()
+        side = torch.cuda.Stream(device=sx.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, int(warmup))):
+                self.step(sx, so, sw)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        world = self._world()
+        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_fb):
+            sloss = self.forward_backward(sx, so, sw)
+        with torch.cuda.graph(g_opt, pool=g_fb.pool()):
+            self._adam(world)
+        self._graphs = (g_fb, g_opt, sx, so, sw, sloss)
+        return self
+
+    def _step_graphed(self, x, onehot, weights):
+        g_fb, g_opt, sx, so, sw, sloss = self._graphs
+        if x.shape != sx.shape:
+            raise ValueError("UNetTrainer: captured for batch shape %s, got %s" % (tuple(sx.shape), tuple(x.shape)))
+        if x is not sx:
+            sx.copy_(x), so.copy_(onehot), sw.copy_(weights)
+        g_fb.replay()
+        allreduce_sum_(self.gbucket.flat, self.group)
+        self.step_count += 1
+        g_opt.replay()
+        self.last_loss = sloss
+        return sloss
+
+    @property
+    def static_inputs(self):
+        """(x, onehot, weights) buffers a loader may fill in place to skip the copy in step()."""
+        return None if self._graphs is None else self._graphs[2:5]

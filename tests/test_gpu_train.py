@@ -194,3 +194,55 @@ def test_training_reduces_loss():
     t = UNetTrainer(params, learning_rate=0.003)
     losses = [t.step(dev(x), dev(onehot), dev(wmap)).item() for _ in range(25)]
     assert losses[-1] < 0.5 * losses[0], losses
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_captured_step_replays_bit_exact_with_eager(dtype):
+    """UNetTrainer.capture(): hipGraph replay of (zero, fwd, loss, bwd) + (Adam) must give the same
+    weights, bit for bit, as the eager step - including the device-side step counter that drives Adam's
+    bias correction and salts the dropout seeds."""
+    params = {"shape": (64, 64), "dropout": 0.4, "device": "cuda:0", "seed": 3, "filters": (16, 32, 64),
+              "dtype": dtype}
+    x, onehot, wmap = _batch(7, 4, 64)
+    x2, onehot2, wmap2 = _batch(8, 4, 64)
+    eager, graphed = UNetTrainer(params, learning_rate=0.003), UNetTrainer(params, learning_rate=0.003)
+    graphed.capture(dev(x), dev(onehot), dev(wmap), warmup=2)
+    assert graphed.step_count == 2
+    for _ in range(2):
+        eager.step(dev(x), dev(onehot), dev(wmap))
+    for xs in ((x, onehot, wmap), (x2, onehot2, wmap2), (x, onehot, wmap)):
+        le = eager.step(*[dev(a) for a in xs])
+        lg = graphed.step(*[dev(a) for a in xs])
+        assert le.item() == lg.item()
+    assert int(graphed.step_state[0].item()) == 5 == graphed.step_count
+    we, wg = eager.state_dict(), graphed.state_dict()
+    for k in we:
+        assert np.array_equal(we[k], wg[k]), k
+    with pytest.raises(ValueError):
+        graphed.step(dev(x[:2]), dev(onehot[:2]), dev(wmap[:2]))
+
+
+def test_dropout_step_counter_changes_mask():
+    from sequitr_amd import ops
+    x = torch.ones(4096, dtype=torch.float32, device="cuda:0")
+    st = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+    _, m0 = ops.dropout_fwd(x, 0.4, seed=11, step_dev=st)
+    _, m0b = ops.dropout_fwd(x, 0.4, seed=11, step_dev=st)
+    st[0] = 1
+    _, m1 = ops.dropout_fwd(x, 0.4, seed=11, step_dev=st)
+    _, mn = ops.dropout_fwd(x, 0.4, seed=11)
+    assert torch.equal(m0, m0b) and torch.equal(m0, mn) and not torch.equal(m0, m1)
+    assert abs(m1.float().mean().item() - 0.6) < 0.05
+
+
+def test_adam_dev_matches_host_step():
+    from sequitr_amd import ops
+    rng = np.random.default_rng(0)
+    p0, g = rng.standard_normal(5000).astype(np.float32), rng.standard_normal(5000).astype(np.float32)
+    pa, pb = dev(p0), dev(p0)
+    ma, va, mb, vb = [torch.zeros(5000, device="cuda:0") for _ in range(4)]
+    st = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+    for t in range(1, 6):
+        ops.adam_step(pa, dev(g), ma, va, 0.01, 0.9, 0.999, 1e-8, t, grad_scale=0.5)
+        ops.adam_step_dev(pb, dev(g), mb, vb, 0.01, 0.9, 0.999, 1e-8, st, grad_scale=0.5)
+    assert int(st[0].item()) == 5 and torch.equal(pa, pb)
