@@ -37,32 +37,55 @@ def mfma_conv_flops(n, h, w, cin, cout, k):
 
 
 class ConvTimer(object):
-    """Wraps ops.conv2d so every MFMA-path convolution launch is bracketed by HIP events on
-    the stream it is launched on (torch's current stream IS the launch stream)."""
+    """Wraps the ops entry points that launch the MFMA implicit-GEMM convolution kernel
+    (conv2d and its fused-epilogue forms conv3x3_pool / conv3x3_head / conv3x3_first_block) so every
+    such launch is bracketed by HIP events on the stream it is launched on (torch's current stream
+    IS the launch stream).  FLOPs are the algorithmic ones of the convolutions the launch computes."""
+
+    NAMES = ("conv2d", "conv3x3_pool", "conv3x3_head", "conv3x3_first_block")
 
     def __init__(self, ops_mod):
         self.ops = ops_mod
-        self.orig = ops_mod.conv2d
+        self.orig = {n: getattr(ops_mod, n) for n in self.NAMES}
         self.records = []        # (start_event, end_event, flops)
 
+    @staticmethod
+    def _flops(name, a):
+        x = a[0]
+        n, h, w = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+        if name == "conv3x3_first_block":                     # conv1 (1->16) + conv2 (16->16), one launch
+            return mfma_conv_flops(n, h, w, 1, 16, 3) + mfma_conv_flops(n, h, w, 16, 16, 3)
+        wt = a[1]
+        cin, cout, k = int(wt.shape[2]), int(wt.shape[3]), int(wt.shape[0])
+        if name == "conv2d" and not ((cin % 16 == 0 or cin == 8) and not (k == 1 and cout <= 4)):
+            return None                                       # VALU kernels (first layer, small head)
+        f = mfma_conv_flops(n, h, w, cin, cout, k)
+        if name == "conv3x3_head":
+            f += mfma_conv_flops(n, h, w, 16, int(a[3].shape[3]), 1)
+        return f
+
     def __enter__(self):
-        def timed(x, w, bias=None, act=None, wscale=1.0, out=None):
-            cin, cout, k = int(w.shape[2]), int(w.shape[3]), int(w.shape[0])
-            on_mfma = (cin % 16 == 0 or cin == 8) and not (k == 1 and cout <= 4)
-            if not on_mfma:
-                return self.orig(x, w, bias, act=act, wscale=wscale, out=out)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            y = self.orig(x, w, bias, act=act, wscale=wscale, out=out)
-            e.record()
-            n, h, ww = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
-            self.records.append((s, e, mfma_conv_flops(n, h, ww, cin, cout, k)))
-            return y
-        self.ops.conv2d = timed
+        def wrap(name):
+            orig = self.orig[name]
+
+            def timed(*a, **kw):
+                fl = self._flops(name, a)
+                if fl is None:
+                    return orig(*a, **kw)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                y = orig(*a, **kw)
+                e.record()
+                self.records.append((s, e, fl))
+                return y
+            return timed
+        for n in self.NAMES:
+            setattr(self.ops, n, wrap(n))
         return self
 
     def __exit__(self, *a):
-        self.ops.conv2d = self.orig
+        for n in self.NAMES:
+            setattr(self.ops, n, self.orig[n])
 
     def summary(self):
         ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
@@ -75,8 +98,9 @@ def pmc_traffic_per_launch():
     PMC passes of THIS command, collected and corrected as MI355X_MICROARCH.md prescribes
     (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE x2 on gfx950).  PMC counters cannot
     be read from inside the timed run, so the committed summary is reported; None if absent."""
-    fn = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    import glob
     try:
+        fn = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]   # newest round
         with open(fn) as f:
             return round(json.load(f)["_summary"]["conv_mfma_hbm_bytes_per_launch_avg"], 1)
     except Exception:
@@ -315,7 +339,8 @@ def main():
                        "parity": "logits and masks bit-exact vs oracle/sq_oracle.c (tests/test_gpu_unet.py)"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv_mfma_f32_kernel (3x3 implicit GEMM, v_mfma_f32_16x16x4_f32)",
+                "kernel": "conv_mfma_f32_v2_kernel, all instantiations incl. the pool / head / first-block epilogues "
+                          "(3x3 implicit GEMM on v_mfma_f32_16x16x4_f32)",
                 "achieved": round(achieved, 3),
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
