@@ -107,7 +107,36 @@ def pmc_traffic_per_launch():
         return None
 
 
-def cpu_baseline(weights, params, budget_s=20.0):
+def iou_per_class(a, b, nclass=2):
+    out = []
+    for c in range(nclass):
+        pa, pb = (a == c), (b == c)
+        union = np.logical_or(pa, pb).sum()
+        out.append(float(np.logical_and(pa, pb).sum()) / float(union) if union else 1.0)
+    return out
+
+
+def end_to_end_rate(net, x_dev, iters=5):
+    """PCIe-inclusive rate (reported beside `value`, never as it): the batch starts in pinned host
+    memory and the uint8 masks end in pinned host memory; H2D + predict + D2H on one stream."""
+    xh = x_dev.cpu().pin_memory()
+    mh = torch.empty(x_dev.shape[:3], dtype=torch.uint8).pin_memory()
+    xd = torch.empty_like(x_dev)
+    for _ in range(2):
+        xd.copy_(xh, non_blocking=True), mh.copy_(net.predict(xd), non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        xd.copy_(xh, non_blocking=True)
+        mh.copy_(net.predict(xd), non_blocking=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(x_dev.shape[0] * TILE * TILE / dt / 1e6, 3), "unit": "Mpixels/s",
+            "ms_per_step": round(dt * 1e3, 4),
+            "what": "pinned-host f32 tiles -> H2D -> predict -> uint8 masks -> D2H to pinned host, serial on one stream"}
+
+
+def cpu_baseline(weights, params, budget_s=20.0, gpu_net=None):
     """Bounded CPU sample: time the torch-CPU (oneDNN, fp32, channels_last) restatement on a
     few tiles of the same workload; never the thing shipped, only the reported baseline."""
     from oracle.torch_ref import TorchCpuUNet
@@ -127,8 +156,13 @@ def cpu_baseline(weights, params, budget_s=20.0):
         net(xb)
         times.append(time.perf_counter() - t0)
     best = min(times)
+    iou = None
+    if gpu_net is not None:                       # matched-IoU check of the timed GPU net against this CPU run
+        cpu_mask = np.argmax(net(xb), axis=-1).astype(np.uint8)
+        gpu_mask = gpu_net.predict(torch.from_numpy(xb).to(gpu_net.device)).cpu().numpy()
+        iou = [round(v, 6) for v in iou_per_class(gpu_mask, cpu_mask, gpu_net.n_outputs)]
     return {"value": round(nt * TILE * TILE / best / 1e6, 3), "unit": "Mpixels/s", "cores": net.threads,
-            "kind": "port",
+            "kind": "port", "iou_gpu_vs_cpu_per_class": iou,
             "sample": "torch-CPU oneDNN fp32 restatement of the same U-Net (oracle/torch_ref.py), "
                       "%d x 512x512 tiles per pass, best of 3 passes, %d threads; stands in for the "
                       "reference TF-CPU path (TensorFlow not installable)" % (nt, net.threads)}
@@ -352,7 +386,9 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(weights, params)
+            out["cpu_baseline"] = cpu_baseline(weights, params, gpu_net=net)
+        if world == 1:
+            out["end_to_end"] = end_to_end_rate(net, x)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

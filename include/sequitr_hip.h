@@ -181,6 +181,31 @@ int sq_adam_step_dev_f32(float *p, const float *g, float *m, float *v, int64_t n
                          float beta2, float eps, int32_t *state, float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Batch normalisation between a convolution and its activation: the optional `batch_norm` of the
+ * conv_layer hook (sequitr/networks/unet.py:326-328 leaves the layer abstract; SURVEY.md A.1 pins
+ * tf.layers.batch_normalization defaults: epsilon 1e-3, momentum 0.99).  x (npix, C) NHWC-flat,
+ * C % 4 == 0, C <= 1024.  workspace: sq_bn_workspace_f32 bytes, 8-byte aligned.
+ * ---------------------------------------------------------------------------------------- */
+int64_t sq_bn_workspace_f32(int64_t npix, int C);
+/* batch mean and POPULATION variance per channel (tf.nn.moments); fp64 fixed-order accumulation */
+int sq_bn_stats_f32(const float *x, float *mean, float *var, void *workspace, int64_t npix, int C, void *stream);
+/* scale = gamma / sqrtf(var + eps), shift = fmaf(-mean, scale, beta)  (batch or moving statistics) */
+int sq_bn_fold_f32(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
+                   float *scale, float *shift, int C, void *stream);
+/* moving -= (moving - batch) * (1 - momentum); the variance enters with Bessel's correction
+ * npix/(npix-1) as TF's fused kernel does */
+int sq_bn_update_moving_f32(float *moving_mean, float *moving_var, const float *mean, const float *var,
+                            float momentum, int64_t npix, int C, void *stream);
+/* y = act(fmaf(x, scale[c], shift[c])) */
+int sq_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, int64_t npix, int C, int act,
+                    void *stream);
+/* gradients of y = act(BN(x)) given dy: the activation is differentiated through y_act (= y; NULL when
+ * act == SQ_ACT_NONE); dx (npix,C), dgamma (C), dbeta (C). */
+int sq_bn_bwd_f32(const float *x, const float *dy, const float *y_act, int act, const float *mean, const float *var,
+                  const float *gamma, float eps, float *dx, float *dgamma, float *dbeta, void *workspace,
+                  int64_t npix, int C, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * GAN side (sequitr/networks/gan.py).  weighted_conv2d / to_image / from_image are
  * sq_conv2d_nhwc_fwd_f32 with wscale + act; the entries below are the remaining leaf ops, their
  * gradients and the second-order pieces the WGAN-GP penalty needs (gan.py:719-729).

@@ -124,3 +124,28 @@ def wsoftmax_ce(logits, onehot, weights, want_grad=True):
     _check(lib().oracle_wsoftmax_ce_f32(_p(z), _p(y), _p(w), ctypes.c_long(npix), C,
                                        ctypes.byref(loss), _p(dz)), "wsoftmax_ce")
     return loss.value, dz
+
+
+def bn_stats(x):
+    x = _f32(x)
+    C = x.shape[-1]
+    mean, var = np.empty(C, np.float32), np.empty(C, np.float32)
+    _check(lib().oracle_bn_stats_f32(_p(x), _p(mean), _p(var), ctypes.c_long(x.size // C), C), "bn_stats")
+    return mean, var
+
+
+def bn_fold(gamma, beta, mean, var, eps=1e-3):
+    gamma, beta, mean, var = _f32(gamma), _f32(beta), _f32(mean), _f32(var)
+    scale, shift = np.empty_like(gamma), np.empty_like(gamma)
+    _check(lib().oracle_bn_fold_f32(_p(gamma), _p(beta), _p(mean), _p(var), ctypes.c_float(eps), _p(scale),
+                                    _p(shift), gamma.size), "bn_fold")
+    return scale, shift
+
+
+def bn_apply(x, scale, shift, act=None):
+    x = _f32(x)
+    C = x.shape[-1]
+    y = np.empty_like(x)
+    _check(lib().oracle_bn_apply_f32(_p(x), _p(_f32(scale)), _p(_f32(shift)), _p(y), ctypes.c_long(x.size // C), C,
+                                     ACT[act]), "bn_apply")
+    return y

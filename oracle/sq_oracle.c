@@ -259,4 +259,44 @@ int oracle_wsoftmax_ce_f32(const float *logits, const uint8_t *onehot,
     return 0;
 }
 
-int oracle_version(void) { return 1; }
+/* Batch normalisation between conv and activation (SURVEY.md A.1 optional `batch_norm`;
+ * tf.layers.batch_normalization: y = gamma*(x-mean)/sqrt(var+eps)+beta).  The reference leaves the layer
+ * abstract (sequitr/networks/unet.py:326-328) -> parity unpinned; the restatement fixes the arithmetic:
+ *   stats: mean = sum(x)/M, var = sum(x^2)/M - mean^2 in double, rounded to float (population variance)
+ *   fold : scale = gamma / sqrtf(var + eps); shift = fmaf(-mean, scale, beta)
+ *   apply: y = act(fmaf(x, scale[c], shift[c])) */
+int oracle_bn_stats_f32(const float *x, float *mean, float *var, long npix, int C) {
+    for (int c = 0; c < C; ++c) {
+        double s = 0.0, q = 0.0;
+        for (long p = 0; p < npix; ++p) {
+            const double v = (double)x[p * C + c];
+            s += v;
+            q += v * v;
+        }
+        const double m = s / (double)npix;
+        const double v = q / (double)npix - m * m;
+        mean[c] = (float)m;
+        var[c] = (float)(v > 0.0 ? v : 0.0);
+    }
+    return 0;
+}
+
+int oracle_bn_fold_f32(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
+                       float *scale, float *shift, int C) {
+    for (int c = 0; c < C; ++c) {
+        const float s = gamma[c] / sqrtf(var[c] + eps);
+        scale[c] = s;
+        shift[c] = fmaf(-mean[c], s, beta[c]);
+    }
+    return 0;
+}
+
+int oracle_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, long npix, int C, int act) {
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < npix; ++p)
+        for (int c = 0; c < C; ++c)
+            y[p * C + c] = act_f32(fmaf(x[p * C + c], scale[c], shift[c]), act);
+    return 0;
+}
+
+int oracle_version(void) { return 2; }

@@ -153,9 +153,19 @@ def unet_loss_and_grads(x_nhwc, onehot, wmap, weights, params=None, dropout_mask
         y = F.conv2d(t, w_hwio.permute(3, 2, 0, 1), b, padding=w_hwio.shape[0] // 2)
         return F.relu(y) if act else y
 
+    bn = bool(params.get("batch_norm", False))
+    eps = float(params.get("bn_epsilon", 1e-3))
+
     def block(t, s):
         for k in ("conv1", "conv2"):
-            t = conv(t, W[s + "/" + k + "/kernel"], W[s + "/" + k + "/bias"], True)
+            if bn:                                              # training form: batch statistics
+                z = conv(t, W[s + "/" + k + "/kernel"], W[s + "/" + k + "/bias"], False)
+                mu = z.mean((0, 2, 3), keepdim=True)
+                var = ((z - mu) ** 2).mean((0, 2, 3), keepdim=True)
+                g, b = W[s + "/" + k + "/gamma"].view(1, -1, 1, 1), W[s + "/" + k + "/beta"].view(1, -1, 1, 1)
+                t = F.relu(g * (z - mu) / torch.sqrt(var + eps) + b)
+            else:
+                t = conv(t, W[s + "/" + k + "/kernel"], W[s + "/" + k + "/bias"], True)
         if masks is not None and rate > 0:
             m = torch.as_tensor(np.asarray(masks.pop(0))).to(dtype).permute(0, 3, 1, 2)
             t = t * m / (1.0 - rate)

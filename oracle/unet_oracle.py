@@ -24,10 +24,21 @@ def unet_forward(x, weights, params=None, return_net=False):
     if bridge == "concat":
         raise NotImplementedError("concat bridge is restated in torch_ref only")
 
+    bn = bool(params.get("batch_norm", False))                 # SURVEY A.1 optional BN, inference form
+    eps = float(params.get("bn_epsilon", 1e-3))
+
     def conv_block(t, scope):                                  # unet.py:265-277
         for k in ("conv1", "conv2"):
-            t = co.conv2d(t, weights[scope + "/" + k + "/kernel"],
-                          weights[scope + "/" + k + "/bias"], act="relu")
+            s = scope + "/" + k
+            if not bn:
+                t = co.conv2d(t, weights[s + "/kernel"], weights[s + "/bias"], act="relu")
+                continue
+            z = co.conv2d(t, weights[s + "/kernel"], weights[s + "/bias"], act=None)
+            ones, zeros = np.ones(z.shape[-1], np.float32), np.zeros(z.shape[-1], np.float32)
+            scale, shift = co.bn_fold(weights[s + "/gamma"], weights[s + "/beta"],
+                                      weights.get(s + "/moving_mean", zeros),
+                                      weights.get(s + "/moving_variance", ones), eps)
+            t = co.bn_apply(z, scale, shift, act="relu")
         return t
 
     x = np.ascontiguousarray(x, np.float32)

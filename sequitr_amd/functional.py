@@ -444,3 +444,27 @@ class _WeightedSoftmaxCE(torch.autograd.Function):
 
 def weighted_softmax_cross_entropy(logits, onehot, weights):
     return _WeightedSoftmaxCE.apply(logits, onehot, weights)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    """y = act(BN(x)) with batch statistics; updates the moving statistics in place (first order only)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act):
+        mean, var = ops.bn_stats(x)
+        scale, shift = ops.bn_fold(gamma, beta, mean, var, eps)
+        y = ops.bn_apply(x, scale, shift, act)
+        ops.bn_update_moving_(moving_mean, moving_var, mean, var, x.numel() // x.shape[-1], momentum)
+        ctx.save_for_backward(x, y, mean, var, gamma)
+        ctx.eps, ctx.act = eps, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, var, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.bn_bwd(x, dy.contiguous(), y, ctx.act, mean, var, gamma, ctx.eps)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batch_norm_train(x, gamma, beta, moving_mean, moving_var, eps=ops.BN_EPS, momentum=ops.BN_MOMENTUM, act=None):
+    return _BatchNormTrain.apply(x, gamma, beta, moving_mean, moving_var, float(eps), float(momentum), act)

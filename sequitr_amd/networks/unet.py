@@ -56,17 +56,22 @@ def unet_variable_shapes(params):
     cin = params.get('num_inputs', 1)
     nout = params.get('num_outputs', 2)
     concat = params.get('bridge', 'eltwise_mul') == 'concat'
+    bn = bool(params.get('batch_norm', False))                # trainable BN variables follow their conv's
     out = []
+
+    def conv_vars(s, ci, fo):
+        v = [(s + '/kernel', k + (ci, fo)), (s + '/bias', (fo,))]
+        return v + ([(s + '/gamma', (fo,)), (s + '/beta', (fo,))] if bn else [])
+
     for i, fo in enumerate(f):
         for j, ci in enumerate((cin, fo)):
-            s = 'UNet/down%d/conv%d' % (i, j + 1)
-            out += [(s + '/kernel', k + (ci, fo)), (s + '/bias', (fo,))]
+            out += conv_vars('UNet/down%d/conv%d' % (i, j + 1), ci, fo)
         cin = fo
     for i in reversed(range(len(f) - 1)):
         s = 'UNet/up%d' % i
         out += [(s + '/upscale/kernel', (2, 2, f[i], f[i + 1])), (s + '/upscale/bias', (f[i],))]
         for j, ci in enumerate((2 * f[i] if concat else f[i], f[i])):
-            out += [(s + '/conv%d/kernel' % (j + 1), k + (ci, f[i])), (s + '/conv%d/bias' % (j + 1), (f[i],))]
+            out += conv_vars(s + '/conv%d' % (j + 1), ci, f[i])
     out += [('UNet/to_image/kernel', (1, 1, f[0], nout)), ('UNet/to_image/bias', (nout,))]
     return out
 
@@ -77,7 +82,10 @@ def init_unet_weights(params, seed=0):
     rng = np.random.default_rng(seed)
     w = {}
     for key, shape in unet_variable_shapes(params):
-        w[key] = variance_scaling(shape, rng) if key.endswith('kernel') else np.zeros(shape, np.float32)
+        if key.endswith('kernel'):
+            w[key] = variance_scaling(shape, rng)
+        else:
+            w[key] = (np.ones if key.endswith('gamma') else np.zeros)(shape, np.float32)
     return w
 
 
@@ -261,6 +269,10 @@ class UNet2D(UNet):
         self._builds = 0                                      # host-side step salt when no device counter is set
         self.dropout_masks = None
         self.fuse = bool(params.get('fuse', True))          # fused inference kernels (same bits)
+        # optional BN between conv and ReLU (tf.layers.batch_normalization defaults)
+        self.batch_norm = bool(params.get('batch_norm', False))
+        self.bn_eps = float(params.get('bn_epsilon', ops.BN_EPS))
+        self.bn_momentum = float(params.get('bn_momentum', ops.BN_MOMENTUM))
         self._mask = None
 
     # -- variables ---------------------------------------------------------------------
@@ -307,9 +319,25 @@ class UNet2D(UNet):
     def conv_layer(self, x, filters):
         k = tuple(self.kernel)
         w, b = self._kernel(k + (x.shape[-1], filters)), self._bias(filters)
+        if self.batch_norm:
+            z = F.conv2d(x, w, b, act=None) if self.training else ops.conv2d(x, w, b, act=None)
+            return self.batch_norm_layer(z, act='relu')
         if self.training:
             return F.conv2d(x, w, b, act='relu')
         return ops.conv2d(x, w, b, act='relu')
+
+    def batch_norm_layer(self, z, act=None):
+        """tf.layers.batch_normalization(training=self.training) + activation: batch statistics (and a
+        moving-average update) when training, the moving statistics otherwise.  Variables gamma, beta,
+        moving_mean, moving_variance live in the conv's scope."""
+        n = z.shape[-1]
+        gamma = self.get_variable('gamma', (n,), lambda s: np.ones(s, np.float32))
+        beta = self.get_variable('beta', (n,), lambda s: np.zeros(s, np.float32))
+        mmean = self.get_variable('moving_mean', (n,), lambda s: np.zeros(s, np.float32))
+        mvar = self.get_variable('moving_variance', (n,), lambda s: np.ones(s, np.float32))
+        if self.training:
+            return F.batch_norm_train(z, gamma, beta, mmean, mvar, self.bn_eps, self.bn_momentum, act=act)
+        return ops.bn_inference(z, gamma, beta, mmean, mvar, self.bn_eps, act=act)
 
     def conv_layer_1x1(self, x, filters):
         w, b = self._kernel((1, 1, x.shape[-1], filters)), self._bias(filters)
@@ -383,7 +411,7 @@ class UNet2D(UNet):
     def _fusable(self):
         """The fused kernels replace whole hook sequences, so they are used only when no hook (and
         not the bridge) has been overridden and the graph is the plain inference graph."""
-        if self.training or tuple(self.kernel) != (3, 3):
+        if self.training or tuple(self.kernel) != (3, 3) or self.batch_norm:
             return False
         if self.bridge is not self._default_bridge or self.bridge_type not in ('eltwise_add', 'eltwise_mul', 'eltwise_sub'):
             return False
@@ -470,6 +498,8 @@ class UNet2DBf16(UNet2D):
         UNet2D.__init__(self, dict(params, fuse=False), mode)
         if self.n_inputs != 1:
             raise ValueError('the bf16 graph takes a single-channel f32 image (num_inputs == 1)')
+        if self.batch_norm:
+            raise ValueError('batch_norm is an f32-graph option (the bf16 graph has no BN kernels yet)')
         if any(f % 16 for f in self.filters) or self.bridge_type == 'concat':
             raise ValueError('the bf16 graph needs filter counts that are multiples of 16 and an eltwise bridge')
         k = self.bridge_type

@@ -554,3 +554,77 @@ def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, state, grad_scale=1.0):
     _lib.check(lib.sq_adam_step_dev_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
                                        float(beta2), float(eps), _ptr(state), float(grad_scale), _stream()),
                "sq_adam_step_dev_f32")
+
+
+# ----------------------------------------------------------------------------------------------
+# batch normalisation (include/sequitr_hip.h "Batch normalisation"; SURVEY.md A.1 `batch_norm`)
+# ----------------------------------------------------------------------------------------------
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99                  # tf.layers.batch_normalization defaults
+
+
+def _bn_shape(x):
+    _chk(x, "x")
+    C = x.shape[-1]
+    return x.numel() // C, C
+
+
+def bn_stats(x):
+    """(mean, population variance) per channel over every leading axis of the NHWC tensor x."""
+    npix, C = _bn_shape(x)
+    lib = _lib.load()
+    nbytes = lib.sq_bn_workspace_f32(npix, C)
+    if nbytes < 0:
+        raise _lib.SequitrHipError("bn_stats: unsupported channel count %d" % C)
+    ws = _workspace(nbytes, x.device)
+    mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+    var = torch.empty((C,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.sq_bn_stats_f32(_ptr(x), _ptr(mean), _ptr(var), _ptr(ws), npix, C, _stream()), "sq_bn_stats_f32")
+    return mean, var
+
+
+def bn_fold(gamma, beta, mean, var, eps=BN_EPS):
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (mean, "mean"), (var, "var")):
+        _chk(t, n)
+    C = gamma.numel()
+    scale, shift = torch.empty_like(gamma), torch.empty_like(gamma)
+    lib = _lib.load()
+    _lib.check(lib.sq_bn_fold_f32(_ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), float(eps), _ptr(scale),
+                                 _ptr(shift), C, _stream()), "sq_bn_fold_f32")
+    return scale, shift
+
+
+def bn_apply(x, scale, shift, act=None):
+    npix, C = _bn_shape(x)
+    _chk(scale, "scale"), _chk(shift, "shift")
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.sq_bn_apply_f32(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), npix, C, ACT[act], _stream()),
+               "sq_bn_apply_f32")
+    return y
+
+
+def bn_update_moving_(moving_mean, moving_var, mean, var, npix, momentum=BN_MOMENTUM):
+    lib = _lib.load()
+    _lib.check(lib.sq_bn_update_moving_f32(_ptr(moving_mean), _ptr(moving_var), _ptr(mean), _ptr(var),
+                                          float(momentum), int(npix), moving_mean.numel(), _stream()),
+               "sq_bn_update_moving_f32")
+
+
+def bn_inference(x, gamma, beta, moving_mean, moving_var, eps=BN_EPS, act=None):
+    """y = act(BN(x)) with the moving statistics (training == False)."""
+    scale, shift = bn_fold(gamma, beta, moving_mean, moving_var, eps)
+    return bn_apply(x, scale, shift, act)
+
+
+def bn_bwd(x, dy, y, act, mean, var, gamma, eps=BN_EPS):
+    """(dx, dgamma, dbeta) of y = act(BN_batchstats(x)); y is needed only when act is not None."""
+    npix, C = _bn_shape(x)
+    _chk(dy, "dy")
+    lib = _lib.load()
+    ws = _workspace(lib.sq_bn_workspace_f32(npix, C), x.device)
+    dx = torch.empty_like(x)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+    _lib.check(lib.sq_bn_bwd_f32(_ptr(x), _ptr(dy), _ptr(y) if ACT[act] else None, ACT[act], _ptr(mean), _ptr(var),
+                                _ptr(gamma), float(eps), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), npix, C,
+                                _stream()), "sq_bn_bwd_f32")
+    return dx, dgamma, dbeta

@@ -6,6 +6,7 @@ loss is SURVEY.md A.3, the optimiser is Adam in tf.train.AdamOptimizer form with
 reference's `learning_rate` default 0.01 (sequitr/utils.py:289).  Parameters and gradients
 live in two flat fp32 buffers (parallel.FlatBucket): one all-reduce, one optimiser launch.
 """
+import numpy as np
 import torch
 
 from . import functional as F
@@ -48,9 +49,18 @@ class UNetTrainer(object):
         with torch.no_grad():
             for name in self.pbucket.names:
                 self.pbucket.view(name).copy_(torch.as_tensor(weights[name]).to(self.pbucket.flat.device))
+            for k, v in weights.items():                        # non-trainable state (BN moving statistics)
+                if k not in self.pbucket.shapes:
+                    self.net._vars[k] = torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(
+                        self.pbucket.flat.device)
 
     def state_dict(self):
-        return {k: self.pbucket.view(k).detach().cpu().numpy() for k in self.pbucket.names}
+        """Trainable variables (flat bucket) plus the net's non-trainable state (BN moving statistics)."""
+        sd = {k: self.pbucket.view(k).detach().cpu().numpy() for k in self.pbucket.names}
+        for k, v in self.net._vars.items():
+            if k not in sd:
+                sd[k] = v.detach().cpu().numpy()
+        return sd
 
     def grads(self):
         return {k: self.gbucket.view(k).detach().cpu().numpy() for k in self.gbucket.names}

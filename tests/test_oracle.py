@@ -108,3 +108,30 @@ def test_unet_forward_matches_fp64_64px():
     diff = m != rm
     gap = np.abs(rlogits[..., 0] - rlogits[..., 1])
     assert (gap[diff] < 1e-5).all()
+
+
+def test_batchnorm_oracle_matches_fp64():
+    """BN restatement (SURVEY A.1 optional batch_norm): stats / fold / apply vs plain fp64 numpy."""
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((3, 10, 6, 8)) * 2 + 0.7).astype(np.float32)
+    gamma, beta = rng.standard_normal(8).astype(np.float32), rng.standard_normal(8).astype(np.float32)
+    mean, var = co.bn_stats(x)
+    x64 = x.reshape(-1, 8).astype(np.float64)
+    assert np.allclose(mean, x64.mean(0), rtol=1e-6, atol=1e-7) and np.allclose(var, x64.var(0), rtol=1e-6)
+    scale, shift = co.bn_fold(gamma, beta, mean, var, 1e-3)
+    y = co.bn_apply(x, scale, shift, act="relu")
+    ref = np.maximum(gamma * (x64 - x64.mean(0)) / np.sqrt(x64.var(0) + 1e-3) + beta, 0).reshape(x.shape)
+    assert np.allclose(y, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_unet_oracle_with_batchnorm_identity_stats_is_scaled_plain_net():
+    """moving_mean 0 / moving_variance 1 / gamma 1 / beta 0: BN is a division by sqrt(1+eps) per layer."""
+    from sequitr_amd.networks.unet import init_unet_weights
+    params = {"filters": (16, 32), "batch_norm": True}
+    w = init_unet_weights(params, 1)
+    assert "UNet/down0/conv1/gamma" in w and w["UNet/down0/conv1/gamma"].min() == 1.0
+    x = np.random.default_rng(0).standard_normal((1, 16, 16, 1)).astype(np.float32)
+    z = unet_oracle.unet_forward(x, w, params)
+    plain = unet_oracle.unet_forward(x, {k: v for k, v in w.items() if k.split("/")[-1] in ("kernel", "bias")},
+                                     {"filters": (16, 32)})
+    assert np.allclose(z, plain / np.sqrt(1.001) ** 8, rtol=1e-4, atol=1e-6)     # mul bridge: s^4 (up) * s^2 (skip), then 2 more layers
