@@ -180,6 +180,14 @@ int sq_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, fl
 int sq_adam_step_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
                          float beta2, float eps, int32_t *state, float grad_scale, void *stream);
 
+/* conv_transpose_layer with a 3x3 kernel (SURVEY.md A.1 `up_kernel` = (3,3); hook at
+ * sequitr/networks/unet.py:336-338): TF's conv2d_transpose(k=3, s=2, SAME) equals a SAME 3x3
+ * convolution (sq_conv2d_nhwc_fwd_f32, filter = sq_conv_weight_transform_f32 of the TF (3,3,Cout,Cin)
+ * kernel) of the zero-inserted input u[n,2i+1,2j+1,:] = x[n,i,j,:].  H, W are the SMALL side; C % 4 == 0.
+ * sq_gather_odd2x_f32 is the adjoint (dx[n,i,j,:] = du[n,2i+1,2j+1,:]). */
+int sq_zero_insert2x_f32(const float *x, float *u, int N, int H, int W, int C, void *stream);
+int sq_gather_odd2x_f32(const float *du, float *dx, int N, int H, int W, int C, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Batch normalisation between a convolution and its activation: the optional `batch_norm` of the
  * conv_layer hook (sequitr/networks/unet.py:326-328 leaves the layer abstract; SURVEY.md A.1 pins

@@ -177,6 +177,8 @@ def unet_loss_and_grads(x_nhwc, onehot, wmap, weights, params=None, dropout_mask
     for i in reversed(range(len(filters) - 1)):
         s = "UNet/up%d" % i
         up = F.conv_transpose2d(net[-1], W[s + "/upscale/kernel"].permute(3, 2, 0, 1), W[s + "/upscale/bias"], stride=2)
+        if W[s + "/upscale/kernel"].shape[0] == 3:              # k=3, s=2, TF SAME: keep the first 2H x 2W
+            up = up[:, :, :2 * net[-1].shape[2], :2 * net[-1].shape[3]]
         net.append(block(bridge_op(up, net[i], bridge), s))
     logits = conv(net[-1], W["UNet/to_image/kernel"], W["UNet/to_image/bias"], False).permute(0, 2, 3, 1)
     y = torch.as_tensor(np.asarray(onehot)).to(dtype)

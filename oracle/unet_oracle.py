@@ -47,13 +47,29 @@ def unet_forward(x, weights, params=None, return_net=False):
         net.append(conv_block(co.maxpool2x2(net[-1]), "UNet/down%d" % i))
     for i in reversed(range(len(filters) - 1)):                # unet.py:246-249
         s = "UNet/up%d" % i
-        up = co.convT2x2s2(net[-1], weights[s + "/upscale/kernel"], weights[s + "/upscale/bias"],
-                           skip=net[i], bridge=bridge)         # unet.py:312-319
+        if tuple(params.get("up_kernel", (2, 2))) == (3, 3):
+            up = convT3x3s2(net[-1], weights[s + "/upscale/kernel"], weights[s + "/upscale/bias"])
+            up = {"eltwise_add": up + net[i], "eltwise_mul": up * net[i], "eltwise_sub": up - net[i],
+                  None: up}[bridge]
+        else:
+            up = co.convT2x2s2(net[-1], weights[s + "/upscale/kernel"], weights[s + "/upscale/bias"],
+                               skip=net[i], bridge=bridge)     # unet.py:312-319
         net.append(conv_block(up, s))                          # unet.py:321
     logits = co.conv2d(net[-1], weights["UNet/to_image/kernel"],
                        weights["UNet/to_image/bias"], act=None)  # unet.py:252-253
     net.append(logits)
     return (logits, net) if return_net else logits
+
+
+def convT3x3s2(x, w_tf, bias):
+    """SURVEY A.1 `up_kernel` = (3,3): tf conv2d_transpose(k=3, s=2, SAME).  Restated as the build
+    defines it: zero insertion (x at the odd positions) + SAME 3x3 conv with the 180-degree rotated,
+    in/out-transposed kernel, each output one fmaf chain in the conv oracle's order."""
+    N, H, W, C = x.shape
+    u = np.zeros((N, 2 * H, 2 * W, C), np.float32)
+    u[:, 1::2, 1::2, :] = x
+    w = np.ascontiguousarray(np.transpose(w_tf[::-1, ::-1], (0, 1, 3, 2)))       # (3,3,Cout,Cin) -> HWIO rotated
+    return co.conv2d(u, w, bias, act=None)
 
 
 def predict_mask(logits):

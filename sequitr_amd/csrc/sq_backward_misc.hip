@@ -142,6 +142,39 @@ __global__ __launch_bounds__(256) void space_to_depth2_kernel(const float4 *__re
     }
 }
 
+// zero insertion for the 3x3/s2 transpose conv (`up_kernel` = (3,3)): u[n,2i+1,2j+1,:] = x[n,i,j,:], 0 elsewhere.
+// A SAME 3x3 convolution of u with the rotated, transposed kernel is TF's conv2d_transpose(k=3, s=2, SAME).
+__global__ __launch_bounds__(256) void zero_insert2x_kernel(const float4 *__restrict__ x, float4 *__restrict__ u,
+                                                             int N, int H, int W, int C4) {
+    const int64_t total = (int64_t)N * 2 * H * 2 * W * C4;    // H, W = the SMALL side
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        int64_t t = i / C4;
+        const int xx = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int yy = (int)(t % (2 * H));
+        const int n = (int)(t / (2 * H));
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((xx & 1) && (yy & 1)) v = x[(((int64_t)n * H + (yy >> 1)) * W + (xx >> 1)) * C4 + c];
+        u[i] = v;
+    }
+}
+
+// its adjoint: dx[n,i,j,:] = du[n,2i+1,2j+1,:]
+__global__ __launch_bounds__(256) void gather_odd2x_kernel(const float4 *__restrict__ du, float4 *__restrict__ dx,
+                                                            int N, int H, int W, int C4) {
+    const int64_t total = (int64_t)N * H * W * C4;
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        int64_t t = i / C4;
+        const int j = (int)(t % W);
+        t /= W;
+        const int ii = (int)(t % H);
+        const int n = (int)(t / H);
+        dx[i] = du[(((int64_t)n * 2 * H + 2 * ii + 1) * (2 * W) + 2 * j + 1) * C4 + c];
+    }
+}
+
 // to_image head backward (1x1, Cout <= 4, Cin in {8,16,32}): dx[p,c] = sum_o dz[p,o] w[c,o]; dW / db
 // as block partials [gridDim.x][CIN*COUT + COUT] (wave shuffle tree, then waves 0..3 in order),
 // finished in fixed block order by head_finish_kernel.
@@ -368,6 +401,24 @@ extern "C" int sq_space_to_depth2_f32(const float *dy, float *g, int N, int H, i
     hipLaunchKernelGGL(space_to_depth2_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(256), 0, SQ_ST(stream),
                        reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(g), N, H, W, C / 4);
     return sq_check_launch("sq_space_to_depth2_f32");
+}
+
+extern "C" int sq_zero_insert2x_f32(const float *x, float *u, int N, int H, int W, int C, void *stream) {
+    SQ_REQUIRE(x && u, "sq_zero_insert2x_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "sq_zero_insert2x_f32: C %% 4 == 0");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(u);
+    hipLaunchKernelGGL(zero_insert2x_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(u), N, H, W, C / 4);
+    return sq_check_launch("sq_zero_insert2x_f32");
+}
+
+extern "C" int sq_gather_odd2x_f32(const float *du, float *dx, int N, int H, int W, int C, void *stream) {
+    SQ_REQUIRE(du && dx, "sq_gather_odd2x_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "sq_gather_odd2x_f32: C %% 4 == 0");
+    SQ_REQUIRE_ALIGNED(du); SQ_REQUIRE_ALIGNED(dx);
+    hipLaunchKernelGGL(gather_odd2x_kernel, dim3(grid_for((int64_t)N * H * W * C / 4)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(du), reinterpret_cast<float4 *>(dx), N, H, W, C / 4);
+    return sq_check_launch("sq_gather_odd2x_f32");
 }
 
 static inline int head_blocks(int64_t npix) {

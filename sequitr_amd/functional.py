@@ -468,3 +468,29 @@ class _BatchNormTrain(torch.autograd.Function):
 
 def batch_norm_train(x, gamma, beta, moving_mean, moving_var, eps=ops.BN_EPS, momentum=ops.BN_MOMENTUM, act=None):
     return _BatchNormTrain.apply(x, gamma, beta, moving_mean, moving_var, float(eps), float(momentum), act)
+
+
+class _ConvT3x3(torch.autograd.Function):
+    """3x3 / stride-2 SAME transpose conv (first order): zero insertion + SAME conv with the rotated,
+    transposed kernel.  Backward: dX = odd samples of conv(dY, w as HWIO) (the strided conv this op is the
+    adjoint of), dW = transform(wgrad(u, dY))."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        u = ops.zero_insert2x(x)
+        y = ops.conv2d(u, ops.conv_weight_transform(w), bias, act=None)
+        ctx.save_for_backward(u, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.gather_odd2x(ops.conv2d(dy, w, None, act=None)) if ctx.needs_input_grad[0] else None
+        dwt, db = ops.conv2d_wgrad(u, dy, 3, want_bias=ctx.has_bias)
+        return dx, ops.conv_weight_transform(dwt), db
+
+
+def convT3x3s2(x, w, bias=None):
+    return _ConvT3x3.apply(x, w, bias)

@@ -56,6 +56,7 @@ def unet_variable_shapes(params):
     cin = params.get('num_inputs', 1)
     nout = params.get('num_outputs', 2)
     concat = params.get('bridge', 'eltwise_mul') == 'concat'
+    uk = tuple(params.get('up_kernel', (2, 2)))
     bn = bool(params.get('batch_norm', False))                # trainable BN variables follow their conv's
     out = []
 
@@ -69,7 +70,7 @@ def unet_variable_shapes(params):
         cin = fo
     for i in reversed(range(len(f) - 1)):
         s = 'UNet/up%d' % i
-        out += [(s + '/upscale/kernel', (2, 2, f[i], f[i + 1])), (s + '/upscale/bias', (f[i],))]
+        out += [(s + '/upscale/kernel', uk + (f[i], f[i + 1])), (s + '/upscale/bias', (f[i],))]
         for j, ci in enumerate((2 * f[i] if concat else f[i], f[i])):
             out += conv_vars(s + '/conv%d' % (j + 1), ci, f[i])
     out += [('UNet/to_image/kernel', (1, 1, f[0], nout)), ('UNet/to_image/bias', (nout,))]
@@ -270,6 +271,9 @@ class UNet2D(UNet):
         self.dropout_masks = None
         self.fuse = bool(params.get('fuse', True))          # fused inference kernels (same bits)
         # optional BN between conv and ReLU (tf.layers.batch_normalization defaults)
+        self.up_kernel = tuple(params.get('up_kernel', (2, 2)))   # transpose-conv kernel: (2,2) default or (3,3)
+        if self.up_kernel not in ((2, 2), (3, 3)):
+            raise ValueError('up_kernel %s unsupported: (2,2) or (3,3)' % (self.up_kernel,))
         self.batch_norm = bool(params.get('batch_norm', False))
         self.bn_eps = float(params.get('bn_epsilon', ops.BN_EPS))
         self.bn_momentum = float(params.get('bn_momentum', ops.BN_MOMENTUM))
@@ -352,6 +356,9 @@ class UNet2D(UNet):
         return ops.conv2d(x, w, b, act=None)
 
     def conv_transpose_layer(self, x, filters):
+        if self.up_kernel == (3, 3):                           # SURVEY A.1 alternative: k=3, s=2, SAME
+            w, b = self._kernel((3, 3, filters, x.shape[-1])), self._bias(filters)
+            return F.convT3x3s2(x, w, b) if self.training else ops.convT3x3s2(x, w, b)
         w, b = self._kernel((2, 2, filters, x.shape[-1])), self._bias(filters)
         if self.training:
             return F.convT2x2s2(x, w, b)
@@ -374,7 +381,7 @@ class UNet2D(UNet):
         """Same wiring as the base class, but when neither conv_transpose_layer nor the
         bridge has been overridden the two run as ONE kernel at inference (convT epilogue
         applies the bridge), saving a write + two reads of the up-scaled tensor."""
-        fused = (not self.training
+        fused = (not self.training and self.up_kernel == (2, 2)
                  and type(self).conv_transpose_layer is UNet2D.conv_transpose_layer
                  and self.bridge is self._default_bridge
                  and self.bridge_type in ('eltwise_add', 'eltwise_mul', 'eltwise_sub'))
@@ -411,7 +418,7 @@ class UNet2D(UNet):
     def _fusable(self):
         """The fused kernels replace whole hook sequences, so they are used only when no hook (and
         not the bridge) has been overridden and the graph is the plain inference graph."""
-        if self.training or tuple(self.kernel) != (3, 3) or self.batch_norm:
+        if self.training or tuple(self.kernel) != (3, 3) or self.batch_norm or self.up_kernel != (2, 2):
             return False
         if self.bridge is not self._default_bridge or self.bridge_type not in ('eltwise_add', 'eltwise_mul', 'eltwise_sub'):
             return False

@@ -628,3 +628,32 @@ def bn_bwd(x, dy, y, act, mean, var, gamma, eps=BN_EPS):
                                 _ptr(gamma), float(eps), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), npix, C,
                                 _stream()), "sq_bn_bwd_f32")
     return dx, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------------------------
+# 3x3 / stride-2 transpose conv (`up_kernel` = (3,3)) = zero insertion + SAME 3x3 conv
+# ----------------------------------------------------------------------------------------------
+def zero_insert2x(x):
+    _chk(x, "x", ndim=4)
+    N, H, W, C = x.shape
+    u = torch.empty((N, 2 * H, 2 * W, C), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_zero_insert2x_f32(_ptr(x), _ptr(u), N, H, W, C, _stream()), "sq_zero_insert2x_f32")
+    return u
+
+
+def gather_odd2x(du):
+    _chk(du, "du", ndim=4)
+    N, H2, W2, C = du.shape
+    dx = torch.empty((N, H2 // 2, W2 // 2, C), dtype=torch.float32, device=du.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_gather_odd2x_f32(_ptr(du), _ptr(dx), N, H2 // 2, W2 // 2, C, _stream()), "sq_gather_odd2x_f32")
+    return dx
+
+
+def convT3x3s2(x, w, bias=None):
+    """TF conv2d_transpose(kernel 3, stride 2, SAME): x (N,H,W,Cin), w (3,3,Cout,Cin) -> (N,2H,2W,Cout)."""
+    _chk(w, "w", ndim=4)
+    if tuple(w.shape[:2]) != (3, 3) or w.shape[3] != x.shape[3]:
+        raise ValueError("convT3x3s2: weight %s does not match %d input channels" % (tuple(w.shape), x.shape[3]))
+    return conv2d(zero_insert2x(x), conv_weight_transform(w), bias, act=None)

@@ -141,3 +141,32 @@ def test_rejects_cpu_device_and_bad_bridge():
         UNet2D({"device": "cpu"}, "infer")
     with pytest.raises(ValueError):
         UNet2D({"bridge": "nope", "device": "cuda:0"}, "infer")
+
+
+def test_up_kernel_3x3_transpose_conv_bit_exact_and_trainable():
+    """SURVEY A.1 alternative conv_transpose_layer: kernel (3,3), stride 2, SAME."""
+    from oracle import torch_ref as tr
+    from sequitr_amd.train import UNetTrainer
+    params = {"shape": (32, 32), "filters": (16, 32, 64), "up_kernel": (3, 3)}
+    net, w = make(params, seed=5)
+    assert w["UNet/up0/upscale/kernel"].shape == (3, 3, 16, 32)
+    x = tiles(2, 2, 32, 32)
+    mask = net.predict(x)
+    ref_logits, ref_net = unet_oracle.unet_forward(x, w, params, return_net=True)
+    for i, (a, b) in enumerate(zip(net._net, ref_net)):
+        assert_bit_exact(a.cpu().numpy(), b, "layer %d" % i)
+    assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref_logits), "mask")
+    # gradients through the zero-insert / gather pair vs the fp64 graph
+    rng = np.random.default_rng(1)
+    lab = rng.random((2, 32, 32)) < 0.4
+    onehot = np.stack([~lab, lab], -1).astype(np.uint8)
+    wmap = (1 + rng.random((2, 32, 32, 1))).astype(np.float32)
+    t = UNetTrainer(dict(params, device="cuda:0", dropout=0.0, seed=5), learning_rate=0.01)
+    w0 = t.state_dict()
+    d = lambda a: torch.from_numpy(a).to("cuda:0")
+    loss = t.forward_backward(d(x), d(onehot), d(wmap))
+    rloss, rgrads, _ = tr.unet_loss_and_grads(x, onehot, wmap, w0, params)
+    assert abs(loss.item() - rloss) <= 1e-5 * abs(rloss)
+    g = t.grads()
+    for k in rgrads:
+        assert np.max(np.abs(g[k] - rgrads[k])) <= 1e-3 * np.max(np.abs(rgrads[k])) + 1e-7, k

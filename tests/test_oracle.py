@@ -135,3 +135,18 @@ def test_unet_oracle_with_batchnorm_identity_stats_is_scaled_plain_net():
     plain = unet_oracle.unet_forward(x, {k: v for k, v in w.items() if k.split("/")[-1] in ("kernel", "bias")},
                                      {"filters": (16, 32)})
     assert np.allclose(z, plain / np.sqrt(1.001) ** 8, rtol=1e-4, atol=1e-6)     # mul bridge: s^4 (up) * s^2 (skip), then 2 more layers
+
+
+def test_convT3x3s2_restatement_matches_torch_conv_transpose():
+    """up_kernel=(3,3): zero insertion + rotated SAME conv == conv_transpose2d(k=3, s=2) cropped to 2H x 2W
+    (TF SAME for the adjoint conv pads 0 before / 1 after)."""
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 5, 6, 8)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 4, 8)) * 0.2).astype(np.float32)           # TF layout (kh,kw,Cout,Cin)
+    b = rng.standard_normal(4).astype(np.float32)
+    y = unet_oracle.convT3x3s2(x, w, b)
+    xt = torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2)
+    wt = torch.tensor(w, dtype=torch.float64).permute(3, 2, 0, 1)                # (Cin, Cout, kh, kw)
+    ref = torch.nn.functional.conv_transpose2d(xt, wt, torch.tensor(b, dtype=torch.float64), stride=2)
+    ref = ref[:, :, :10, :12].permute(0, 2, 3, 1).numpy()
+    assert y.shape == (2, 10, 12, 4) and np.allclose(y, ref, rtol=1e-5, atol=1e-5)
