@@ -248,6 +248,13 @@ int sq_dot_per_sample_f32(const float *a, const float *b, float *out, float *wor
  * workspace: 256 floats. */
 int sq_mbstd_fwd_f32(const float *x, float *out, float *workspace, int N, int64_t per_sample, void *stream);
 
+/* Small-image batches (the 4x4 / 8x8 levels of generator_network / discriminator_network,
+ * gan.py:246-316,149-240) as ONE image of R x Cc cells of pitch (H+1, W+1): m (1, R*(H+1), Cc*(W+1), C),
+ * image n at cell (n / Cc, n % Cc), a zero row and column after every image = the SAME padding.  A KxK
+ * (K <= 3) SAME convolution of m equals the per-image convolutions on the image cells, bit for bit. */
+int sq_mosaic_pack_f32(const float *x, float *m, int N, int H, int W, int C, int R, int Cc, void *stream);
+int sq_mosaic_unpack_f32(const float *m, float *y, int N, int H, int W, int C, int R, int Cc, void *stream);
+
 /* M (Ca,Cb) = sum_p a[p,:]^T b[p,:] with Ca <= 4, Cb % 4 == 0: weight gradient of to_image / from_image. */
 int64_t sq_wgrad1x1_small_workspace_f32(int64_t npix, int Ca, int Cb);
 int sq_wgrad1x1_small_f32(const float *a, const float *b, float *m, float *workspace, int64_t npix, int Ca, int Cb,

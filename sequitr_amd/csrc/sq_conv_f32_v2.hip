@@ -449,8 +449,14 @@ int launch_v2(const float *x, const float *w, const float *bias, float *y, int N
 template <int KS, int KC>
 int dispatch_bn(const float *x, const float *w, const float *bias, float *y, int N, int H, int W, int Cin,
                 int Cout, float wscale, int act, const SqConvEpi &epi, hipStream_t st) {
-    if (Cout >= 64) return launch_v2<64, KS, KC, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
-    if (Cout > 16) return launch_v2<32, KS, KC, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
+    // widest channel block the layer fills the chip with: small images (GAN 4x4..32x32 levels, small
+    // batches) have few pixel tiles, so trade operand reuse for blocks until there are ~2 per CU.
+    // BN only changes which block computes an output, never its fmaf chain.
+    const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * N;
+    int bn = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16);
+    while (bn > 16 && (int64_t)ntiles * ((Cout + bn - 1) / bn) < 2 * 256) bn >>= 1;
+    if (bn == 64) return launch_v2<64, KS, KC, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
+    if (bn == 32) return launch_v2<32, KS, KC, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
     return launch_v2<16, KS, KC, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
 }
 

@@ -6,6 +6,8 @@ torch is plumbing only: it owns device memory and the HIP stream.  Every op
 validates device / dtype / contiguity / shape on the host before launching, and
 there is no CPU path: a CPU tensor is an error.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -45,8 +47,45 @@ def _out(out, shape, like, dtype=torch.float32):
     return out
 
 
+USE_MOSAIC = os.environ.get("SQ_MOSAIC", "1") != "0"      # A/B switch for the small-image batching below
+
+
+def _mosaic_plan(N, H, W):
+    """(R, Cc) cell grid that packs N small images into one image with the fewest 16x16 conv tiles
+    (sq_mosaic_pack_f32), or None when the batch is better left as it is."""
+    if not USE_MOSAIC or N < 2 or max(H, W) > 8:
+        return None
+    best = None
+    for cc in range(1, N + 1):
+        r = -(-N // cc)
+        tiles = -(-(r * (H + 1)) // 16) * -(-(cc * (W + 1)) // 16)
+        if best is None or tiles < best[0]:
+            best = (tiles, r, cc)
+    return None if best[0] >= N else (best[1], best[2])
+
+
+def mosaic_pack(x, R, Cc):
+    _chk(x, "x", ndim=4)
+    N, H, W, C = x.shape
+    m = torch.empty((1, R * (H + 1), Cc * (W + 1), C), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_mosaic_pack_f32(_ptr(x), _ptr(m), N, H, W, C, R, Cc, _stream()), "sq_mosaic_pack_f32")
+    return m
+
+
+def mosaic_unpack(m, N, H, W, R, Cc):
+    _chk(m, "m", ndim=4)
+    C = m.shape[3]
+    y = torch.empty((N, H, W, C), dtype=torch.float32, device=m.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_mosaic_unpack_f32(_ptr(m), _ptr(y), N, H, W, C, R, Cc, _stream()), "sq_mosaic_unpack_f32")
+    return y
+
+
 def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None):
-    """KxK SAME conv + bias + activation.  x (N,H,W,Cin), w (K,K,Cin,Cout) HWIO."""
+    """KxK SAME conv + bias + activation.  x (N,H,W,Cin), w (K,K,Cin,Cout) HWIO.
+    Batches of small images (H, W <= 8) run as one mosaic image (3x3) or as a flat pixel strip (1x1):
+    same fmaf chain per output, far fewer and fuller 16x16 tiles."""
     _chk(x, "x", ndim=4), _chk(w, "w", ndim=4)
     N, H, W, Cin = x.shape
     K, K2, Ci, Cout = w.shape
@@ -56,6 +95,14 @@ def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None):
         _chk(bias, "bias")
         if bias.numel() != Cout:
             raise ValueError("bias must have %d elements" % Cout)
+    if out is None and USE_MOSAIC and W < 16 and N * H > 1:
+        P = N * H * W
+        if K == 1 and P % 16 == 0:                            # pixels are independent: a free view
+            return conv2d(x.view(1, P // 16, 16, Cin), w, bias, act, wscale).view(N, H, W, Cout)
+        plan = _mosaic_plan(N, H, W) if (K == 3 and Cin % 4 == 0 and Cout % 4 == 0) else None
+        if plan is not None:
+            ym = conv2d(mosaic_pack(x, *plan), w, bias, act, wscale)
+            return mosaic_unpack(ym, N, H, W, *plan)
     y = _out(out, (N, H, W, Cout), x)
     lib = _lib.load()
     _lib.check(lib.sq_conv2d_nhwc_fwd_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, K,
@@ -216,6 +263,13 @@ def conv2d_wgrad(x, dy, K, want_bias=True):
     Cout = dy.shape[3]
     if tuple(dy.shape[:3]) != (N, H, W):
         raise ValueError("x %s and dy %s differ in N,H,W" % (tuple(x.shape), tuple(dy.shape)))
+    if USE_MOSAIC and W < 16 and N * H > 1 and Cin % 4 == 0 and Cout % 4 == 0:
+        P = N * H * W
+        if K == 1 and P % 16 == 0:
+            return conv2d_wgrad(x.view(1, P // 16, 16, Cin), dy.view(1, P // 16, 16, Cout), K, want_bias)
+        plan = _mosaic_plan(N, H, W) if K == 3 else None
+        if plan is not None:                                  # separator cells of dY are zero: they add nothing
+            return conv2d_wgrad(mosaic_pack(x, *plan), mosaic_pack(dy, *plan), K, want_bias)
     lib = _lib.load()
     nbytes = lib.sq_conv2d_nhwc_wgrad_workspace_f32(N, H, W, Cin, Cout, K)
     if nbytes < 0:

@@ -130,3 +130,33 @@ def test_errors_are_loud():
         ops.conv2d(x, w)                          # Cin = 12 unsupported
     with pytest.raises(ValueError):
         ops.conv2d(dev(tiles(1, 1, 16, 16, 16)), w)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,K", [(32, 4, 4, 64, 128, 3), (5, 8, 8, 32, 48, 3), (7, 4, 8, 16, 16, 3),
+                                              (32, 1, 1, 528, 64, 1), (32, 4, 4, 64, 32, 1), (3, 5, 3, 16, 32, 3)])
+def test_small_image_batches_run_as_mosaic_bit_exact(N, H, W, Cin, Cout, K):
+    """GAN 4x4 / 8x8 levels and dense layers (gan.py:149-316): the batch is convolved as ONE mosaic image
+    (3x3) or a flat pixel strip (1x1); every output keeps its exact fmaf chain."""
+    x = tiles(N + H, N, H, W, Cin)
+    w = rand_weights(Cin + Cout, (K, K, Cin, Cout))
+    b = rand_weights(1, (Cout,), 0.1)
+    if K == 3 and max(H, W) <= 8:
+        assert ops._mosaic_plan(N, H, W) is not None
+    y = ops.conv2d(dev(x), dev(w), dev(b), act="leaky", wscale=0.7)
+    assert_bit_exact(y.cpu().numpy(), co.conv2d(x, w, b, act="leaky", wscale=0.7), "mosaic conv")
+    # pack / unpack are inverse on the image cells and write zeros everywhere else
+    if K == 3:
+        R, Cc = ops._mosaic_plan(N, H, W)
+        m = ops.mosaic_pack(dev(x), R, Cc)
+        assert_bit_exact(ops.mosaic_unpack(m, N, H, W, R, Cc).cpu().numpy(), x, "unpack(pack)")
+        assert float(m.abs().sum().item()) == pytest.approx(float(np.abs(x).astype(np.float64).sum()), rel=1e-5)
+    # weight gradient over the mosaic == fp64 reference
+    dy = tiles(9, N, H, W, Cout)
+    dw, db = ops.conv2d_wgrad(dev(x), dev(dy), K)
+    xt = torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2)
+    wt = torch.zeros((Cout, Cin, K, K), dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    (torch.nn.functional.conv2d(xt, wt, bt, padding=K // 2) * torch.tensor(dy, dtype=torch.float64).permute(0, 3, 1, 2)).sum().backward()
+    ref = wt.grad.permute(2, 3, 1, 0).numpy()
+    assert np.max(np.abs(dw.cpu().numpy() - ref)) <= 2e-5 * np.max(np.abs(ref))
+    assert np.max(np.abs(db.cpu().numpy() - bt.grad.numpy())) <= 2e-5 * np.max(np.abs(bt.grad.numpy()))
