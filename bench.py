@@ -227,6 +227,67 @@ def main_train(args):
         dist.destroy_process_group()
 
 
+def main_centroids(args):
+    """mask -> connected components -> centroids (CentroidWriter.write, utils.py:531-578)
+    on 32 resident 512x512 uint8 masks (60 random disks of radius 6-15 per tile); CPU leg = the reference's
+    scipy loop (oracle/centroids_ref.py) on a few of the same frames."""
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from sequitr_amd import centroids, _lib
+    rng = np.random.default_rng(2)
+    yy, xx = np.mgrid[0:TILE, 0:TILE]
+    mask = np.zeros((BATCH, TILE, TILE), np.uint8)
+    for i in range(BATCH):
+        for _ in range(60):
+            cy, cx, r = rng.integers(0, TILE), rng.integers(0, TILE), rng.integers(6, 16)
+            mask[i][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 1
+    md = torch.from_numpy(mask).to(dev)
+    for _ in range(args.warmup):
+        frames = centroids.mask_centroids(md)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frames = centroids.mask_centroids(md)          # includes the D2H of the rows and the host ordering
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # kernel-only time of the same call (HIP events around the C-ABI launch sequence)
+    lib = _lib.load()
+    ws = torch.empty(lib.sq_mask_centroids_workspace(BATCH, TILE, TILE) // 4 + 4, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = torch.empty((1 << 18, 5), dtype=torch.float32, device=dev)
+    keys = torch.empty((1 << 18,), dtype=torch.int32, device=dev)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(args.steps):
+        lib.sq_mask_centroids_u8(md.data_ptr(), BATCH, TILE, TILE, ws.data_ptr(), cnt.data_ptr(), out.data_ptr(),
+                                 keys.data_ptr(), 1 << 18, torch.cuda.current_stream().cuda_stream)
+    e.record()
+    torch.cuda.synchronize()
+    kms = s.elapsed_time(e) / args.steps
+    npx = BATCH * TILE * TILE
+    alg_bytes = npx * (3 * 1 + 3 * 4)                  # mask read by 3 passes, parent written once + read twice
+    res = {"metric": "mask -> centroids Mpixels/sec on 512x512 uint8 masks", "value": round(npx / dt / 1e6, 2),
+           "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8/int32", "data": "synthetic",
+           "config": {"workload": "CentroidWriter.write on 32 x 512x512 masks, 60 disks per tile",
+                      "components": int(sum(len(f) for f in frames))},
+           "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(alg_bytes / (kms * 1e-3) / 8e12, 4), "traffic": None,
+                        "kernel_ms_per_step": round(kms, 4),
+                        "algorithmic_bytes_per_pixel": 15}}
+    if not args.no_cpu_baseline:
+        from oracle import centroids_ref
+        t0 = time.perf_counter()
+        ref = centroids_ref.mask_centroids(mask[:4])
+        ct = time.perf_counter() - t0
+        same = all(np.array_equal(a, b) for a, b in zip(frames[:4], ref))
+        res["cpu_baseline"] = {"value": round(4 * TILE * TILE / ct / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
+                               "kind": "port", "sample": "the reference's scipy label + center_of_mass loop "
+                               "(oracle/centroids_ref.py) on 4 of the 32 frames", "rows_identical": bool(same)}
+    print(json.dumps(res))
+
+
 def main_gan(args):
     """BASELINE configs[4]: progressive WGAN-GP at level 6 (256x256x2), batch 32 per GPU, alpha = 1;
     one iteration = one d_solver + one g_solver (sequitr/networks/gan.py:850-851)."""
@@ -297,7 +358,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="training dtype (--mode train)")
     ap.add_argument("--graph", type=int, default=1, help="--mode train: replay the step as hipGraphs (1) or eager (0)")
     ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
-    ap.add_argument("--mode", choices=["infer", "train", "gan"], default="infer",
+    ap.add_argument("--mode", choices=["infer", "train", "gan", "centroids"], default="infer",
                     help="infer = the headline metric (BASELINE configs[1]); train = configs[2]/[3] "
                          "(U-Net training step, batch 16 per GPU) for DESIGN.md, not the driver's line")
     args = ap.parse_args()
@@ -305,6 +366,8 @@ def main():
         return main_train(args)
     if args.mode == "gan":
         return main_gan(args)
+    if args.mode == "centroids":
+        return main_centroids(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -343,6 +343,20 @@ int64_t sq_conv3x3_first_wgrad_workspace_bf16(int N, int H, int W, int Cout);
 int sq_conv3x3_first_wgrad_bf16(const float *x, const void *dy, float *dw, float *db, float *workspace, int N,
                                 int H, int W, int Cout, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Mask -> connected components -> centroids (the step after the hot path).
+ * CentroidWriter.write, sequitr/utils.py:531-578: per frame, per class c > 0,
+ * scipy.ndimage.label(mask == c) (4-connectivity) and center_of_mass of every label.
+ *   mask (N,H,W) uint8 class labels on the device; workspace sq_mask_centroids_workspace bytes, 16-B aligned.
+ *   count (device int32): number of components found (may exceed max_out: then re-run with more room).
+ *   out (max_out,5) f32 rows [frame, x = row centre, y = column centre, 0, class] in NO particular order;
+ *   keys (max_out) int32 = linear index of each component's first pixel in raster order: sorting rows by
+ *   (frame, class, key) gives the reference's order (scipy numbers labels by first pixel).
+ * ---------------------------------------------------------------------------------------- */
+int64_t sq_mask_centroids_workspace(int N, int H, int W);
+int sq_mask_centroids_u8(const uint8_t *mask, int N, int H, int W, void *workspace, int32_t *count, float *out,
+                         int32_t *keys, int max_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

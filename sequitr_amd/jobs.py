@@ -99,6 +99,11 @@ def SERVER_segment(params, options):
 
     pipe = ImagePipeline.load(params['pipeline']) if params.get('pipeline') else None
     batch = int(params.get('batch', 32))
+    writer = None
+    if options.get('centroids'):                               # the reference's next step: utils.CentroidWriter
+        from .centroids import CentroidWriter
+        writer, n_objects = CentroidWriter(os.path.join(out_dir, 'tracks.hdf5')), 0
+        frames_out = {}
     masks = np.empty(x.shape[:3], np.uint8)
     logits = np.empty(x.shape[:3] + (net.n_outputs,), np.float32) if options.get('save_logits') else None
     t0 = time.time()
@@ -108,15 +113,31 @@ def SERVER_segment(params, options):
             xb = np.stack([pipe(t.copy()) for t in xb]).astype(np.float32)
         m = net.predict(xb)
         masks[i:i + batch] = m.cpu().numpy()
+        if writer is not None:                                 # centroids straight from the mask in HBM
+            from .centroids import mask_centroids
+            for k, coords in enumerate(mask_centroids(m)):
+                coords[:, 0] = i + k                           # frame index within the whole stack
+                frames_out[i + k] = coords
+                n_objects += len(coords)
         if logits is not None:
             logits[i:i + batch] = net.logits().cpu().numpy()
     torch.cuda.synchronize()
     dt = time.time() - t0
+    if writer is not None:
+        for k in sorted(frames_out):
+            if writer._hdf is not None:
+                writer._hdf['frames'].create_group('frame_' + str(k)).create_dataset(
+                    'coords', data=frames_out[k], dtype='float32')
+            else:
+                writer._frames['frames/frame_' + str(k) + '/coords'] = frames_out[k]
+        writer.close()
     np.save(os.path.join(out_dir, 'mask.npy'), masks)
     if logits is not None:
         np.save(os.path.join(out_dir, 'logits.npy'), logits)
     info = {'tiles': int(N), 'shape': [int(s) for s in x.shape[1:3]], 'seconds': dt,
             'mpixels_per_s': float(N * x.shape[1] * x.shape[2] / max(dt, 1e-9) / 1e6), 'device': device}
+    if writer is not None:
+        info['centroids'] = {'file': os.path.basename(writer.filename), 'objects': int(n_objects)}
     with open(os.path.join(out_dir, 'segment.json'), 'w') as f:
         json.dump(info, f, indent=2)
     logger.info('Segmented {tiles} tiles in {seconds:.3f}s on {device}'.format(**info))

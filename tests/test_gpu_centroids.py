@@ -1,0 +1,86 @@
+"""Mask -> components -> centroids on the GPU vs the reference's scipy loop
+(oracle/centroids_ref.py restates CentroidWriter.write, sequitr/utils.py:531-578): bit-exact rows in
+the reference's order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import centroids_ref
+from sequitr_amd import centroids
+
+pytestmark = pytest.mark.gpu
+
+
+def disks(seed, n, h, w, count, classes=1, rmax=9):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    m = np.zeros((n, h, w), np.uint8)
+    for i in range(n):
+        for _ in range(count):
+            cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(1, rmax)
+            m[i][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = rng.integers(1, classes + 1)
+    return m
+
+
+def check(mask):
+    got = centroids.mask_centroids(torch.from_numpy(mask).to("cuda:0"))
+    ref = centroids_ref.mask_centroids(mask)
+    assert len(got) == len(ref)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert a.shape == b.shape, (i, a.shape, b.shape)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (i, a[:4], b[:4])
+
+
+@pytest.mark.parametrize("shape,count,classes", [((3, 64, 64), 12, 1), ((2, 100, 130), 30, 3), ((4, 37, 200), 25, 2),
+                                                 ((1, 512, 512), 120, 1), ((2, 17, 5), 3, 4)])
+def test_random_disks_bit_exact(shape, count, classes):
+    check(disks(sum(shape), shape[0], shape[1], shape[2], count, classes))
+
+
+def test_edge_cases():
+    check(np.zeros((2, 16, 16), np.uint8))                                  # nothing
+    check(np.ones((1, 70, 150), np.uint8))                                  # one component, runs cross segments
+    m = np.zeros((1, 40, 140), np.uint8)
+    m[0, ::2, :] = 1                                                        # stripes
+    m[0, :, 69] = 1                                                         # ... joined by one column
+    check(m)
+    rng = np.random.default_rng(0)
+    check((rng.random((2, 48, 96)) < 0.55).astype(np.uint8))                # percolation-like noise, many merges
+    check(rng.integers(0, 4, (2, 33, 67)).astype(np.uint8))                 # 3 classes of salt and pepper
+    spiral = np.zeros((1, 64, 64), np.uint8)                                # long winding component
+    for k in range(0, 30, 4):
+        spiral[0, k, k:64 - k] = 2
+        spiral[0, k:64 - k, 63 - k] = 2
+        spiral[0, 63 - k, k + 2:64 - k] = 2
+        spiral[0, k + 4:64 - k, k + 2] = 2
+    check(spiral)
+    diag = np.eye(32, dtype=np.uint8)[None]                                 # 4-connectivity: 32 single pixels
+    check(diag)
+
+
+def test_full_batch_properties_and_writer(tmp_path):
+    """BASELINE-size batch (32 x 512 x 512): component count, total area and the writer's file layout."""
+    mask = disks(7, 32, 512, 512, 60, 1, rmax=15)
+    md = torch.from_numpy(mask).to("cuda:0")
+    frames = centroids.mask_centroids(md)
+    from scipy.ndimage import label
+    for i in (0, 13, 31):
+        assert len(frames[i]) == label(mask[i])[1]
+        assert np.all(frames[i][:, 0] == i) and np.all(frames[i][:, 4] == 1)
+    with centroids.CentroidWriter(str(tmp_path / "tracks.hdf5")) as cw:
+        cw.write(md)
+    fn = cw.filename
+    assert os.path.exists(fn)
+    if fn.endswith(".npz"):
+        z = np.load(fn)
+        assert sorted(z.files, key=lambda s: int(s.split("_")[1].split("/")[0]))[5] == "frames/frame_5/coords"
+        assert np.array_equal(z["frames/frame_31/coords"], frames[31])
+
+
+def test_errors_are_loud():
+    with pytest.raises(Exception):
+        centroids.mask_centroids(torch.zeros((1, 8, 8), dtype=torch.uint8))     # CPU tensor
+    with pytest.raises(ValueError):
+        centroids.mask_centroids(torch.zeros((8, 8), dtype=torch.uint8, device="cuda:0"))

@@ -85,3 +85,26 @@ def test_train_job_then_segment_with_the_saved_model(tmp_path, monkeypatch):
     inter = np.logical_and(mask == 1, lab[None] == 1).sum()
     union = np.logical_or(mask == 1, lab[None] == 1).sum()
     assert inter / union > 0.8                                  # IoU of the trained model on its own data
+
+
+def test_segment_job_writes_centroids(tmp_path):
+    """options['centroids']: the step after the hot path (CentroidWriter, sequitr/utils.py:479-578) runs on
+    the masks while they are still in HBM; rows equal the reference's scipy loop on the saved masks."""
+    from oracle import centroids_ref
+    x = np.random.default_rng(1).standard_normal((5, 64, 64, 1)).astype(np.float32)
+    np.save(str(tmp_path / "tiles.npy"), x)
+    params = {"input": str(tmp_path / "tiles.npy"), "shape": (64, 64), "num_outputs": 2, "seed": 3, "batch": 2}
+    fn = write_job(tmp_path, func="SERVER_segment", params=repr(params), options="{'gpu': 0, 'centroids': True}")
+    out = str(tmp_path / "out")
+    worker.worker(argparse.Namespace(job=fn, out=out))
+    logs = open(os.path.join(out, [f for f in os.listdir(out) if f.startswith("LOG_")][0])).read()
+    assert "exception" not in logs, logs
+    info = json.load(open(os.path.join(out, "segment.json")))
+    mask = np.load(os.path.join(out, "mask.npy"))
+    ref = centroids_ref.mask_centroids(mask)
+    assert info["centroids"]["objects"] == sum(len(r) for r in ref) > 0
+    fn = os.path.join(out, info["centroids"]["file"])
+    if fn.endswith(".npz"):
+        z = np.load(fn)
+        for i, r in enumerate(ref):
+            assert np.array_equal(z["frames/frame_%d/coords" % i], r), i
