@@ -288,6 +288,56 @@ def main_centroids(args):
     print(json.dumps(res))
 
 
+def main_weightmap(args):
+    """ImageWeightMap (pipeline.py:475-479) of 16 resident 512x512 label tiles (config 3's
+    label definition: 60 disks of radius 6-15); CPU leg = the reference's scipy expression on 4 tiles."""
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from sequitr_amd import ops as sq_ops
+    nb = 16
+    rng = np.random.default_rng(2)
+    yy, xx = np.mgrid[0:TILE, 0:TILE]
+    lab = np.zeros((nb, TILE, TILE), np.float32)
+    for i in range(nb):
+        for _ in range(60):
+            cy, cx, r = rng.integers(0, TILE), rng.integers(0, TILE), rng.integers(6, 16)
+            lab[i][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 1
+    ld = torch.from_numpy(lab).to(dev)
+    for _ in range(args.warmup):
+        w = sq_ops.weightmap_edt(ld, 10., 5.)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    s.record()
+    for _ in range(args.steps):
+        w = sq_ops.weightmap_edt(ld, 10., 5.)
+    e.record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    kms = s.elapsed_time(e) / args.steps
+    npx = nb * TILE * TILE
+    alg = npx * (4 * 3 + 2 + 2 + 4)                    # image read by 3 passes, g written + read, f32 map written
+    res = {"metric": "EDT weight maps Mpixels/sec on 512x512 label tiles", "value": round(npx / dt / 1e6, 2),
+           "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "int32/f64", "data": "synthetic",
+           "config": {"workload": "ImageWeightMap(w0=10, sigma=5) on 16 x 512x512 binary label tiles, f32 maps left in HBM"},
+           "roofline": {"bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(alg / (kms * 1e-3) / 8e12, 4), "traffic": None,
+                        "kernel_ms_per_step": round(kms, 4), "algorithmic_bytes_per_pixel": 20}}
+    if not args.no_cpu_baseline:
+        from oracle import weightmap_ref
+        t0 = time.perf_counter()
+        ref = [weightmap_ref.image_weight_map(lab[i]) for i in range(4)]
+        ct = time.perf_counter() - t0
+        wn = w[:4].cpu().numpy()
+        same = all(np.array_equal(wn[i], ref[i][..., 0].astype(np.float32)) for i in range(4))
+        res["cpu_baseline"] = {"value": round(4 * TILE * TILE / ct / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
+                               "kind": "port", "sample": "the reference's scipy EDT expression "
+                               "(oracle/weightmap_ref.py) on 4 of the 16 tiles", "maps_identical_f32": bool(same)}
+    print(json.dumps(res))
+
+
 def main_gan(args):
     """BASELINE configs[4]: progressive WGAN-GP at level 6 (256x256x2), batch 32 per GPU, alpha = 1;
     one iteration = one d_solver + one g_solver (sequitr/networks/gan.py:850-851)."""
@@ -358,7 +408,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="training dtype (--mode train)")
     ap.add_argument("--graph", type=int, default=1, help="--mode train: replay the step as hipGraphs (1) or eager (0)")
     ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
-    ap.add_argument("--mode", choices=["infer", "train", "gan", "centroids"], default="infer",
+    ap.add_argument("--mode", choices=["infer", "train", "gan", "centroids", "weightmap"], default="infer",
                     help="infer = the headline metric (BASELINE configs[1]); train = configs[2]/[3] "
                          "(U-Net training step, batch 16 per GPU) for DESIGN.md, not the driver's line")
     args = ap.parse_args()
@@ -368,6 +418,8 @@ def main():
         return main_gan(args)
     if args.mode == "centroids":
         return main_centroids(args)
+    if args.mode == "weightmap":
+        return main_weightmap(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

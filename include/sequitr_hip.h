@@ -357,6 +357,22 @@ int64_t sq_mask_centroids_workspace(int N, int H, int W);
 int sq_mask_centroids_u8(const uint8_t *mask, int N, int H, int W, void *workspace, int32_t *count, float *out,
                          int32_t *keys, int max_out, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * EDT weight maps (the step in front of the training hot path).
+ * ImageWeightMap.pipe, sequitr/pipeline.py:475-479:
+ *   d = distance_transform_edt(1 - image);  out = w0*(1-image)*exp(-(d*d)/(2 sigma^2 + 1e-99)) + image + 1
+ * img (N,H,W) f32 binary label images (values 0 / 1; a pixel is a feature iff 1 - image == 0), one map per
+ * image.  workspace: sq_weightmap_workspace bytes, 16-B aligned.  H, W < 30000.
+ *   sq_edt_sq_f32        : d2 (N,H,W) int32 = EXACT squared Euclidean distance to the nearest feature
+ *                          (an image with no feature reproduces scipy's artefact: distance to index (-1, 0))
+ *   sq_weightmap_edt_f32 : out64 (N,H,W) f64 as the reference computes it and / or out32 (N,H,W) f32, the
+ *                          `weights` tensor the loss kernel takes (sq_wsoftmax_ce_fwd_bwd_f32)
+ * ---------------------------------------------------------------------------------------- */
+int64_t sq_weightmap_workspace(int N, int H, int W);
+int sq_edt_sq_f32(const float *img, int32_t *d2, void *workspace, int N, int H, int W, void *stream);
+int sq_weightmap_edt_f32(const float *img, double *out64, float *out32, void *workspace, int N, int H, int W,
+                         double w0, double sigma, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

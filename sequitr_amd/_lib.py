@@ -44,6 +44,10 @@ SIGNATURES = {
     "sq_mask_centroids_workspace": (c_int64, [c_int, c_int, c_int]),
     "sq_mask_centroids_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p]),
+    "sq_weightmap_workspace": (c_int64, [c_int, c_int, c_int]),
+    "sq_edt_sq_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sq_weightmap_edt_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                     ctypes.c_double, ctypes.c_double, c_void_p]),
     "sq_mosaic_pack_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "sq_mosaic_unpack_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "sq_zero_insert2x_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -711,3 +711,41 @@ def convT3x3s2(x, w, bias=None):
     if tuple(w.shape[:2]) != (3, 3) or w.shape[3] != x.shape[3]:
         raise ValueError("convT3x3s2: weight %s does not match %d input channels" % (tuple(w.shape), x.shape[3]))
     return conv2d(zero_insert2x(x), conv_weight_transform(w), bias, act=None)
+
+
+# ----------------------------------------------------------------------------------------------
+# EDT weight maps on the device (include/sequitr_hip.h "EDT weight maps"; pipeline.py:475-479)
+# ----------------------------------------------------------------------------------------------
+def _wm_args(img):
+    _chk(img, "img")
+    if img.dim() == 4 and img.shape[-1] == 1:
+        img = img.reshape(img.shape[:3])
+    if img.dim() != 3:
+        raise ValueError("img must be (N,H,W) or (N,H,W,1), got %s" % (tuple(img.shape),))
+    N, H, W = img.shape
+    lib = _lib.load()
+    nbytes = lib.sq_weightmap_workspace(N, H, W)
+    if nbytes < 0:
+        raise ValueError("weight map batch %s is too large for one call" % (tuple(img.shape),))
+    return img, N, H, W, lib, _workspace(nbytes, img.device)
+
+
+def edt_squared(img):
+    """Exact squared Euclidean distance (int32) of every pixel to the nearest pixel with 1 - img == 0."""
+    img, N, H, W, lib, ws = _wm_args(img)
+    d2 = torch.empty((N, H, W), dtype=torch.int32, device=img.device)
+    _lib.check(lib.sq_edt_sq_f32(_ptr(img), _ptr(d2), _ptr(ws), N, H, W, _stream()), "sq_edt_sq_f32")
+    return d2
+
+
+def weightmap_edt(img, w0=10.0, sigma=5.0, dtype=torch.float32):
+    """ImageWeightMap (pipeline.py:455-479) of a batch of binary label images, on the device.
+    dtype float64 = the reference's own precision; float32 = the loss kernel's `weights` operand."""
+    img, N, H, W, lib, ws = _wm_args(img)
+    out = torch.empty((N, H, W), dtype=dtype, device=img.device)
+    o64, o32 = (_ptr(out), None) if dtype == torch.float64 else (None, _ptr(out))
+    if dtype not in (torch.float64, torch.float32):
+        raise TypeError("weightmap_edt: dtype must be float32 or float64")
+    _lib.check(lib.sq_weightmap_edt_f32(_ptr(img), o64, o32, _ptr(ws), N, H, W, float(w0), float(sigma), _stream()),
+               "sq_weightmap_edt_f32")
+    return out

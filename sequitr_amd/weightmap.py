@@ -76,8 +76,28 @@ def weights_file_name(label_file):
     return re.match('([a-zA-Z0-9()]+)_([a-zA-Z0-9()]+_)*', label_file).group(0) + 'weights.tif'
 
 
-def create_weightmaps(path, folders, w0=10., sigma=3., thresh_fn=lambda x: x > 0, name_weights_folder=True):
-    """ Generate weightmaps for the images using the binary masks; returns the files written. """
+def device_weightmaps(labels, w0=10., sigma=5., device=None):
+    """EDT weight maps (ImageWeightMap, pipeline.py:455-479) of a stack of binary label images computed on
+    the GPU and LEFT THERE as the (N,H,W,1) float32 `weights` tensor the training step takes -- no TIFF
+    round trip.  labels: (N,H,W) array or device tensor, non-zero = cell."""
+    import torch
+    from . import ops
+    if not isinstance(labels, torch.Tensor):
+        dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        labels = torch.from_numpy(np.ascontiguousarray(np.asarray(labels) > 0, dtype=np.float32)).to(dev)
+    else:
+        labels = (labels > 0).to(torch.float32).contiguous()
+    w = ops.weightmap_edt(labels, w0, sigma, dtype=torch.float32)
+    return w.reshape(tuple(w.shape) + (1,))
+
+
+def create_weightmaps(path, folders, w0=10., sigma=3., thresh_fn=lambda x: x > 0, name_weights_folder=True,
+                      method='delaunay'):
+    """ Generate weightmaps for the images using the binary masks; returns the files written.
+    method='delaunay' is the reference's ImageWeightMap2 on the host (weightmap.py:181); method='edt'
+    computes ImageWeightMap on the GPU (sq_weightmap_edt_f32) and writes the same float32 TIFFs. """
+    if method not in ('delaunay', 'edt'):
+        raise ValueError("method must be 'delaunay' or 'edt'")
     w_pipe = ImageWeightMap2(w0=w0, sigma=sigma)
     written = []
     for d in folders:
@@ -87,7 +107,10 @@ def create_weightmaps(path, folders, w0=10., sigma=3., thresh_fn=lambda x: x > 0
         utils.check_and_makedir(w_dir)
         for f in f_labels:
             im_label = ImageLabels(os.path.join(r_dir, 'label', f), thresh_fn=thresh_fn).labels()
-            im_weights = np.squeeze(w_pipe(im_label.astype('bool')))
+            if method == 'edt':
+                im_weights = device_weightmaps(im_label[np.newaxis], w0, sigma).cpu().numpy()[0, ..., 0]
+            else:
+                im_weights = np.squeeze(w_pipe(im_label.astype('bool')))
             out = os.path.join(w_dir, weights_file_name(f))
             imsave(out, im_weights.astype('float32'))
             written.append(out)
