@@ -17,6 +17,33 @@ from . import ops
 # ---------------------------------------------------------------------------------------------
 # convolution: ConvFwd / ConvDgrad / ConvWgrad are each other's derivatives
 # ---------------------------------------------------------------------------------------------
+def grad_sink(param):
+    """Gradient destination a trainer attached to a parameter (``param._sq_grad_sink``: a float32 view of
+    its flat gradient bucket), or None.  Each U-Net parameter feeds exactly one op per step, so that op's
+    gradient kernel writes the view directly and hands autograd ``None`` -- no AccumulateGrad add kernel
+    per parameter, no zeroing dependency.  Only first-order backward passes use it."""
+    return getattr(param, '_sq_grad_sink', None) if param is not None else None
+
+
+def convT_param_grads(dwp, dbp, Cin, Cout, sinks):
+    """(dW (2,2,Cout,Cin), db (Cout)) of the 2x2/s2 transpose conv from the 1x1 wgrad of its
+    space-to-depth form (dwp (1,1,Cin,4Cout), dbp (4Cout) or None); written into the sinks when set."""
+    sw, sb = sinks
+    dw = dwp.reshape(Cin, 2, 2, Cout).permute(1, 2, 3, 0)
+    if sw is not None:
+        sw.copy_(dw)
+        dw = None
+    else:
+        dw = dw.contiguous()
+    db = None
+    if dbp is not None:
+        if sb is not None:
+            torch.sum(dbp.reshape(4, Cout), 0, out=sb)
+        else:
+            db = dbp.reshape(4, Cout).sum(0)
+    return dw, db
+
+
 class _ConvFwd(torch.autograd.Function):
     """y = conv2d(x, w * wscale), no bias, no activation (linear in x and in w)."""
 
@@ -130,6 +157,7 @@ class _Conv2d(torch.autograd.Function):
     def forward(ctx, x, w, bias, act, wscale):
         y = ops.conv2d(x, w, bias, act=act, wscale=wscale)
         ctx.act, ctx.wscale, ctx.has_bias = act, wscale, bias is not None
+        ctx.sinks = (grad_sink(w), grad_sink(bias)) if wscale == 1.0 else (None, None)
         ctx.save_for_backward(x, w, y if ops.ACT[act] else None)
         return y
 
@@ -143,9 +171,17 @@ class _Conv2d(torch.autograd.Function):
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and not torch.is_grad_enabled():
             # first-order fast path: dW and db from ONE pass of the wgrad kernel
-            dw, db = ops.conv_wgrad_raw(x, dpre, w.shape[0], want_bias=need_b)
+            sw, sb = ctx.sinks
+            Cin, Cout = w.shape[2], w.shape[3]
+            if sw is None or (Cout % 4) or not (Cin % 8 == 0 or Cin == 1):   # sinks only on the MFMA wgrad kernels
+                sw = sb = None
+            dw, db = ops.conv_wgrad_raw(x, dpre, w.shape[0], want_bias=need_b, dw_out=sw,
+                                        db_out=sb if need_b else None)
             if ctx.wscale != 1.0:
                 dw = dw * ctx.wscale                     # w' = w * wscale (gan.py:79)
+            if sw is not None:
+                dw = None
+                db = None if sb is not None else db
         else:
             if ctx.needs_input_grad[1]:
                 dw = _ConvWgrad.apply(x, dpre, w.shape[0], ctx.wscale)
@@ -173,13 +209,16 @@ class _Head(torch.autograd.Function):
         y = ops.conv2d(x, w, bias, act=None)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.sinks = (grad_sink(w), grad_sink(bias))
         return y
 
     @staticmethod
     def backward(ctx, dz):
         x, w = ctx.saved_tensors
-        dx, dw, db = ops.conv1x1_small_bwd(x, w, dz.contiguous(), want_dx=ctx.needs_input_grad[0])
-        return dx, dw, (db if ctx.has_bias else None)
+        sw, sb = ctx.sinks
+        dx, dw, db = ops.conv1x1_small_bwd(x, w, dz.contiguous(), want_dx=ctx.needs_input_grad[0], dw_out=sw,
+                                           db_out=sb if ctx.has_bias else None)
+        return dx, (None if sw is not None else dw), (db if ctx.has_bias and sb is None else None)
 
 
 def conv1x1_head(x, w, bias=None):
@@ -361,6 +400,7 @@ class _ConvT(torch.autograd.Function):
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.sinks = (grad_sink(w), grad_sink(bias))
         return ops.convT2x2s2(x, w, bias)
 
     @staticmethod
@@ -375,9 +415,7 @@ class _ConvT(torch.autograd.Function):
             dx = ops.conv2d(g, w.reshape(1, 1, 4 * Cout, Cin), None, act=None)
         if ctx.needs_input_grad[1] or ctx.has_bias:
             dwp, dbp = ops.conv2d_wgrad(x, g, 1, want_bias=ctx.has_bias)  # (1,1,Cin,4Cout), (4Cout)
-            dw = dwp.reshape(Cin, 2, 2, Cout).permute(1, 2, 3, 0).contiguous()
-            if ctx.has_bias:
-                db = dbp.reshape(4, Cout).sum(0)
+            dw, db = convT_param_grads(dwp, dbp if ctx.has_bias else None, Cin, Cout, ctx.sinks)
         return dx, dw, db
 
 

@@ -6,6 +6,8 @@ from torch.autograd.function import once_differentiable
 
 from . import ops
 from . import ops_bf16 as ob
+from .functional import grad_sink, convT_param_grads
+
 
 
 class _Conv2d(torch.autograd.Function):
@@ -14,6 +16,7 @@ class _Conv2d(torch.autograd.Function):
         K, _, Cin, Cout = w.shape
         y = ob.conv2d(x, ob.pack_weights(w), bias, K, Cout, act=act)
         ctx.act, ctx.has_bias = act, bias is not None
+        ctx.sinks = (grad_sink(w), grad_sink(bias))
         ctx.save_for_backward(x, w, y if ops.ACT[act] else None)
         return y
 
@@ -26,9 +29,10 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ob.conv2d(dpre, ob.pack_weights(w, transform=True), None, K, Cin)
+        sw, sb = ctx.sinks
         if ctx.needs_input_grad[1] or ctx.has_bias:
-            dw, db = ob.conv2d_wgrad(x, dpre, K, want_bias=ctx.has_bias)
-        return dx, dw, db, None
+            dw, db = ob.conv2d_wgrad(x, dpre, K, want_bias=ctx.has_bias, dw_out=sw, db_out=sb)
+        return dx, (None if sw is not None else dw), (None if sb is not None else db), None
 
 
 def conv2d(x, w, bias=None, act=None):
@@ -42,6 +46,7 @@ class _ConvFirst(torch.autograd.Function):
     def forward(ctx, x, w, bias, act):
         y = ob.conv3x3_first(x, w, bias, act=act)
         ctx.act = act
+        ctx.sinks = (grad_sink(w), grad_sink(bias))
         ctx.save_for_backward(x, y)
         return y
 
@@ -50,8 +55,9 @@ class _ConvFirst(torch.autograd.Function):
     def backward(ctx, dy):
         x, y = ctx.saved_tensors
         dpre = ob.act_bwd(dy.contiguous(), y, ctx.act)
-        dw, db = ob.conv3x3_first_wgrad(x, dpre)
-        return None, dw, db, None
+        sw, sb = ctx.sinks
+        dw, db = ob.conv3x3_first_wgrad(x, dpre, dw_out=sw, db_out=sb)
+        return None, (None if sw is not None else dw), (None if sb is not None else db), None
 
 
 def conv3x3_first(x, w, bias, act='relu'):
@@ -80,6 +86,7 @@ class _ConvT(torch.autograd.Function):
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.sinks = (grad_sink(w), grad_sink(bias))
         return ob.convT2x2s2(x, ob.to_bf16(w), bias)
 
     @staticmethod
@@ -93,9 +100,7 @@ class _ConvT(torch.autograd.Function):
             wp = ob.pack_weights(w.reshape(1, 1, 4 * Cout, Cin))              # 1x1 conv 4Cout -> Cin
             dx = ob.conv2d(g, wp, None, 1, Cin)
         dwp, dbp = ob.conv2d_wgrad(x, g, 1, want_bias=ctx.has_bias)           # (1,1,Cin,4Cout)
-        dw = dwp.reshape(Cin, 2, 2, Cout).permute(1, 2, 3, 0).contiguous()
-        if ctx.has_bias:
-            db = dbp.reshape(4, Cout).sum(0)
+        dw, db = convT_param_grads(dwp, dbp if ctx.has_bias else None, Cin, Cout, ctx.sinks)
         return dx, dw, db
 
 
@@ -151,14 +156,17 @@ class _Head(torch.autograd.Function):
         logits, _ = ob.head_fwd(x, w, bias, want_mask=False)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.sinks = (grad_sink(w), grad_sink(bias))
         return logits
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dz):
         x, w = ctx.saved_tensors
-        dx, dw, db = ob.head_bwd(x, w, dz.contiguous(), want_dx=ctx.needs_input_grad[0])
-        return dx, dw, (db if ctx.has_bias else None)
+        sw, sb = ctx.sinks
+        dx, dw, db = ob.head_bwd(x, w, dz.contiguous(), want_dx=ctx.needs_input_grad[0], dw_out=sw,
+                                 db_out=sb if ctx.has_bias else None)
+        return dx, (None if sw is not None else dw), (db if ctx.has_bias and sb is None else None)
 
 
 def conv1x1_head(x, w, bias=None):

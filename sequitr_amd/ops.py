@@ -256,8 +256,18 @@ def conv2d_dgrad(dy, w, wscale=1.0):
     return conv2d(dy, conv_weight_transform(w), None, act=None, wscale=wscale)
 
 
-def conv2d_wgrad(x, dy, K, want_bias=True):
-    """(dW (K,K,Cin,Cout), db (Cout) or None) from X (N,H,W,Cin) and dY (N,H,W,Cout)."""
+def _grad_out(buf, shape, device):
+    """A caller-provided gradient destination (e.g. a view of the flat gradient bucket) or a new tensor."""
+    if buf is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if buf.dtype != torch.float32 or not buf.is_contiguous() or buf.numel() != int(torch.Size(shape).numel()):
+        raise ValueError("gradient destination %s does not fit %s" % (tuple(buf.shape), tuple(shape)))
+    return buf
+
+
+def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None):
+    """(dW (K,K,Cin,Cout), db (Cout) or None) from X (N,H,W,Cin) and dY (N,H,W,Cout).  dw_out / db_out:
+    optional float32 destinations the kernel writes straight into."""
     _chk(x, "x", ndim=4), _chk(dy, "dy", ndim=4)
     N, H, W, Cin = x.shape
     Cout = dy.shape[3]
@@ -266,17 +276,18 @@ def conv2d_wgrad(x, dy, K, want_bias=True):
     if USE_MOSAIC and W < 16 and N * H > 1 and Cin % 4 == 0 and Cout % 4 == 0:
         P = N * H * W
         if K == 1 and P % 16 == 0:
-            return conv2d_wgrad(x.view(1, P // 16, 16, Cin), dy.view(1, P // 16, 16, Cout), K, want_bias)
+            return conv2d_wgrad(x.view(1, P // 16, 16, Cin), dy.view(1, P // 16, 16, Cout), K, want_bias,
+                                dw_out, db_out)
         plan = _mosaic_plan(N, H, W) if K == 3 else None
         if plan is not None:                                  # separator cells of dY are zero: they add nothing
-            return conv2d_wgrad(mosaic_pack(x, *plan), mosaic_pack(dy, *plan), K, want_bias)
+            return conv2d_wgrad(mosaic_pack(x, *plan), mosaic_pack(dy, *plan), K, want_bias, dw_out, db_out)
     lib = _lib.load()
     nbytes = lib.sq_conv2d_nhwc_wgrad_workspace_f32(N, H, W, Cin, Cout, K)
     if nbytes < 0:
         raise _lib.SequitrHipError("conv2d_wgrad: unsupported shape Cin=%d Cout=%d K=%d" % (Cin, Cout, K))
     ws = _workspace(nbytes, x.device)
-    dw = torch.empty((K, K, Cin, Cout), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    dw = _grad_out(dw_out, (K, K, Cin, Cout), x.device)
+    db = _grad_out(db_out, (Cout,), x.device) if want_bias else None
     _lib.check(lib.sq_conv2d_nhwc_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout,
                                            K, _stream()), "sq_conv2d_nhwc_wgrad_f32")
     return dw, db
@@ -342,7 +353,7 @@ def space_to_depth2(dy):
     return g
 
 
-def conv1x1_small_bwd(x, w, dz, want_dx=True):
+def conv1x1_small_bwd(x, w, dz, want_dx=True, dw_out=None, db_out=None):
     """Backward of the to_image head: returns (dx or None, dw (1,1,Cin,Cout), db (Cout))."""
     _chk(x, "x", ndim=4), _chk(w, "w", ndim=4), _chk(dz, "dz", ndim=4)
     N, H, W, Cin = x.shape
@@ -351,8 +362,8 @@ def conv1x1_small_bwd(x, w, dz, want_dx=True):
     lib = _lib.load()
     ws = _workspace(lib.sq_conv1x1_small_bwd_workspace_f32(npix, Cin, Cout), x.device)
     dx = torch.empty_like(x) if want_dx else None
-    dw = torch.empty((1, 1, Cin, Cout), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    dw = _grad_out(dw_out, (1, 1, Cin, Cout), x.device)
+    db = _grad_out(db_out, (Cout,), x.device)
     _lib.check(lib.sq_conv1x1_small_bwd_f32(_ptr(x), _ptr(w), _ptr(dz), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws),
                                            npix, Cin, Cout, _stream()), "sq_conv1x1_small_bwd_f32")
     return dx, dw, db
@@ -531,13 +542,15 @@ def conv_dgrad_raw(dy, w, wscale=1.0):
     return conv2d(dy, conv_weight_transform(w), None, act=None, wscale=wscale)
 
 
-def conv_wgrad_raw(x, dy, K, want_bias=False):
+def conv_wgrad_raw(x, dy, K, want_bias=False, dw_out=None, db_out=None):
     """(dW (K,K,Cin,Cout), db or None) for every channel mix the GAN / U-Net graphs use."""
     Cin, Cout = x.shape[-1], dy.shape[-1]
     N, H, W = x.shape[0], x.shape[1], x.shape[2]
     lib = _lib.load()
     if Cout % 4 == 0 and lib.sq_conv2d_nhwc_wgrad_workspace_f32(N, H, W, Cin, Cout, K) >= 0:
-        return conv2d_wgrad(x, dy, K, want_bias=want_bias)
+        return conv2d_wgrad(x, dy, K, want_bias=want_bias, dw_out=dw_out, db_out=db_out)
+    if dw_out is not None or db_out is not None:
+        raise _lib.SequitrHipError("conv wgrad: gradient destinations need the MFMA kernel (Cin=%d Cout=%d)" % (Cin, Cout))
     npix = N * H * W
     if K == 1 and Cin <= 4 and Cout % 4 == 0:                      # from_image: image side is the input
         dw = wgrad1x1_small(x, dy).view(1, 1, Cin, Cout)

@@ -3,7 +3,7 @@ weights / biases / accumulation; every op is a hand-written HIP kernel of libseq
 import torch
 
 from . import _lib
-from .ops import ACT, BRIDGE, _ptr, _stream, _workspace  # noqa: F401
+from .ops import ACT, BRIDGE, _ptr, _stream, _workspace, _grad_out  # noqa: F401
 
 BF16 = torch.bfloat16
 
@@ -61,7 +61,7 @@ def conv3x3_first(x, w, bias, act="relu"):
     return y
 
 
-def conv2d_wgrad(x, dy, K, want_bias=True):
+def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None):
     """(dW (K,K,Cin,Cout) f32, db f32 or None) from bf16 X and bf16 dY."""
     _chk(x, "x", ndim=4), _chk(dy, "dy", ndim=4)
     N, H, W, Cin = x.shape
@@ -71,8 +71,8 @@ def conv2d_wgrad(x, dy, K, want_bias=True):
     if nbytes < 0:
         raise _lib.SequitrHipError("conv2d_wgrad(bf16): unsupported Cin=%d Cout=%d K=%d" % (Cin, Cout, K))
     ws = _workspace(nbytes, x.device)
-    dw = torch.empty((K, K, Cin, Cout), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    dw = _grad_out(dw_out, (K, K, Cin, Cout), x.device)
+    db = _grad_out(db_out, (Cout,), x.device) if want_bias else None
     _lib.check(lib.sq_conv2d_nhwc_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout, K,
                                             _stream()), "sq_conv2d_nhwc_wgrad_bf16")
     return dw, db
@@ -197,7 +197,7 @@ def head_fwd(x, w, bias, want_mask=True):
     return logits, mask
 
 
-def head_bwd(x, w, dz, want_dx=True):
+def head_bwd(x, w, dz, want_dx=True, dw_out=None, db_out=None):
     _chk(x, "x", ndim=4), _chk(dz, "dz", dtype=torch.float32)
     N, H, W, Cin = x.shape
     Cout = w.shape[3]
@@ -205,22 +205,22 @@ def head_bwd(x, w, dz, want_dx=True):
     lib = _lib.load()
     ws = _workspace(lib.sq_conv1x1_head_bwd_workspace_bf16(npix, Cin, Cout), x.device)
     dx = torch.empty_like(x) if want_dx else None
-    dw = torch.empty((1, 1, Cin, Cout), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    dw = _grad_out(dw_out, (1, 1, Cin, Cout), x.device)
+    db = _grad_out(db_out, (Cout,), x.device)
     _lib.check(lib.sq_conv1x1_head_bwd_bf16(_ptr(x), _ptr(w), _ptr(dz), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), npix, Cin,
                                            Cout, _stream()), "sq_conv1x1_head_bwd_bf16")
     return dx, dw, db
 
 
-def conv3x3_first_wgrad(x, dy):
+def conv3x3_first_wgrad(x, dy, dw_out=None, db_out=None):
     """x f32 (N,H,W,1), dy bf16 (N,H,W,Cout) -> (dW (3,3,1,Cout) f32, db f32)."""
     _chk(x, "x", dtype=torch.float32, ndim=4), _chk(dy, "dy", ndim=4)
     N, H, W, _ = x.shape
     Cout = dy.shape[3]
     lib = _lib.load()
     ws = _workspace(lib.sq_conv3x3_first_wgrad_workspace_bf16(N, H, W, Cout), x.device)
-    dw = torch.empty((3, 3, 1, Cout), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    dw = _grad_out(dw_out, (3, 3, 1, Cout), x.device)
+    db = _grad_out(db_out, (Cout,), x.device)
     _lib.check(lib.sq_conv3x3_first_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cout, _stream()),
                "sq_conv3x3_first_wgrad_bf16")
     return dw, db

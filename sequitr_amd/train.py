@@ -17,7 +17,7 @@ from .parallel import FlatBucket, allreduce_sum_
 
 class UNetTrainer(object):
     def __init__(self, params, learning_rate=0.01, beta1=0.9, beta2=0.999, epsilon=1e-8, group=None,
-                 net_cls=None):
+                 net_cls=None, direct_grads=True):
         # params['dtype'] == 'bf16': bf16 activations + bf16 MFMA, fp32 master weights / Adam (configs 3-4)
         if net_cls is None:
             net_cls = UNet2DBf16 if str(params.get('dtype', 'f32')).lower() in ('bf16', 'bfloat16') else UNet2D
@@ -37,6 +37,8 @@ class UNetTrainer(object):
             view.copy_(self.net._vars[name])
             leaf = view.detach().requires_grad_(True)           # shares the flat storage
             leaf.grad = self.gbucket.view(name)                 # autograd accumulates in place
+            if direct_grads:
+                leaf._sq_grad_sink = leaf.grad                  # ... or the gradient kernel writes it directly
             self.net._vars[name] = leaf
         self.last_loss = None
         # Adam's step counter lives on the device ({step, lr_t bits}) so a captured step replays correctly;

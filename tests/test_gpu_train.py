@@ -246,3 +246,21 @@ def test_adam_dev_matches_host_step():
         ops.adam_step(pa, dev(g), ma, va, 0.01, 0.9, 0.999, 1e-8, t, grad_scale=0.5)
         ops.adam_step_dev(pb, dev(g), mb, vb, 0.01, 0.9, 0.999, 1e-8, st, grad_scale=0.5)
     assert int(st[0].item()) == 5 and torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_direct_gradient_sinks_equal_autograd_accumulation(dtype):
+    """UNetTrainer(direct_grads=True): the gradient kernels write the flat bucket themselves (no
+    AccumulateGrad add per parameter); same gradients as the accumulate path, bit for bit."""
+    params = {"shape": (64, 64), "dropout": 0.4, "device": "cuda:0", "seed": 2, "filters": (16, 32, 64),
+              "dtype": dtype}
+    x, onehot, wmap = _batch(3, 2, 64)
+    a, b = UNetTrainer(params, direct_grads=True), UNetTrainer(params, direct_grads=False)
+    assert all(getattr(v, "_sq_grad_sink", None) is not None for k, v in a.net._vars.items() if k in a.pbucket.shapes)
+    la = a.forward_backward(dev(x), dev(onehot), dev(wmap))
+    a_first = a.grads()
+    lb = b.forward_backward(dev(x), dev(onehot), dev(wmap))
+    assert la.item() == lb.item()
+    gb = b.grads()
+    for k in gb:
+        assert np.array_equal(a_first[k], gb[k]), k
