@@ -338,6 +338,59 @@ def main_weightmap(args):
     print(json.dumps(res))
 
 
+def main_frontend(args):
+    """8 raw uint16 camera frames of 1200x1600 -> ImageNorm -> 512x512 tiles (margin 32) on the
+    GPU, and the streamed end-to-end path (host frames -> masks on the host) through the default U-Net."""
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from sequitr_amd.frontend import FrameTiler, segment_frames
+    from sequitr_amd.networks.unet import UNet2D
+    F, H, W = 8, 1200, 1600
+    fr = np.random.default_rng(4).integers(200, 4000, (F, H, W)).astype(np.uint16)
+    fd = torch.from_numpy(fr).to(dev)
+    tl = FrameTiler((H, W), TILE, 32, device=dev)
+    for _ in range(args.warmup):
+        tiles = tl.tiles(fd)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(args.steps):
+        tiles = tl.tiles(fd)
+    e.record()
+    torch.cuda.synchronize()
+    kms = s.elapsed_time(e) / args.steps
+    npx = F * H * W
+    alg = npx * 2 * 3 + tiles.numel() * 4                    # frame read by 3 passes (u16), tiles written once (f32)
+    net = UNet2D({"shape": (TILE, TILE), "filters": FILTERS, "device": str(dev)}, "infer").initialize()
+    segment_frames(net, fr[:4], tile=TILE, margin=32, frames_per_batch=2)
+    reps = 4
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        masks = segment_frames(net, fr, tile=TILE, margin=32, frames_per_batch=2)
+    dt = (time.perf_counter() - t0) / reps
+    res = {"metric": "frames -> normalised tiles Mpixels/sec (1200x1600 uint16 frames, 512x512 tiles)",
+           "value": round(npx / (kms * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(kms, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u16/f32", "data": "synthetic",
+           "config": {"workload": "ImageNorm + tiling of 8 x 1200x1600 uint16 frames into %d tiles of 512x512" % tiles.shape[0],
+                      "tiles_per_frame": tl.tiles_per_frame},
+           "roofline": {"bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(alg / (kms * 1e-3) / 8e12, 4), "traffic": None},
+           "end_to_end": {"value": round(npx / dt / 1e6, 2), "unit": "Mpixels/s (frame pixels)",
+                          "what": "host uint16 frames -> pinned -> H2D -> norm/tile -> U-Net -> stitch -> host masks, "
+                                  "2 frames (24 tiles) per batch, uploads overlapped", "seconds": round(dt, 4),
+                          "mask_shape": list(masks.shape)}}
+    if not args.no_cpu_baseline:
+        from oracle import frontend_ref
+        t0 = time.perf_counter()
+        ref = frontend_ref.tiles(fr[:2], tl.oy, tl.ox, TILE)
+        ct = time.perf_counter() - t0
+        same = np.array_equal(tiles[:2 * tl.tiles_per_frame].cpu().numpy(), ref)
+        res["cpu_baseline"] = {"value": round(2 * H * W / ct / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                               "sample": "numpy ImageNorm + slicing (oracle/frontend_ref.py) on 2 of the 8 frames",
+                               "tiles_identical": bool(same)}
+    print(json.dumps(res))
+
+
 def main_gan(args):
     """BASELINE configs[4]: progressive WGAN-GP at level 6 (256x256x2), batch 32 per GPU, alpha = 1;
     one iteration = one d_solver + one g_solver (sequitr/networks/gan.py:850-851)."""
@@ -408,7 +461,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="training dtype (--mode train)")
     ap.add_argument("--graph", type=int, default=1, help="--mode train: replay the step as hipGraphs (1) or eager (0)")
     ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
-    ap.add_argument("--mode", choices=["infer", "train", "gan", "centroids", "weightmap"], default="infer",
+    ap.add_argument("--mode", choices=["infer", "train", "gan", "centroids", "weightmap", "frontend"], default="infer",
                     help="infer = the headline metric (BASELINE configs[1]); train = configs[2]/[3] "
                          "(U-Net training step, batch 16 per GPU) for DESIGN.md, not the driver's line")
     args = ap.parse_args()
@@ -420,6 +473,8 @@ def main():
         return main_centroids(args)
     if args.mode == "weightmap":
         return main_weightmap(args)
+    if args.mode == "frontend":
+        return main_frontend(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

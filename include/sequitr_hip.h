@@ -373,6 +373,28 @@ int sq_edt_sq_f32(const float *img, int32_t *d2, void *workspace, int N, int H, 
 int sq_weightmap_edt_f32(const float *img, double *out64, float *out32, void *workspace, int N, int H, int W,
                          double w0, double sigma, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Tile front end: raw single-channel camera frames in HBM (OctopusData .dat memmap,
+ * sequitr/dataio/octopus.py:231-245) -> ImageNorm (sequitr/pipeline.py:350-356) -> network tiles, and the
+ * tile masks back to full-frame masks.
+ *   sq_frame_stats     : per-frame float32 mean and std EXACTLY as numpy's np.mean / np.std of the float32
+ *                        frame (8192-element chunks, pairwise blocks of 128 with 8 accumulators); H*W <= 2^24.
+ *                        workspace: sq_frame_stats_workspace bytes.
+ *   sq_frames_to_tiles : tiles (F*TR*TC, TS, TS) f32, tile (f,ty,tx) = frame f at origin (oy[ty], ox[tx]),
+ *                        value (x - mean[f]) / std[f], or the plain cast when mean == std == NULL.
+ *   sq_stitch_masks_u8 : out (F,H,W): pixel (y,x) = tile_masks[(f, ymap[y]>>16, xmap[x]>>16)][ymap[y]&0xffff][xmap[x]&0xffff]
+ * ---------------------------------------------------------------------------------------- */
+#define SQ_PIX_U8 0
+#define SQ_PIX_U16 1
+#define SQ_PIX_F32 2
+int64_t sq_frame_stats_workspace(int F, int H, int W);
+int sq_frame_stats(const void *frames, int dtype, float *mean, float *stdv, void *workspace, int F, int H, int W,
+                   void *stream);
+int sq_frames_to_tiles(const void *frames, int dtype, const float *mean, const float *stdv, const int32_t *oy,
+                       const int32_t *ox, float *tiles, int F, int H, int W, int TR, int TC, int TS, void *stream);
+int sq_stitch_masks_u8(const uint8_t *tile_masks, const int32_t *ymap, const int32_t *xmap, uint8_t *out, int F, int H,
+                       int W, int TR, int TC, int TS, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

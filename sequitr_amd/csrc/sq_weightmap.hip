@@ -15,6 +15,9 @@
 // Integer / streaming work: 4 B/pixel in, 2 B/pixel of g written and re-read, 8 (+4) B/pixel out.
 #include "sq_common.h"
 
+// every multiply and add below is a separate, correctly rounded operation as in numpy: no fused contraction
+#pragma clang fp contract(off)
+
 namespace {
 
 typedef unsigned long long u64;

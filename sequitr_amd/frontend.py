@@ -1,0 +1,196 @@
+"""Tile front end: raw camera frames -> ImageNorm -> network tiles on the GPU, and
+tile masks -> full-frame masks.  The reference feeds its networks fixed-size float32 tiles that went through
+ImagePipeline([ImageNorm()]) on the host (sequitr/pipeline.py:338-356, 62-78); here the raw uint8/uint16
+frames cross PCIe (1-2 B/pixel instead of 4), and normalisation, tiling and stitching are HIP kernels
+(include/sequitr_hip.h "Tile front end").  ImageNorm is bit-exact with numpy (the kernel follows numpy's
+float32 summation order).
+
+Tiling (build-defined: the reference only ever crops fixed-size tiles, pipeline.py:429-441): along an axis of
+length L, tiles of size T start at 0, T-2m, 2(T-2m), ... and the last one at L-T; every pixel is owned by the
+tile in which it lies at least `m` (margin) pixels from the tile border, except at the frame border.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+PIX = {torch.uint8: 0, torch.uint16: 1, torch.float32: 2}
+NP_TORCH = {np.dtype('uint8'): torch.uint8, np.dtype('uint16'): torch.uint16, np.dtype('float32'): torch.float32}
+
+
+def axis_tiles(L, T, margin):
+    """(origins, owner map) along one axis: owner[p] = (tile index << 16) | local coordinate."""
+    if T > L:
+        raise ValueError('tile %d does not fit an axis of %d pixels' % (T, L))
+    if not 0 <= 2 * margin < T:
+        raise ValueError('margin %d too large for tile %d' % (margin, T))
+    stride = T - 2 * margin
+    origins = [0]
+    while origins[-1] + T < L:
+        origins.append(min(origins[-1] + stride, L - T))
+    origins = np.asarray(origins, np.int32)
+    starts = origins + margin                                   # first pixel each tile owns
+    starts[0] = 0
+    owner = np.searchsorted(starts, np.arange(L), side='right') - 1
+    local = np.arange(L) - origins[owner]
+    return origins, ((owner.astype(np.int64) << 16) | local).astype(np.int32)
+
+
+class FrameTiler(object):
+    """Geometry + device kernels for frames of one (H, W) shape."""
+
+    def __init__(self, frame_shape, tile=512, margin=32, device=None):
+        self.H, self.W = int(frame_shape[0]), int(frame_shape[1])
+        self.T, self.margin = int(tile), int(margin)
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        if self.device.type != 'cuda':
+            raise _lib.SequitrHipError('FrameTiler runs on the HIP back end only')
+        self.oy, self.ymap = axis_tiles(self.H, self.T, self.margin)
+        self.ox, self.xmap = axis_tiles(self.W, self.T, self.margin)
+        self.TR, self.TC = len(self.oy), len(self.ox)
+        d = self.device
+        self._oy, self._ox = torch.from_numpy(self.oy).to(d), torch.from_numpy(self.ox).to(d)
+        self._ymap, self._xmap = torch.from_numpy(self.ymap).to(d), torch.from_numpy(self.xmap).to(d)
+
+    @property
+    def tiles_per_frame(self):
+        return self.TR * self.TC
+
+    def _check_frames(self, frames):
+        if not isinstance(frames, torch.Tensor) or not frames.is_cuda:
+            raise _lib.SequitrHipError('frames must be a tensor in GPU memory (no CPU fallback exists)')
+        if frames.dtype not in PIX or frames.dim() != 3 or not frames.is_contiguous():
+            raise ValueError('frames must be a contiguous (F,H,W) uint8 / uint16 / float32 tensor')
+        if tuple(frames.shape[1:]) != (self.H, self.W):
+            raise ValueError('frames are %s, tiler was built for %s' % (tuple(frames.shape[1:]), (self.H, self.W)))
+
+    def stats(self, frames):
+        """per-frame float32 (mean, std) exactly as np.mean / np.std of the float32 frame."""
+        self._check_frames(frames)
+        F = frames.shape[0]
+        lib = _lib.load()
+        nbytes = lib.sq_frame_stats_workspace(F, self.H, self.W)
+        if nbytes < 0:
+            raise ValueError('frames of %d x %d pixels exceed 2^24 pixels' % (self.H, self.W))
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+        mean = torch.empty(F, dtype=torch.float32, device=self.device)
+        std = torch.empty(F, dtype=torch.float32, device=self.device)
+        _lib.check(lib.sq_frame_stats(frames.data_ptr(), PIX[frames.dtype], mean.data_ptr(), std.data_ptr(), ws.data_ptr(),
+                                      F, self.H, self.W, torch.cuda.current_stream().cuda_stream), 'sq_frame_stats')
+        return mean, std
+
+    def tiles(self, frames, normalise=True):
+        """(F*TR*TC, T, T, 1) float32 tiles, ImageNorm applied per frame when `normalise`."""
+        self._check_frames(frames)
+        F = frames.shape[0]
+        mean, std = self.stats(frames) if normalise else (None, None)
+        out = torch.empty((F * self.TR * self.TC, self.T, self.T, 1), dtype=torch.float32, device=self.device)
+        lib = _lib.load()
+        _lib.check(lib.sq_frames_to_tiles(frames.data_ptr(), PIX[frames.dtype],
+                                          mean.data_ptr() if normalise else None, std.data_ptr() if normalise else None,
+                                          self._oy.data_ptr(), self._ox.data_ptr(), out.data_ptr(), F, self.H, self.W,
+                                          self.TR, self.TC, self.T, torch.cuda.current_stream().cuda_stream),
+                   'sq_frames_to_tiles')
+        return out
+
+    def stitch(self, tile_masks):
+        """(F*TR*TC, T, T) uint8 tile masks -> (F, H, W) uint8 frame masks."""
+        if tile_masks.dtype != torch.uint8 or not tile_masks.is_cuda or not tile_masks.is_contiguous():
+            raise ValueError('tile_masks must be a contiguous uint8 tensor in GPU memory')
+        n = tile_masks.shape[0]
+        if n % self.tiles_per_frame or tuple(tile_masks.shape[1:3]) != (self.T, self.T):
+            raise ValueError('tile_masks %s do not match %d tiles of %d per frame' % (tuple(tile_masks.shape), n, self.T))
+        F = n // self.tiles_per_frame
+        out = torch.empty((F, self.H, self.W), dtype=torch.uint8, device=self.device)
+        lib = _lib.load()
+        _lib.check(lib.sq_stitch_masks_u8(tile_masks.data_ptr(), self._ymap.data_ptr(), self._xmap.data_ptr(),
+                                          out.data_ptr(), F, self.H, self.W, self.TR, self.TC, self.T,
+                                          torch.cuda.current_stream().cuda_stream), 'sq_stitch_masks_u8')
+        return out
+
+
+_PINNED = {}
+
+
+def _pinned(tag, shape, dtype):
+    """pinned staging buffers are expensive to create (hipHostMalloc): keep them between calls"""
+    key = (tag, tuple(shape), dtype)
+    buf = _PINNED.get(key)
+    if buf is None:
+        buf = _PINNED[key] = torch.empty(shape, dtype=dtype).pin_memory()
+    return buf
+
+
+def segment_frames(net, frames, tile=512, margin=32, frames_per_batch=4, normalise=True, on_masks=None):
+    """Segment a stack of raw frames (numpy array / memmap / OctopusData, (F,H,W) uint8|uint16|float32).
+    Raw frames are staged through two pinned buffers and uploaded on a side stream while the previous batch is
+    normalised, tiled, segmented (net.predict) and stitched; returns the (F,H,W) uint8 masks (host), or
+    streams each batch's device masks to on_masks(first_frame, masks) and returns None."""
+    from .dataio.octopus import OctopusData
+    if isinstance(frames, OctopusData):
+        get = frames.block
+        F, (H, W) = len(frames), frames.framesize
+        np_dtype = np.dtype('uint' + str(frames.bit_depth))
+    else:
+        arr = frames
+        F, H, W = arr.shape
+        np_dtype = np.dtype(arr.dtype)
+        get = lambda first, count: arr[first:first + count]
+    if np_dtype not in NP_TORCH:
+        raise TypeError('frames must be uint8, uint16 or float32, got %s' % np_dtype)
+    tdt = NP_TORCH[np_dtype]
+    tiler = FrameTiler((H, W), tile, margin, device=net.device)
+    dev = tiler.device
+    B = int(frames_per_batch)
+    pinned = [_pinned('in%d' % i, (B, H, W), tdt) for i in range(2)]
+    staged = [torch.empty((B, H, W), dtype=tdt, device=dev) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    ready = [torch.cuda.Event(), torch.cuda.Event()]            # upload of buffer i finished
+    freed = [torch.cuda.Event(), torch.cuda.Event()]            # compute no longer reads staged[i]
+    out = None if on_masks is not None else np.empty((F, H, W), np.uint8)
+
+    def upload(k, first):
+        n = min(B, F - first)
+        ready[k].synchronize()                                 # the previous upload out of this pinned buffer is done
+        pinned[k][:n].numpy()[...] = get(first, n)             # page cache / memmap -> pinned
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(freed[k])
+            staged[k][:n].copy_(pinned[k][:n], non_blocking=True)
+            ready[k].record(copy_stream)
+        return n
+
+    for e in freed + ready:
+        e.record(torch.cuda.current_stream(dev))
+    nb = (F + B - 1) // B
+    counts = {0: upload(0, 0)} if F else {}
+    host_masks = [_pinned('out%d' % i, (B, H, W), torch.uint8) for i in range(2)] if out is not None else None
+    done = [torch.cuda.Event(), torch.cuda.Event()]             # masks of batch parity k are in host_masks[k]
+    pending = None                                              # (batch index, n) whose masks are still in flight
+
+    def drain(p):
+        pb, pn = p
+        done[pb & 1].synchronize()
+        out[pb * B:pb * B + pn] = host_masks[pb & 1][:pn].numpy()
+
+    for b in range(nb):
+        k = b & 1
+        if b + 1 < nb:
+            counts[b + 1] = upload(1 - k, (b + 1) * B)         # overlaps with this batch's kernels
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(ready[k])
+        n = counts[b]
+        tiles = tiler.tiles(staged[k][:n], normalise=normalise)
+        freed[k].record(cur)
+        masks = tiler.stitch(net.predict(tiles))
+        if on_masks is not None:
+            on_masks(b * B, masks)
+            continue
+        host_masks[k][:n].copy_(masks, non_blocking=True)      # D2H queued behind this batch's kernels
+        done[k].record(cur)
+        if pending is not None:
+            drain(pending)                                      # the previous batch's masks, while this one runs
+        pending = (b, n)
+    if pending is not None:
+        drain(pending)
+    torch.cuda.synchronize(dev)
+    return out

@@ -144,6 +144,75 @@ def SERVER_segment(params, options):
     return info
 
 
+def SERVER_segment_frames(params, options):
+    """Segment whole camera frames (larger than the network tile): params['input'] = an Octopus stream stem
+    (sequitr/dataio/octopus.py), a .npy of (F,H,W) uint8/uint16/float32 frames, or an ndarray.  Raw frames
+    cross PCIe; ImageNorm, tiling, the U-Net and stitching run on the GPU (sequitr_amd/frontend.py).  Writes
+    ``mask.npy`` (F,H,W) uint8, ``segment.json`` and, with options['centroids'], the centroid file.
+    params: shape (tile, default (512,512)), margin, frames_per_batch, model / filters / ... as SERVER_segment."""
+    import torch
+    from .networks.unet import UNet2D
+    from . import utils
+    from .frontend import segment_frames
+    from .dataio import OctopusData
+
+    device = _resolve_device(params, options)
+    out_dir = params['output']
+    src = params.get('input')
+    if isinstance(src, str) and not src.endswith('.npy'):
+        frames = OctopusData(src, timeout=params.get('timeout', 60))
+        F, (H, W) = len(frames), frames.framesize
+    else:
+        frames = np.load(src, mmap_mode='r', allow_pickle=False) if isinstance(src, str) else np.asarray(src)
+        F, H, W = frames.shape
+    net_p = _net_params(params, device)
+    net_p.setdefault('shape', (512, 512))
+    tile = int(net_p['shape'][0])
+    net = UNet2D(net_p, 'infer')
+    model = params.get('model')
+    if model:
+        model_dir = model if os.path.isdir(model) else utils.get_latest_model_dir(
+            os.path.join(utils.core.TensorflowConfiguration.MODELDIR, model))
+        if model_dir is None:
+            raise IOError('No saved model found for {0}'.format(model))
+        net.load_state_dict(utils.load_model_weights(model_dir))
+    else:
+        net.initialize()
+    masks = np.empty((F, H, W), np.uint8)
+    per_frame = {}
+
+    def sink(first, m):
+        masks[first:first + m.shape[0]] = m.cpu().numpy()
+        if options.get('centroids'):
+            from .centroids import mask_centroids
+            for k, coords in enumerate(mask_centroids(m)):
+                coords[:, 0] = first + k
+                per_frame[first + k] = coords
+
+    t0 = time.time()
+    segment_frames(net, frames, tile=tile, margin=int(params.get('margin', 32)),
+                   frames_per_batch=int(params.get('frames_per_batch', 4)), on_masks=sink)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    np.save(os.path.join(out_dir, 'mask.npy'), masks)
+    info = {'frames': int(F), 'shape': [int(H), int(W)], 'tile': tile, 'seconds': dt,
+            'mpixels_per_s': float(F * H * W / max(dt, 1e-9) / 1e6), 'device': device}
+    if options.get('centroids'):
+        from .centroids import CentroidWriter
+        with CentroidWriter(os.path.join(out_dir, 'tracks.hdf5')) as cw:
+            for k in sorted(per_frame):
+                if cw._hdf is not None:
+                    cw._hdf['frames'].create_group('frame_' + str(k)).create_dataset('coords', data=per_frame[k],
+                                                                                      dtype='float32')
+                else:
+                    cw._frames['frames/frame_' + str(k) + '/coords'] = per_frame[k]
+        info['centroids'] = {'file': os.path.basename(cw.filename), 'objects': int(sum(len(v) for v in per_frame.values()))}
+    with open(os.path.join(out_dir, 'segment.json'), 'w') as f:
+        json.dump(info, f, indent=2)
+    logger.info('Segmented {frames} frames in {seconds:.3f}s on {device}'.format(**info))
+    return info
+
+
 def SERVER_test(params, options):
     """Plumbing check (the reference's commented-out SERVER_test, worker.py:300-302):
     writes the params it was called with into the output folder."""

@@ -108,3 +108,27 @@ def test_segment_job_writes_centroids(tmp_path):
         z = np.load(fn)
         for i, r in enumerate(ref):
             assert np.array_equal(z["frames/frame_%d/coords" % i], r), i
+
+
+def test_segment_frames_job_from_an_octopus_stream(tmp_path):
+    """Whole frames from an Octopus .dat/.dth stream -> GPU front end -> U-Net -> stitched masks + centroids."""
+    from tests.test_frontend_cpu import write_stream
+    from oracle import frontend_ref
+    from sequitr_amd.frontend import axis_tiles
+    ref_frames = write_stream(str(tmp_path), "BF_pos0_", [(0, 2), (1, 1)], 96, 160, bits=16, seed=5)
+    params = {"input": os.path.join(str(tmp_path), "BF_pos0_"), "shape": (64, 64), "filters": (16, 32), "seed": 2,
+              "margin": 8, "frames_per_batch": 2, "timeout": -1}
+    fn = write_job(tmp_path, func="SERVER_segment_frames", params=repr(params), options="{'gpu': 0, 'centroids': True}")
+    out = str(tmp_path / "out")
+    worker.worker(argparse.Namespace(job=fn, out=out))
+    logs = open(os.path.join(out, [f for f in os.listdir(out) if f.startswith("LOG_")][0])).read()
+    assert "exception" not in logs, logs
+    mask = np.load(os.path.join(out, "mask.npy"))
+    oy, ymap = axis_tiles(96, 64, 8)
+    ox, xmap = axis_tiles(160, 64, 8)
+    tiles = frontend_ref.tiles(ref_frames, oy, ox, 64)
+    p = {"shape": (64, 64), "filters": (16, 32)}
+    rm = unet_oracle.predict_mask(unet_oracle.unet_forward(tiles, init_unet_weights(p, 2), p))
+    assert np.array_equal(mask, frontend_ref.stitch(rm, oy, ox, ymap, xmap, 96, 160))
+    info = json.load(open(os.path.join(out, "segment.json")))
+    assert info["frames"] == 3 and "centroids" in info
