@@ -11,9 +11,9 @@ from sequitr_amd import core, serverlogs, utils, worker
 
 JOB = """[job]
 complete = False
-ID = 467e3c034f84acbf3d5d955e93358043
+ID = {ID}
 user = Alan
-priority = 99
+priority = {priority}
 time = (2018-09-28)_10-59-02
 module = {module}
 func = {func}
@@ -24,10 +24,11 @@ options = {options}
 
 
 def write_job(tmp_path, name="JOB_a.job", module="sequitr_amd.jobs", func="SERVER_test", device="GPU",
-              params="{'test': 'x'}", options="{'option': True}"):
+              params="{'test': 'x'}", options="{'option': True}", ID="467e3c034f84acbf3d5d955e93358043", priority=99):
     fn = str(tmp_path / name)
     with open(fn, "w") as f:
-        f.write(JOB.format(module=module, func=func, device=device, params=params, options=options))
+        f.write(JOB.format(module=module, func=func, device=device, params=params, options=options, ID=ID,
+                           priority=priority))
     return fn
 
 

@@ -1,0 +1,39 @@
+"""CPU: the minimal job server (README.md:42-81 of the reference; sequitr_amd/server.py): setup config
+round trip, priority order, worker cap, GPU hand-out and the .job -> .job.complete rename, using the
+GPU-free SERVER_test job."""
+import json
+import os
+
+from sequitr_amd import core, server
+from tests.test_jobs_config import write_job
+
+
+def test_setup_writes_a_config_core_reads_back(tmp_path):
+    fn = server.setup(str(tmp_path / "server.config"), jobdir="/jobs", logdir="/logs", outdir="/out", modeldir="/models")
+    saved = {k: getattr(core.ServerConfiguration, k) for k in ("JOBDIR", "OUTDIR", "LOGDIR", "MAX_PROCESSES", "DEFAULT_GPUS")}
+    try:
+        assert core._configure(fn) == core.ServerConfiguration.VERSION
+        assert core.ServerConfiguration.JOBDIR == "/jobs" and core.ServerConfiguration.OUTDIR == "/out"
+        assert core.TensorflowConfiguration.MODELDIR == "/models"
+        assert isinstance(core.ServerConfiguration.DEFAULT_GPUS, list) and core.ServerConfiguration.MAX_PROCESSES >= 1
+    finally:
+        for k, v in saved.items():
+            setattr(core.ServerConfiguration, k, v)
+
+
+def test_server_runs_jobs_by_priority_and_marks_them_complete(tmp_path):
+    jobs, out = tmp_path / "jobs", tmp_path / "out"
+    jobs.mkdir(), out.mkdir()
+    for i, prio in enumerate((10, 99, 50)):
+        write_job(jobs, func="SERVER_test", params=repr({"tag": i}), options="{}", ID="job%d" % i, priority=prio,
+                  name="JOB_%d.job" % i)
+    srv = server.Server(str(jobs), str(out), gpus=[0, 1], max_processes=2, delay=0.05)
+    assert [j.ID for j in srv.pending()] == ["job1", "job2", "job0"]
+    assert srv.poll_once() == 2                                            # worker cap
+    assert sorted(g for _, g, _ in srv.running.values()) == [0, 1]         # one GPU each, least loaded first
+    done = srv.serve(once=True)
+    assert sorted(d[0] for d in done) == ["job0", "job1", "job2"] and all(rc == 0 for _, rc in done)
+    assert sorted(os.listdir(str(jobs))) == ["JOB_%d.job.complete" % i for i in range(3)]
+    for i in range(3):
+        t = json.load(open(os.path.join(str(out), "JOB_job%d" % i, "test.json")))
+        assert "tag" in t["params"]
