@@ -318,6 +318,14 @@ int sq_cast_bf16_to_f32(const void *x, float *y, int64_t n, void *stream);
 int sq_maxpool2x2_fwd_bf16(const void *x, void *y, int N, int H, int W, int C, void *stream);
 int sq_maxpool2x2_bwd_bf16(const void *x, const void *dy, void *dx, int N, int H, int W, int C, void *stream);
 int sq_act_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, int act, void *stream);
+/* dropout backward + the backward of the activation in front of it, one pass:
+ * dx = act'(y) * (mask ? dy / (1 - rate) : 0), y = the activation output that entered the dropout */
+int sq_act_dropout_bwd_bf16(const void *dy, const uint8_t *mask, const void *y, void *dx, int64_t n, float rate,
+                            int act, void *stream);
+/* dX of a convolution whose input was the ReLU output `gate` (same shape as dx): sq_conv2d_nhwc_fwd_bf16 of dy
+ * with the transposed packed filter, passed only where gate > 0 (the upstream ReLU backward fused in) */
+int sq_conv2d_nhwc_dgrad_relu_bf16(const void *dy, const void *wp_t, const void *gate, void *dx, int N, int H, int W,
+                                   int Cin, int Cout, int K, void *stream);
 int sq_bridge_fwd_bf16(const void *a, const void *b, void *y, int64_t n, int bridge, void *stream);
 int sq_bridge_bwd_bf16(const void *dy, const void *a, const void *b, void *da, void *db, int64_t n, int bridge,
                        void *stream);

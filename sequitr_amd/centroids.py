@@ -94,12 +94,16 @@ class CentroidWriter(object):
         for i, coords in enumerate(frames):
             if i % 100 == 0:
                 logger.info('Written out {0:d} of {1:d} frames (Image)...'.format(i, len(frames)))
-            if self._hdf is not None:
-                grp = self._hdf['frames'].create_group('frame_' + str(i))
-                grp.create_dataset('coords', data=coords, dtype='float32')
-            else:
-                self._frames['frames/frame_' + str(i) + '/coords'] = coords
+            self.add_frame(i, coords)
         return frames
+
+    def add_frame(self, i, coords):
+        """store one frame's (k,5) rows as frames/frame_<i>/coords (utils.py:569-578)"""
+        if self._hdf is not None:
+            grp = self._hdf['frames'].create_group('frame_' + str(i))
+            grp.create_dataset('coords', data=coords, dtype='float32')
+        else:
+            self._frames['frames/frame_' + str(i) + '/coords'] = coords
 
     def close(self):
         if self._hdf is not None:

@@ -75,7 +75,7 @@ template <int BN, int KS, int KC>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const __bf16 *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
     __bf16 *__restrict__ y, int N, int H, int W, int Cin, int Cout, int act, int tiles_x, int tiles_y,
-    int ntiles, int tiles_per_block) {
+    int ntiles, int tiles_per_block, const __bf16 *__restrict__ gate) {
     using C = CfgB<BN, KS, KC>;
     constexpr int NR = BN / 16, PAD = KS / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         const_cast<__bf16 *>(wp), 0, (int)((size_t)nchunk * Cout * C::KP * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
         y, 0, (int)((size_t)N * H * W * Cout * 2), 0x00020000);
+    // dgrad fused with the upstream ReLU's backward: outputs pass only where gate (N,H,W,Cout) > 0
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16 *>(gate), 0, gate ? (int)((size_t)N * H * W * Cout * 2) : 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
     uint4 xr[C::XSLOTS], wr[C::WSLOTS];
@@ -190,16 +193,31 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
             const int co = n0 + nb * 16 + 4 * kg;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (bias && co < Cout) bv = *reinterpret_cast<const float4 *>(bias + co);
+            unsigned offs[4];
+            bf16x4 gv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gy = ty * TH + 4 * wv + r;
+                const bool ok = gy < H && gx < W && co < Cout;
+                offs[r] = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 2) : OOB;
+            }
+            if (gate) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    gv[r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(grsrc, offs[r], 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
                 bf16x4 o;
                 o[0] = (__bf16)actf(acc[r][nb][0] + bv.x);
                 o[1] = (__bf16)actf(acc[r][nb][1] + bv.y);
                 o[2] = (__bf16)actf(acc[r][nb][2] + bv.z);
                 o[3] = (__bf16)actf(acc[r][nb][3] + bv.w);
-                const bool ok = gy < H && gx < W && co < Cout;
-                const unsigned off = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 2) : OOB;
+                if (gate) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (float)gv[r][j] > 0.f ? o[j] : (__bf16)0.f;
+                }
+                const unsigned off = offs[r];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
                     __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, o), yrsrc, off, 0, 0);
                 acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
 
 template <int BN, int KS, int KC>
 int launch(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int N, int H, int W, int Cin, int Cout,
-           int act, hipStream_t st) {
+           int act, hipStream_t st, const __bf16 *gate) {
     using C = CfgB<BN, KS, KC>;
     static bool attr_set = false;
     auto kern = conv_mfma_bf16_kernel<BN, KS, KC>;
@@ -309,16 +327,16 @@ int launch(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int 
     if (tpb < 1) tpb = 1;
     const int gx = (ntiles + tpb - 1) / tpb;
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), C::LDS_BYTES, st, x, wp, bias, y, N, H, W, Cin, Cout, act,
-                       tiles_x, tiles_y, ntiles, tpb);
+                       tiles_x, tiles_y, ntiles, tpb, gate);
     return sq_check_launch("sq_conv2d_nhwc_fwd_bf16");
 }
 
 template <int KS, int KC>
 int dispatch_bn(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int N, int H, int W, int Cin,
-                int Cout, int act, hipStream_t st) {
-    if (Cout >= 64) return launch<64, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st);
-    if (Cout > 16) return launch<32, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st);
-    return launch<16, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st);
+                int Cout, int act, hipStream_t st, const __bf16 *gate = nullptr) {
+    if (Cout >= 64) return launch<64, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate);
+    if (Cout > 16) return launch<32, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate);
+    return launch<16, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate);
 }
 
 inline int kc_for(int Cin) { return Cin % 32 == 0 ? 32 : 16; }
@@ -349,8 +367,8 @@ extern "C" int sq_conv_pack_weights_bf16(const float *w, void *wp, int K, int Ci
 
 // conv_layer / weighted_conv2d on bf16 tensors: x (N,H,W,Cin) bf16, wp from sq_conv_pack_weights_bf16,
 // bias f32 or NULL, y (N,H,W,Cout) bf16.  Cin % 16 == 0, Cout % 4 == 0.
-extern "C" int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H,
-                                       int W, int Cin, int Cout, int K, int act, void *stream) {
+static int conv_fwd_bf16_impl(const void *x, const void *wp, const float *bias, void *y, int N, int H, int W, int Cin,
+                              int Cout, int K, int act, void *stream, const void *gate) {
     SQ_REQUIRE(x && wp && y, "sq_conv2d_nhwc_fwd_bf16: null tensor pointer");
     SQ_REQUIRE(N > 0 && H > 0 && W > 0 && (K == 1 || K == 3), "sq_conv2d_nhwc_fwd_bf16: bad shape / K");
     SQ_REQUIRE(Cin % 16 == 0 && Cin > 0 && Cout % 4 == 0 && Cout > 0,
@@ -360,14 +378,30 @@ extern "C" int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const floa
     SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_conv2d_nhwc_fwd_bf16: bad activation %d", act);
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(wp); SQ_REQUIRE_ALIGNED(y);
     if (bias) SQ_REQUIRE_ALIGNED(bias);
+    if (gate) SQ_REQUIRE_ALIGNED(gate);
+    const __bf16 *gb = reinterpret_cast<const __bf16 *>(gate);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *wb = reinterpret_cast<const __bf16 *>(wp);
     __bf16 *yb = reinterpret_cast<__bf16 *>(y);
     if (kc_for(Cin) == 32)
-        return K == 3 ? dispatch_bn<3, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st)
-                      : dispatch_bn<1, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st);
-    return K == 3 ? dispatch_bn<3, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st)
-                  : dispatch_bn<1, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st);
+        return K == 3 ? dispatch_bn<3, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb)
+                      : dispatch_bn<1, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb);
+    return K == 3 ? dispatch_bn<3, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb)
+                  : dispatch_bn<1, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb);
+}
+
+extern "C" int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H,
+                                       int W, int Cin, int Cout, int K, int act, void *stream) {
+    return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, K, act, stream, nullptr);
+}
+
+// dX of a convolution whose INPUT was the ReLU output `gate` (N,H,W,Cout): the dgrad convolution of dy with
+// the transposed packed filter, passed only where gate > 0 -- the upstream activation's backward fused in,
+// one pass over dX saved.
+extern "C" int sq_conv2d_nhwc_dgrad_relu_bf16(const void *dy, const void *wp_t, const void *gate, void *dx, int N, int H,
+                                              int W, int Cin, int Cout, int K, void *stream) {
+    SQ_REQUIRE(gate, "sq_conv2d_nhwc_dgrad_relu_bf16: null gate");
+    return conv_fwd_bf16_impl(dy, wp_t, nullptr, dx, N, H, W, Cin, Cout, K, SQ_ACT_NONE, stream, gate);
 }
 
 // first conv of down0 in the bf16 graph: f32 single-channel image in, bf16 activation out.

@@ -187,6 +187,28 @@ __global__ __launch_bounds__(256) void dropout_bwd_bf16_kernel(const bf16x8 *__r
     }
 }
 
+// dropout backward and the activation backward of the layer in front of it in ONE pass:
+// dx = act'(y) * (keep ? dy / (1 - rate) : 0), y = the activation's output (the dropout's input)
+__global__ __launch_bounds__(256) void act_dropout_bwd_bf16_kernel(const bf16x8 *__restrict__ dy,
+                                                                    const uint2 *__restrict__ mask,
+                                                                    const bf16x8 *__restrict__ y, bf16x8 *__restrict__ dx,
+                                                                    int64_t n8, float rate, int act) {
+    const float inv = 1.0f / (1.0f - rate);
+    const float slope = act == SQ_ACT_LEAKY ? 0.2f : (act == SQ_ACT_RELU ? 0.0f : 1.0f);
+    SQ_GRID_STRIDE(i, n8) {
+        const uint2 m = mask[i];
+        const bf16x8 v = dy[i], yy = y[i];
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned keep = ((j < 4 ? m.x : m.y) >> (8 * (j & 3))) & 0xFFu;
+            const __bf16 d = keep ? (__bf16)((float)v[j] * inv) : (__bf16)0.f;      // rounded as dropout_bwd does
+            r[j] = (float)yy[j] > 0.f ? d : (__bf16)((float)d * slope);
+        }
+        dx[i] = r;
+    }
+}
+
 // ---- 2x2/s2 transpose conv + bias + bridge on v_mfma_f32_16x16x32_bf16 ------------------------------------
 // D[rho][p] = sum_c Wt[rho][c] X[p][c], rho = (2a+b)*Cout + o; Wt = the (2,2,Cout,Cin) kernel read flat (k = c is
 // contiguous for both operands: 16-byte fragment reads).  Block = 64 rows x 64 input pixels, 32-channel chunks.
@@ -436,6 +458,18 @@ extern "C" int sq_dropout_bwd_bf16(const void *dy, const uint8_t *mask, void *dx
                        reinterpret_cast<const bf16x8 *>(dy), reinterpret_cast<const uint2 *>(mask),
                        reinterpret_cast<bf16x8 *>(dx), n / 8, rate);
     return sq_check_launch("sq_dropout_bwd_bf16");
+}
+
+extern "C" int sq_act_dropout_bwd_bf16(const void *dy, const uint8_t *mask, const void *y, void *dx, int64_t n, float rate,
+                                       int act, void *stream) {
+    SQ_REQUIRE(dy && mask && y && dx && n > 0 && n % 8 == 0, "sq_act_dropout_bwd_bf16: bad arguments (n %% 8 == 0)");
+    SQ_REQUIRE(rate >= 0.f && rate < 1.f, "sq_act_dropout_bwd_bf16: rate must be in [0, 1)");
+    SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(y); SQ_REQUIRE_ALIGNED(dx);
+    SQ_REQUIRE((((uintptr_t)mask) & 7u) == 0, "sq_act_dropout_bwd_bf16: mask must be 8-byte aligned");
+    hipLaunchKernelGGL(act_dropout_bwd_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const bf16x8 *>(dy), reinterpret_cast<const uint2 *>(mask),
+                       reinterpret_cast<const bf16x8 *>(y), reinterpret_cast<bf16x8 *>(dx), n / 8, rate, act);
+    return sq_check_launch("sq_act_dropout_bwd_bf16");
 }
 
 extern "C" int sq_convT2x2s2_nhwc_fwd_bf16(const void *x, const void *w, const float *bias, const void *skip, void *y,

@@ -64,6 +64,53 @@ def conv3x3_first(x, w, bias, act='relu'):
     return _ConvFirst.apply(x, w, bias, act)
 
 
+class _ConvBlock(torch.autograd.Function):
+    """conv_block of the U-Net (sequitr/networks/unet.py:265-277) as ONE tape entry:
+    relu(conv1) -> relu(conv2) -> dropout.  The two activations between the three ops have exactly one
+    consumer each, which lets the backward fuse what separate tape entries cannot:
+      * dropout backward + conv2's ReLU backward: one pass (sq_act_dropout_bwd_bf16),
+      * conv1's ReLU backward: the epilogue of conv2's dgrad kernel (sq_conv2d_nhwc_dgrad_relu_bf16).
+    x is the bf16 block input, or the f32 single-channel image for down0."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, rate, seed, mask, step_dev):
+        first = x.dtype == torch.float32
+        f = w1.shape[3]
+        y1 = ob.conv3x3_first(x, w1, b1, act='relu') if first else ob.conv2d(x, ob.pack_weights(w1), b1, 3, f, act='relu')
+        y2 = ob.conv2d(y1, ob.pack_weights(w2), b2, 3, f, act='relu')
+        m = None
+        out = y2
+        if rate > 0.0:
+            out, m = ob.dropout_fwd(y2, rate, seed=seed, mask=mask, step_dev=step_dev)
+        ctx.rate, ctx.first = rate, first
+        ctx.sinks = (grad_sink(w1), grad_sink(b1), grad_sink(w2), grad_sink(b2))
+        ctx.save_for_backward(x, w1, w2, y1, y2, m)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, w1, w2, y1, y2, m = ctx.saved_tensors
+        s1w, s1b, s2w, s2b = ctx.sinks
+        f = w2.shape[3]
+        dout = dout.contiguous()
+        d2 = ob.act_dropout_bwd(dout, m, y2, ctx.rate, 'relu') if m is not None else ob.act_bwd(dout, y2, 'relu')
+        dw2, db2 = ob.conv2d_wgrad(y1, d2, 3, want_bias=True, dw_out=s2w, db_out=s2b)
+        d1 = ob.conv2d_dgrad_relu(d2, ob.pack_weights(w2, transform=True), y1, 3)
+        if ctx.first:
+            dw1, db1 = ob.conv3x3_first_wgrad(x, d1, dw_out=s1w, db_out=s1b)
+            dx = None
+        else:
+            dw1, db1 = ob.conv2d_wgrad(x, d1, 3, want_bias=True, dw_out=s1w, db_out=s1b)
+            dx = ob.conv2d(d1, ob.pack_weights(w1, transform=True), None, 3, x.shape[3]) if ctx.needs_input_grad[0] else None
+        return (dx, None if s1w is not None else dw1, None if s1b is not None else db1,
+                None if s2w is not None else dw2, None if s2b is not None else db2, None, None, None, None)
+
+
+def conv_block(x, w1, b1, w2, b2, rate=0.0, seed=0, mask=None, step_dev=None):
+    return _ConvBlock.apply(x, w1, b1, w2, b2, float(rate), int(seed), mask, step_dev)
+
+
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

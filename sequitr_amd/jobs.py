@@ -125,11 +125,7 @@ def SERVER_segment(params, options):
     dt = time.time() - t0
     if writer is not None:
         for k in sorted(frames_out):
-            if writer._hdf is not None:
-                writer._hdf['frames'].create_group('frame_' + str(k)).create_dataset(
-                    'coords', data=frames_out[k], dtype='float32')
-            else:
-                writer._frames['frames/frame_' + str(k) + '/coords'] = frames_out[k]
+            writer.add_frame(k, frames_out[k])
         writer.close()
     np.save(os.path.join(out_dir, 'mask.npy'), masks)
     if logits is not None:
@@ -201,11 +197,7 @@ def SERVER_segment_frames(params, options):
         from .centroids import CentroidWriter
         with CentroidWriter(os.path.join(out_dir, 'tracks.hdf5')) as cw:
             for k in sorted(per_frame):
-                if cw._hdf is not None:
-                    cw._hdf['frames'].create_group('frame_' + str(k)).create_dataset('coords', data=per_frame[k],
-                                                                                      dtype='float32')
-                else:
-                    cw._frames['frames/frame_' + str(k) + '/coords'] = per_frame[k]
+                cw.add_frame(k, per_frame[k])
         info['centroids'] = {'file': os.path.basename(cw.filename), 'objects': int(sum(len(v) for v in per_frame.values()))}
     with open(os.path.join(out_dir, 'segment.json'), 'w') as f:
         json.dump(info, f, indent=2)

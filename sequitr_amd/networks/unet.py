@@ -503,6 +503,7 @@ class UNet2DBf16(UNet2D):
 
     def __init__(self, params, mode=PREDICT):
         UNet2D.__init__(self, dict(params, fuse=False), mode)
+        self.fuse_block = bool(params.get('fuse_block', True))   # conv_block as one tape entry (training)
         if self.n_inputs != 1:
             raise ValueError('the bf16 graph takes a single-channel f32 image (num_inputs == 1)')
         if self.batch_norm:
@@ -518,6 +519,25 @@ class UNet2DBf16(UNet2D):
         if x.dtype == torch.float32:
             return FB.conv3x3_first(x, w, b, act='relu')
         return FB.conv2d(x, w, b, act='relu')
+
+    def conv_block(self, x, filters):
+        """unet.py:265-277.  While neither conv_layer nor dropout_layer is overridden the block is one tape
+        entry (FB.conv_block): same forward kernels, backward with the two ReLU gradients fused away."""
+        if not (self.training and self.fuse_block and type(self).conv_layer is UNet2DBf16.conv_layer
+                and type(self).dropout_layer is UNet2DBf16.dropout_layer):
+            return UNet2D.conv_block(self, x, filters)
+        with self.variable_scope('conv1'):
+            w1, b1 = self._kernel((3, 3, x.shape[-1], filters)), self._bias(filters)
+        with self.variable_scope('conv2'):
+            w2, b2 = self._kernel((3, 3, filters, filters)), self._bias(filters)
+        rate = self.dropout if self.dropout > 0.0 else 0.0
+        mask = step_dev = None
+        seed = 0
+        if rate > 0.0:
+            mask = self.dropout_masks.pop(0) if getattr(self, 'dropout_masks', None) else None
+            step_dev = None if mask is not None else getattr(self, '_step_dev', None)
+            seed = self._dropout_seed(step_dev)
+        return FB.conv_block(x, w1, b1, w2, b2, rate, seed, mask, step_dev)
 
     def conv_layer_1x1(self, x, filters):
         w, b = self._kernel((1, 1, x.shape[-1], filters)), self._bias(filters)

@@ -49,6 +49,20 @@ def conv2d(x, wp, bias, K, Cout, act=None):
     return y
 
 
+def conv2d_dgrad_relu(dy, wp_t, gate, K):
+    """dX of a conv whose input was the ReLU output `gate`: conv(dy, wp_t) passed where gate > 0."""
+    _chk(dy, "dy", ndim=4), _chk(wp_t, "wp_t"), _chk(gate, "gate", ndim=4)
+    N, H, W, Cin = dy.shape
+    Cout = gate.shape[3]
+    if tuple(gate.shape[:3]) != (N, H, W):
+        raise ValueError("gate %s does not match dy %s" % (tuple(gate.shape), tuple(dy.shape)))
+    dx = torch.empty((N, H, W, Cout), dtype=BF16, device=dy.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_conv2d_nhwc_dgrad_relu_bf16(_ptr(dy), _ptr(wp_t), _ptr(gate), _ptr(dx), N, H, W, Cin, Cout, K,
+                                                 _stream()), "sq_conv2d_nhwc_dgrad_relu_bf16")
+    return dx
+
+
 def conv3x3_first(x, w, bias, act="relu"):
     """f32 (N,H,W,1) image, f32 (3,3,1,Cout) filter -> bf16 activation."""
     _chk(x, "x", dtype=torch.float32, ndim=4), _chk(w, "w", dtype=torch.float32, ndim=4)
@@ -156,6 +170,16 @@ def dropout_bwd(dy, mask, rate):
     dx = torch.empty_like(dy)
     lib = _lib.load()
     _lib.check(lib.sq_dropout_bwd_bf16(_ptr(dy), _ptr(mask), _ptr(dx), dy.numel(), float(rate), _stream()), "sq_dropout_bwd_bf16")
+    return dx
+
+
+def act_dropout_bwd(dy, mask, y, rate, act):
+    """dropout backward + the backward of the activation whose output y entered the dropout, one pass."""
+    _chk(dy, "dy"), _chk(y, "y"), _chk(mask, "mask", dtype=torch.uint8)
+    dx = torch.empty_like(dy)
+    lib = _lib.load()
+    _lib.check(lib.sq_act_dropout_bwd_bf16(_ptr(dy), _ptr(mask), _ptr(y), _ptr(dx), dy.numel(), float(rate), ACT[act],
+                                          _stream()), "sq_act_dropout_bwd_bf16")
     return dx
 
 

@@ -225,3 +225,23 @@ def test_unet_bf16_trains_and_predicts():
     mask = net.predict(x).cpu().numpy()
     iou = np.logical_and(mask == 1, lab[None]).sum() / np.logical_or(mask == 1, lab[None]).sum()
     assert iou > 0.8
+
+
+def test_fused_conv_block_backward_equals_the_unfused_tape():
+    """UNet2DBf16.conv_block as one tape entry (dropout+ReLU backward in one pass, conv1's ReLU backward in the
+    dgrad epilogue) gives the same loss and the same gradients, bit for bit, as the op-by-op tape."""
+    from sequitr_amd.train import UNetTrainer
+    base = {"shape": (64, 64), "dropout": 0.4, "device": "cuda:0", "seed": 5, "filters": (16, 32, 64), "dtype": "bf16"}
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 64, 64, 1)).astype(np.float32)
+    lab = rng.random((2, 64, 64)) < 0.4
+    onehot = np.stack([~lab, lab], -1).astype(np.uint8)
+    wmap = (1 + rng.random((2, 64, 64, 1))).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to("cuda:0")
+    a, b = UNetTrainer(dict(base, fuse_block=True)), UNetTrainer(dict(base, fuse_block=False))
+    la = a.forward_backward(d(x), d(onehot), d(wmap))
+    lb = b.forward_backward(d(x), d(onehot), d(wmap))
+    assert la.item() == lb.item()
+    ga, gb = a.grads(), b.grads()
+    for k in gb:
+        assert np.array_equal(ga[k], gb[k]), k
