@@ -295,6 +295,13 @@ int sq_conv3x3_first_block_fwd_f32(const float *x, const float *w1, const float 
 int64_t sq_conv_packed_weights_elems_bf16(int K, int Cin, int Cout);
 int sq_conv_pack_weights_bf16(const float *w, void *wp, int K, int Cin, int Cout, float wscale, int transform,
                               void *stream);
+/* Every pack (and plain f32 -> bf16 cast) of one optimiser step in one launch.  base: the flat fp32 parameter
+ * buffer; out: one bf16 buffer; table (device, n_entries x 8 int32, n_entries <= 128):
+ * {src offset in floats, dst offset in bf16 elements, K, Cin, Cout of the packed conv, transform, index of the
+ * entry's first item, kind (0 = pack as sq_conv_pack_weights_bf16, 1 = plain cast of K*K*Cin*Cout values)};
+ * total_items = sum of the entries' item counts (packed elements, or values for kind 1). */
+int sq_conv_pack_weights_multi_bf16(const float *base, void *out, const int32_t *table, int n_entries,
+                                    int total_items, void *stream);
 
 /* conv_layer / weighted_conv2d on bf16 activations: y = act(conv(x, wp) + bias), fp32 accumulate. */
 int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H, int W,

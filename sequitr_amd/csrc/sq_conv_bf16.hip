@@ -71,6 +71,47 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float *__r
     }
 }
 
+// All the packs (and plain bf16 casts) of one optimiser step in ONE launch.  table: n_entries x 8 int32
+// {src offset (floats), dst offset (bf16), K, Cin, Cout of the PACKED conv, transform, first item, kind};
+// kind 0 = pack as pack_weights_bf16_kernel, kind 1 = plain cast of Cin*Cout*K*K elements.  Items are
+// numbered across entries; a thread finds its entry by scanning the (tiny) table in LDS.
+__global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const float *__restrict__ base,
+                                                                       __bf16 *__restrict__ out,
+                                                                       const int *__restrict__ table, int n_entries,
+                                                                       int total) {
+    __shared__ int tb[128 * 8];
+    for (int i = threadIdx.x; i < n_entries * 8; i += 256) tb[i] = table[i];
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int lo = 0, hi = n_entries - 1;                        // last entry whose first item <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tb[mid * 8 + 6] <= i) lo = mid; else hi = mid - 1;
+        }
+        const int *e = tb + lo * 8;
+        const float *w = base + e[0];
+        __bf16 *wp = out + e[1];
+        const int K = e[2], Cin = e[3], Cout = e[4], transform = e[5], j = i - e[6];
+        if (e[7] == 1) {
+            wp[j] = (__bf16)w[j];
+            continue;
+        }
+        const int KC = Cin % 32 == 0 ? 32 : 16, KP = kp_for(K, KC);
+        const int k = j % KP, co = (j / KP) % Cout, chunk = j / (KP * Cout);
+        float v = 0.f;
+        if (k < K * K * KC) {
+            const int tap = k / KC, c = chunk * KC + k % KC;
+            if (!transform) {
+                v = w[((size_t)tap * Cin + c) * Cout + co];
+            } else {
+                const int ky = tap / K, kx = tap % K;
+                v = w[((size_t)((K - 1 - ky) * K + (K - 1 - kx)) * Cout + co) * Cin + c];
+            }
+        }
+        wp[j] = (__bf16)v;
+    }
+}
+
 template <int BN, int KS, int KC>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const __bf16 *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
@@ -363,6 +404,18 @@ extern "C" int sq_conv_pack_weights_bf16(const float *w, void *wp, int K, int Ci
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        w, reinterpret_cast<__bf16 *>(wp), K, Cin, Cout, KC, kp_for(K, KC), wscale, transform);
     return sq_check_launch("sq_conv_pack_weights_bf16");
+}
+
+// every pack / cast of a training step in one launch (table layout: pack_weights_multi_bf16_kernel)
+extern "C" int sq_conv_pack_weights_multi_bf16(const float *base, void *out, const int32_t *table, int n_entries,
+                                               int total_items, void *stream) {
+    SQ_REQUIRE(base && out && table && n_entries > 0 && n_entries <= 128 && total_items > 0,
+               "sq_conv_pack_weights_multi_bf16: bad arguments (at most 128 entries)");
+    int nb = (total_items + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(pack_weights_multi_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       base, reinterpret_cast<__bf16 *>(out), table, n_entries, total_items);
+    return sq_check_launch("sq_conv_pack_weights_multi_bf16");
 }
 
 // conv_layer / weighted_conv2d on bf16 tensors: x (N,H,W,Cin) bf16, wp from sq_conv_pack_weights_bf16,

@@ -144,7 +144,10 @@ class _ConvT(torch.autograd.Function):
         g = ob.space_to_depth2(dy.contiguous())                              # (N,H,W,4*Cout) bf16
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wp = ob.pack_weights(w.reshape(1, 1, 4 * Cout, Cin))              # 1x1 conv 4Cout -> Cin
+            packs = getattr(w, '_sq_packs', None) or {}
+            wp = packs.get('convT_dgrad')
+            if wp is None:
+                wp = ob.pack_weights(w.reshape(1, 1, 4 * Cout, Cin))          # 1x1 conv 4Cout -> Cin
             dx = ob.conv2d(g, wp, None, 1, Cin)
         dwp, dbp = ob.conv2d_wgrad(x, g, 1, want_bias=ctx.has_bias)           # (1,1,Cin,4Cout)
         dw, db = convT_param_grads(dwp, dbp if ctx.has_bias else None, Cin, Cout, ctx.sinks)

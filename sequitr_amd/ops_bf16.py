@@ -24,6 +24,11 @@ def pack_weights(w, transform=False, wscale=1.0):
     """f32 HWIO (K,K,Cin,Cout) -> packed bf16 filter.  transform=True packs the dgrad filter (the
     result convolves Cout channels to Cin)."""
     _chk(w, "w", dtype=torch.float32, ndim=4)
+    packs = getattr(w, "_sq_packs", None)                     # filled once per step by PackPlan.run()
+    if packs is not None and wscale == 1.0:
+        hit = packs.get("T" if transform else "N")
+        if hit is not None:
+            return hit
     K, _, Cin, Cout = w.shape
     ci, co = (Cout, Cin) if transform else (Cin, Cout)
     lib = _lib.load()
@@ -92,7 +97,73 @@ def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None):
     return dw, db
 
 
+class PackPlan(object):
+    """All bf16 filter packs of one training step as ONE launch (sq_conv_pack_weights_multi_bf16).
+    `flat` is the flat fp32 parameter buffer, `leaves` {name: (leaf tensor, float offset)}; every 3x3 / 1x1
+    kernel with Cin % 16 == 0 gets its forward pack ("N") and its dgrad pack ("T"), every (2,2,Cout,Cin)
+    transpose-conv kernel a plain bf16 copy ("cast") and the pack of its 1x1 dgrad form ("convT_dgrad").
+    The packed views hang on the leaves as `_sq_packs`; pack_weights()/to_bf16() pick them up."""
+
+    def __init__(self, flat, leaves):
+        lib = _lib.load()
+        rows, dst, item = [], 0, 0
+
+        def add(src, K, ci, co, transform, kind, count):
+            nonlocal dst, item
+            rows.append([src, dst, K, ci, co, transform, item, kind])
+            view = (dst, count)
+            dst += (count + 7) // 8 * 8                         # keep every pack 16-byte aligned
+            item += count
+            return view
+
+        views = {}
+        for name, (leaf, off) in leaves.items():
+            if leaf.dim() != 4:
+                continue
+            K, K2, A, B = leaf.shape
+            if 'upscale' in name and K == 2:                    # (2,2,Cout,Cin) transpose-conv kernel
+                Cout, Cin = A, B
+                if Cin % 16 or (4 * Cout) % 16:
+                    continue
+                views[name] = {'cast': add(off, 2, Cin, Cout, 0, 1, leaf.numel())}
+                n = lib.sq_conv_packed_weights_elems_bf16(1, 4 * Cout, Cin)
+                if n > 0:                                       # HWIO view (1,1,4Cout,Cin) -> conv 4Cout -> Cin
+                    views[name]['convT_dgrad'] = add(off, 1, 4 * Cout, Cin, 0, 0, n)
+                continue
+            Cin, Cout = A, B
+            v = {}
+            n = lib.sq_conv_packed_weights_elems_bf16(K, Cin, Cout)
+            if K == K2 and n > 0:
+                v['N'] = add(off, K, Cin, Cout, 0, 0, n)
+            n = lib.sq_conv_packed_weights_elems_bf16(K, Cout, Cin)
+            if K == K2 and n > 0:
+                v['T'] = add(off, K, Cout, Cin, 1, 0, n)
+            if v:
+                views[name] = v
+        if len(rows) > 128:
+            raise _lib.SequitrHipError("PackPlan: %d packs exceed the 128-entry table" % len(rows))
+        self.flat, self.total, self.n = flat, item, len(rows)
+        self.table = torch.tensor(rows, dtype=torch.int32, device=flat.device).contiguous()
+        self.out = torch.zeros(max(dst, 8), dtype=BF16, device=flat.device)
+        for name, v in views.items():
+            leaf = leaves[name][0]
+            leaf._sq_packs = {}
+            for key, (d0, cnt) in v.items():
+                t = self.out[d0:d0 + cnt]
+                leaf._sq_packs[key] = t.view(leaf.shape) if key == 'cast' else t
+
+    def run(self):
+        if self.n == 0:
+            return
+        lib = _lib.load()
+        _lib.check(lib.sq_conv_pack_weights_multi_bf16(_ptr(self.flat), _ptr(self.out), _ptr(self.table), self.n,
+                                                      self.total, _stream()), "sq_conv_pack_weights_multi_bf16")
+
+
 def to_bf16(x):
+    packs = getattr(x, "_sq_packs", None)
+    if packs is not None and packs.get("cast") is not None:
+        return packs["cast"]
     _chk(x, "x", dtype=torch.float32)
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
     lib = _lib.load()

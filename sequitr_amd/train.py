@@ -40,6 +40,11 @@ class UNetTrainer(object):
             if direct_grads:
                 leaf._sq_grad_sink = leaf.grad                  # ... or the gradient kernel writes it directly
             self.net._vars[name] = leaf
+        self.pack_plan = None
+        if net_cls is UNet2DBf16 or isinstance(self.net, UNet2DBf16):
+            from .ops_bf16 import PackPlan
+            self.pack_plan = PackPlan(self.pbucket.flat, {n: (self.net._vars[n], self.pbucket.offsets[n][0])
+                                                         for n in self.pbucket.names})
         self.last_loss = None
         # Adam's step counter lives on the device ({step, lr_t bits}) so a captured step replays correctly;
         # the same counter salts the dropout seeds.
@@ -70,6 +75,8 @@ class UNetTrainer(object):
     def forward_backward(self, x, onehot, weights):
         """Leaves the (local) gradients in the flat gradient bucket; returns the loss tensor."""
         self.gbucket.flat.zero_()
+        if self.pack_plan is not None:
+            self.pack_plan.run()                                # every bf16 filter pack of the step, one launch
         logits = self.net.build(x)
         loss = F.weighted_softmax_cross_entropy(logits, onehot, weights)
         loss.backward()

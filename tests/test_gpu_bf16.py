@@ -245,3 +245,31 @@ def test_fused_conv_block_backward_equals_the_unfused_tape():
     ga, gb = a.grads(), b.grads()
     for k in gb:
         assert np.array_equal(ga[k], gb[k]), k
+
+
+def test_pack_plan_equals_the_single_packs():
+    """PackPlan (one launch per step) writes exactly what pack_weights / to_bf16 write one by one."""
+    from sequitr_amd.train import UNetTrainer
+    t = UNetTrainer({"shape": (32, 32), "device": "cuda:0", "seed": 1, "filters": (16, 32, 64), "dtype": "bf16"})
+    assert t.pack_plan is not None and t.pack_plan.n > 20
+    t.pack_plan.run()
+    checked = 0
+    for name in t.pbucket.names:
+        leaf = t.net._vars[name]
+        packs = getattr(leaf, "_sq_packs", None)
+        if not packs:
+            continue
+        plain = leaf.detach().clone()                                  # no cache on the clone
+        for key, got in packs.items():
+            if key == "N":
+                ref = ob.pack_weights(plain)
+            elif key == "T":
+                ref = ob.pack_weights(plain, transform=True)
+            elif key == "cast":
+                ref = ob.to_bf16(plain)
+            else:
+                Cout, Cin = plain.shape[2], plain.shape[3]
+                ref = ob.pack_weights(plain.reshape(1, 1, 4 * Cout, Cin))
+            assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (name, key)
+            checked += 1
+    assert checked >= 20
