@@ -6,13 +6,16 @@
 // receiving channel i of the 4 pixels -- exactly the MFMA fragment, no shuffles, no transposed copy.
 // Semantics were confirmed on hardware with tools/probe_tr16.hip.
 //
-// Block = (16-channel ci chunk, 16-channel co chunk) pair x a run of 16x16 pixel tiles (persistent,
+// Block = (16 NI input channels, 16 NO output channels) x a run of 16x16 pixel tiles (persistent,
 // accumulators stay in registers across the run); wave w owns tile rows 4w..4w+3 = two 32-pixel k-steps.
+// X is re-read once per output-channel block and dY once per input-channel block, so NI = NO = 2 where the
+// layer has >= 32 channels halves the traffic this kernel is bound by.
 // Pixel <-> k mapping of one k-step (rows r, r+1 of the tile), lane group g, element e:
 //     row = r + (g >> 1),  x = 4*(g & 1) + 8*(e >> 2) + (e & 3)
 // chosen so the two groups of a 32-lane half read blocks 128 B apart (conflict-free).
 // Partials + fixed-order finish kernel as in sq_conv_wgrad_f32.hip (no float atomics).
 #include "sq_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -22,18 +25,20 @@ namespace {
 
 constexpr int TH = 16, TW = 16, PSB = 32;          // 16 bf16 channels per pixel row in LDS
 
-template <int KS>
+template <int KS, int NI, int NO>
 struct WB {
     static constexpr int HALO_W = TW + KS - 1;
     static constexpr int HP = HALO_W * (TH + KS - 1);
     static constexpr int NTAP = KS * KS;
-    static constexpr int XS_BYTES = HP * PSB;
-    static constexpr int YS_BYTES = TH * TW * PSB;
-    static constexpr int ROWS = NTAP * 16 + 1;
-    static constexpr int RED_FLOATS = ROWS * 16;
+    static constexpr int CI = 16 * NI, CO = 16 * NO;          // channels of X / dY one block contracts
+    static constexpr int XPLANE = HP * PSB, YPLANE = TH * TW * PSB;   // one 16-channel plane of the tile in LDS
+    static constexpr int XS_BYTES = XPLANE * NI;
+    static constexpr int YS_BYTES = YPLANE * NO;
+    static constexpr int ROWS = NTAP * CI + 1;
+    static constexpr int RED_FLOATS = ROWS * CO;
     static constexpr int LDS_BYTES = (XS_BYTES + YS_BYTES) > RED_FLOATS * 4 ? (XS_BYTES + YS_BYTES) : RED_FLOATS * 4;
-    static constexpr int XITEMS = HP * 2, XSLOTS = (XITEMS + 255) / 256;
-    static constexpr int YITEMS = TH * TW * 2, YSLOTS = YITEMS / 256;
+    static constexpr int XITEMS = HP * 2 * NI, XSLOTS = (XITEMS + 255) / 256;
+    static constexpr int YITEMS = TH * TW * 2 * NO, YSLOTS = YITEMS / 256;
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char *p0, const unsigned char *p1) {
@@ -43,18 +48,25 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char *p0, const unsigne
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int KS>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(
+// NI x NO 16-channel planes per block: every byte of X is read Cout / (16 NO) times and every byte of dY
+// Cin / (16 NI) times over the whole launch, so wider blocks cut the (L2 / HBM) traffic that bounds this
+// kernel; the accumulators (NTAP x NI x NO MFMA blocks) are what limits NI, NO.
+// blocks per CU the register budget is sized for: the 36-accumulator-block shapes take the whole file
+template <int KS, int NI, int NO>
+constexpr int wgrad_occ() { return KS * KS * NI * NO > 18 ? 1 : 2; }
+
+template <int KS, int NI, int NO, int PF>
+__global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf16_kernel(
     const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy, float *__restrict__ partials, int N, int H,
     int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block) {
-    using C = WB<KS>;
+    using C = WB<KS, NI, NO>;
     constexpr int PAD = KS / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *xs = smem, *ys = smem + C::XS_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kg = lane >> 4, q = li >> 2, p = li & 3;
-    const int nco = Cout / 16;
-    const int ci0 = (blockIdx.y / nco) * 16, co0 = (blockIdx.y % nco) * 16;
+    const int nco = Cout / C::CO;
+    const int ci0 = (blockIdx.y / nco) * C::CI, co0 = (blockIdx.y % nco) * C::CO;
     const int t_begin = blockIdx.x * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -63,56 +75,60 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(
         const_cast<__bf16 *>(dy), 0, (int)((size_t)N * H * W * Cout * 2), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
-    int xrel[C::XSLOTS], xpy[C::XSLOTS], xpx[C::XSLOTS];
-#pragma unroll
-    for (int sl = 0; sl < C::XSLOTS; ++sl) {
-        const int idx = tid + sl * 256, pix = idx >> 1, h = idx & 1;
-        xpy[sl] = pix / C::HALO_W;
-        xpx[sl] = pix % C::HALO_W;
-        xrel[sl] = idx < C::XITEMS ? ((xpy[sl] * W + xpx[sl]) * Cin + ci0 + h * 8) * 2 : (int)OOB;
-    }
-    int yrel[C::YSLOTS], ypy[C::YSLOTS], ypx[C::YSLOTS];
-#pragma unroll
-    for (int sl = 0; sl < C::YSLOTS; ++sl) {
-        const int idx = tid + sl * 256, pix = idx >> 1, h = idx & 1;
-        ypy[sl] = pix / TW;
-        ypx[sl] = pix % TW;
-        yrel[sl] = ((ypy[sl] * W + ypx[sl]) * Cout + co0 + h * 8) * 2;
-    }
-    uint4 xr[C::XSLOTS], yr[C::YSLOTS];
-    auto issue = [&](int tile) {
+    // 16-byte items: item = (pixel, plane, half); a pixel's 32 NI bytes are contiguous in HBM.  The index
+    // decode is redone per tile (a handful of integer ops) rather than kept in registers: the accumulators
+    // need them.
+    // PF register sets: the loads of tile t+PF are issued while tile t is computed, i.e. PF-1 whole
+    // iterations before they are committed to LDS -- one iteration is far shorter than an HBM round trip
+    uint4 xr[PF][C::XSLOTS], yr[PF][C::YSLOTS];
+    auto issue = [&](int tile, uint4 (&xr)[C::XSLOTS], uint4 (&yr)[C::YSLOTS]) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW, y0 = ty * TH;
-        const int xbase = (((n * H + y0 - PAD) * W + x0 - PAD) * Cin) * 2;
-        const int ybase = (((n * H + y0) * W + x0) * Cout) * 2;
+        const int xbase = (((n * H + y0 - PAD) * W + x0 - PAD) * Cin + ci0) * 2;
+        const int ybase = (((n * H + y0) * W + x0) * Cout + co0) * 2;
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
-            const bool inb = (unsigned)(y0 - PAD + xpy[sl]) < (unsigned)H &&
-                             (unsigned)(x0 - PAD + xpx[sl]) < (unsigned)W && xrel[sl] != (int)OOB;
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? (unsigned)(xbase + xrel[sl]) : OOB, 0, 0);
+            const int idx = tid + sl * 256, pix = idx / (2 * NI), rem = idx % (2 * NI);
+            const int py = pix / C::HALO_W, px = pix % C::HALO_W;
+            const bool inb = idx < C::XITEMS && (unsigned)(y0 - PAD + py) < (unsigned)H &&
+                             (unsigned)(x0 - PAD + px) < (unsigned)W;
+            const unsigned off = inb ? (unsigned)(xbase + ((py * W + px) * Cin + rem * 8) * 2) : OOB;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
             xr[sl] = *reinterpret_cast<const uint4 *>(&v);
         }
 #pragma unroll
         for (int sl = 0; sl < C::YSLOTS; ++sl) {
-            const bool inb = (y0 + ypy[sl]) < H && (x0 + ypx[sl]) < W;
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, inb ? (unsigned)(ybase + yrel[sl]) : OOB, 0, 0);
+            const int idx = tid + sl * 256, pix = idx / (2 * NO), rem = idx % (2 * NO);
+            const int py = pix / TW, px = pix % TW;
+            const bool inb = (y0 + py) < H && (x0 + px) < W;
+            const unsigned off = inb ? (unsigned)(ybase + ((py * W + px) * Cout + rem * 8) * 2) : OOB;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, off, 0, 0);
             yr[sl] = *reinterpret_cast<const uint4 *>(&v);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](const uint4 (&xr)[C::XSLOTS], const uint4 (&yr)[C::YSLOTS]) {
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
-            const int idx = tid + sl * 256;
-            if (idx < C::XITEMS) *reinterpret_cast<uint4 *>(xs + idx * 16) = xr[sl];
+            const int idx = tid + sl * 256, pix = idx / (2 * NI), rem = idx % (2 * NI);
+            if (idx < C::XITEMS) *reinterpret_cast<uint4 *>(xs + (rem >> 1) * C::XPLANE + pix * PSB + (rem & 1) * 16) = xr[sl];
         }
 #pragma unroll
-        for (int sl = 0; sl < C::YSLOTS; ++sl) *reinterpret_cast<uint4 *>(ys + (tid + sl * 256) * 16) = yr[sl];
+        for (int sl = 0; sl < C::YSLOTS; ++sl) {
+            const int idx = tid + sl * 256, pix = idx / (2 * NO), rem = idx % (2 * NO);
+            *reinterpret_cast<uint4 *>(ys + (rem >> 1) * C::YPLANE + pix * PSB + (rem & 1) * 16) = yr[sl];
+        }
     };
 
-    f32x4 acc[C::NTAP];
+    f32x4 acc[C::NTAP][NI][NO];
 #pragma unroll
-    for (int t = 0; t < C::NTAP; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
+    for (int t = 0; t < C::NTAP; ++t)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int o = 0; o < NO; ++o) acc[t][i][o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) bsum[o] = 0.f;
 
     // this lane's tr-read address inside a k-step: pixel (row kg>>1, x 4*(kg&1) + q), 8-byte piece p;
     // the second read of a fragment is 8 pixels further along the row
@@ -121,50 +137,76 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(
     const unsigned char *yb = ys + ((4 * wv) * TW + lane_px) * PSB + p * 8;
     const unsigned char *xa = xs + ((4 * wv) * C::HALO_W + lane_hx) * PSB + p * 8;
 
-    if (t_begin < t_end) {
-        issue(t_begin);
-        commit();
-    }
+    // an out-of-range tile index loads nothing (every lane's offset is out of bounds) and is never committed
+    auto issue_if = [&](int tile, uint4 (&xr_)[C::XSLOTS], uint4 (&yr_)[C::YSLOTS]) {
+        if (tile < t_end) issue(tile, xr_, yr_);
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) issue_if(t_begin + u, xr[u], yr[u]);
+    if (t_begin < t_end) commit(xr[0], yr[0]);
     __syncthreads();
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        const bool has_next = tile + 1 < t_end;
-        if (has_next) issue(tile + 1);
+    for (int base = t_begin; base < t_end; base += PF) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const unsigned char *yk = yb + (2 * ks) * TW * PSB;
-            const bf16x8 b = tr_frag(yk, yk + 8 * PSB);
+        for (int u = 0; u < PF; ++u) {
+            const int tile = base + u;
+            if (tile >= t_end) break;
+            issue_if(tile + PF, xr[u], yr[u]);                 // set u was committed before this tile's compute
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bsum += (float)b[e];
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char *yk = yb + (2 * ks) * TW * PSB;
+                bf16x8 b[NO];
 #pragma unroll
-            for (int t = 0; t < C::NTAP; ++t) {
-                const unsigned char *xk = xa + ((2 * ks + t / KS) * C::HALO_W + t % KS) * PSB;
-                const bf16x8 a = tr_frag(xk, xk + 8 * PSB);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+                for (int o = 0; o < NO; ++o) {
+                    b[o] = tr_frag(yk + o * C::YPLANE, yk + o * C::YPLANE + 8 * PSB);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[o] += (float)b[o][e];
+                }
+#pragma unroll
+                for (int t = 0; t < C::NTAP; ++t) {
+                    const unsigned char *xk = xa + ((2 * ks + t / KS) * C::HALO_W + t % KS) * PSB;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const bf16x8 a = tr_frag(xk + i * C::XPLANE, xk + i * C::XPLANE + 8 * PSB);
+#pragma unroll
+                        for (int o = 0; o < NO; ++o)
+                            acc[t][i][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[o], acc[t][i][o], 0, 0, 0);
+                    }
+                }
             }
-        }
-        __syncthreads();
-        if (has_next) {
-            commit();
             __syncthreads();
+            if (tile + 1 < t_end) {
+                commit(xr[(u + 1) % PF], yr[(u + 1) % PF]);
+                __syncthreads();
+            }
         }
     }
 
-    // cross-wave reduction in wave order, then one partial per block (layout of the f32 kernel)
+    // cross-wave reduction in wave order, then one partial per block: red[(tap*CI + ci)*CO + co], bias row last
     float *red = reinterpret_cast<float *>(smem);
-    bsum += __shfl_xor(bsum, 16);
-    bsum += __shfl_xor(bsum, 32);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        bsum[o] += __shfl_xor(bsum[o], 16);
+        bsum[o] += __shfl_xor(bsum[o], 32);
+    }
     for (int w = 0; w < 4; ++w) {
         if (wv == w) {
 #pragma unroll
             for (int t = 0; t < C::NTAP; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float *d = red + (t * 16 + 4 * kg + j) * 16 + li;
-                    *d = (w == 0) ? acc[t][j] : *d + acc[t][j];
-                }
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int o = 0; o < NO; ++o)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float *d = red + (t * C::CI + i * 16 + 4 * kg + j) * C::CO + o * 16 + li;
+                            *d = (w == 0) ? acc[t][i][o][j] : *d + acc[t][i][o][j];
+                        }
             if (kg == 0) {
-                float *d = red + (C::NTAP * 16) * 16 + li;
-                *d = (w == 0) ? bsum : *d + bsum;
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {
+                    float *d = red + (C::NTAP * C::CI) * C::CO + o * 16 + li;
+                    *d = (w == 0) ? bsum[o] : *d + bsum[o];
+                }
             }
         }
         __syncthreads();
@@ -173,60 +215,146 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(
     for (int i = tid; i < C::RED_FLOATS; i += 256) out[i] = red[i];
 }
 
-template <int KS>
+template <int KS, int NI, int NO>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float *__restrict__ partials,
                                                                       float *__restrict__ dw, float *__restrict__ db,
                                                                       int nblk, int Cin, int Cout, int G) {
-    using C = WB<KS>;
-    const int nco = Cout / 16, npairs = (Cin / 16) * nco;
+    using C = WB<KS, NI, NO>;
+    const int nco = Cout / C::CO, npairs = (Cin / C::CI) * nco;
     const int total = C::NTAP * Cin * Cout;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t / G, g = t % G;
     const size_t stride = (size_t)npairs * C::RED_FLOATS;
     if (i < total) {
         const int co = i % Cout, ci = (i / Cout) % Cin, tap = i / (Cout * Cin);
-        const size_t off = (size_t)((ci / 16) * nco + co / 16) * C::RED_FLOATS + (tap * 16 + ci % 16) * 16 + co % 16;
+        const size_t off = (size_t)((ci / C::CI) * nco + co / C::CO) * C::RED_FLOATS +
+                           (tap * C::CI + ci % C::CI) * C::CO + co % C::CO;
         const float s = sq_group_reduce(partials + off, stride, nblk, g, G);
         if (g == 0) dw[i] = s;
     } else if (i < total + Cout) {
         const int co = i - total;
-        const size_t off = (size_t)(co / 16) * C::RED_FLOATS + (C::NTAP * 16) * 16 + co % 16;
+        const size_t off = (size_t)(co / C::CO) * C::RED_FLOATS + (C::NTAP * C::CI) * C::CO + co % C::CO;
         const float s = sq_group_reduce(partials + off, stride, nblk, g, G);
         if (g == 0 && db) db[co] = s;
     }
 }
 
-template <int KS>
+template <int KS, int NI, int NO>
 void plan(int N, int H, int W, int Cin, int Cout, int *gx, int *tpb, int64_t *ws_floats) {
+    using C = WB<KS, NI, NO>;
     const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * N;
-    const int npairs = (Cin / 16) * (Cout / 16);
+    const int npairs = (Cin / C::CI) * (Cout / C::CO);
     int want = (512 + npairs - 1) / npairs;
     if (want < 1) want = 1;
     int t = (ntiles + want - 1) / want;
     if (t < 1) t = 1;
     *tpb = t;
     *gx = (ntiles + t - 1) / t;
-    *ws_floats = (int64_t)(*gx) * npairs * WB<KS>::RED_FLOATS;
+    *ws_floats = (int64_t)(*gx) * npairs * C::RED_FLOATS;
 }
 
-template <int KS>
+template <int KS, int NI, int NO>
 int launch(const __bf16 *x, const __bf16 *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin,
            int Cout, hipStream_t st) {
-    using C = WB<KS>;
+    using C = WB<KS, NI, NO>;
+    static bool attr_set = false;
+    // prefetch depth: as deep as the accumulators leave registers for
+    constexpr int acc_regs = C::NTAP * NI * NO * 4, set_regs = (C::XSLOTS + C::YSLOTS) * 4;
+    constexpr int budget = (wgrad_occ<KS, NI, NO>() == 1 ? 300 : 200) - acc_regs - 40;
+    constexpr int PF = budget / set_regs >= 4 ? 4 : (budget / set_regs >= 3 ? 3 : 2);
+    auto kern = conv_wgrad_bf16_kernel<KS, NI, NO, PF>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess) {
+            sq_set_error("conv_wgrad_bf16: cannot reserve %d bytes of LDS", C::LDS_BYTES);
+            return SQ_ELAUNCH;
+        }
+        attr_set = true;
+    }
     int gx, tpb;
     int64_t wsf;
-    plan<KS>(N, H, W, Cin, Cout, &gx, &tpb, &wsf);
+    plan<KS, NI, NO>(N, H, W, Cin, Cout, &gx, &tpb, &wsf);
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int npairs = (Cin / 16) * (Cout / 16);
-    hipLaunchKernelGGL(conv_wgrad_bf16_kernel<KS>, dim3(gx, npairs), dim3(256), C::LDS_BYTES, st, x, dy, ws, N, H, W,
-                       Cin, Cout, tiles_x, tiles_y, tiles_x * tiles_y * N, tpb);
+    const int npairs = (Cin / C::CI) * (Cout / C::CO);
+    hipLaunchKernelGGL(kern, dim3(gx, npairs), dim3(256), C::LDS_BYTES, st, x, dy, ws, N, H, W, Cin, Cout, tiles_x,
+                       tiles_y, tiles_x * tiles_y * N, tpb);
     int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_bf16");
     if (rc) return rc;
     const int G = sq_group_size(gx);
     const int64_t total = ((int64_t)KS * KS * Cin * Cout + Cout) * G;
-    hipLaunchKernelGGL(conv_wgrad_bf16_finish_kernel<KS>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, dw,
-                       db, gx, Cin, Cout, G);
+    hipLaunchKernelGGL((conv_wgrad_bf16_finish_kernel<KS, NI, NO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       ws, dw, db, gx, Cin, Cout, G);
     return sq_check_launch("sq_conv2d_nhwc_wgrad_bf16(finish)");
+}
+
+// SQ_WGRAD_BF16_NARROW=1: 16 x 16 channel blocks everywhere (A/B switch for the wider blocks);
+// SQ_WGRAD_BF16_MAX="ni,no": upper bound on the block shape (tuning experiments)
+inline bool narrow_blocks() {
+    static const bool v = [] { const char *e = getenv("SQ_WGRAD_BF16_NARROW"); return e && e[0] == '1'; }();
+    return v;
+}
+inline void max_shape(int *ni, int *no) {
+    static int mi = 0, mo = 0;
+    if (!mi) {
+        mi = 2, mo = 4;
+        const char *e = getenv("SQ_WGRAD_BF16_MAX");
+        if (e && e[0] >= '1' && e[0] <= '2' && e[1] == ',' && (e[2] == '1' || e[2] == '2' || e[2] == '4')) {
+            mi = e[0] - '0';
+            mo = e[2] - '0';
+        }
+    }
+    *ni = mi;
+    *no = mo;
+}
+
+// channel-block shape per layer, from the measured sweep (tools/wgrad_bf16_bench.py under rocprofv3): every
+// launch is bound by the re-read traffic X * Cout/(16 NO) + dY * Cin/(16 NI) at ~4-5 TB/s; 3x3: 32 x 16 channels
+// (32 x 32 needs 36 accumulator blocks = the whole register file at one block per CU, and is slower);
+// 1x1 (transpose-conv backward): 32 x 64
+#define SQ_WGRAD_BF16_DISPATCH(FN, ...)                                                              \
+    do {                                                                                             \
+        const bool wide = !narrow_blocks();                                                          \
+        int mi_, mo_;                                                                                \
+        max_shape(&mi_, &mo_);                                                                       \
+        const bool i2 = wide && mi_ >= 2 && Cin % 32 == 0, o2 = wide && mo_ >= 2 && Cout % 32 == 0,  \
+                   o4 = wide && mo_ >= 4 && Cout % 64 == 0;                                          \
+        if (K == 3) {                                                                                \
+            if (i2) return FN<3, 2, 1>(__VA_ARGS__);                                                 \
+            if (o2) return FN<3, 1, 2>(__VA_ARGS__);                                                 \
+            return FN<3, 1, 1>(__VA_ARGS__);                                                         \
+        }                                                                                            \
+        if (i2 && o4) return FN<1, 2, 4>(__VA_ARGS__);                                               \
+        if (i2 && o2) return FN<1, 2, 2>(__VA_ARGS__);                                               \
+        if (i2) return FN<1, 2, 1>(__VA_ARGS__);                                                     \
+        if (o2) return FN<1, 1, 2>(__VA_ARGS__);                                                     \
+        return FN<1, 1, 1>(__VA_ARGS__);                                                             \
+    } while (0)
+
+int64_t plan_floats(int N, int H, int W, int Cin, int Cout, int K) {
+    int gx, tpb;
+    int64_t wsf = 0;
+#define SQ_PLAN_CALL(KS_, NI_, NO_) (plan<KS_, NI_, NO_>(N, H, W, Cin, Cout, &gx, &tpb, &wsf), wsf)
+    const bool wide = !narrow_blocks();
+    int mi_, mo_;
+    max_shape(&mi_, &mo_);
+    const bool i2 = wide && mi_ >= 2 && Cin % 32 == 0, o2 = wide && mo_ >= 2 && Cout % 32 == 0,
+               o4 = wide && mo_ >= 4 && Cout % 64 == 0;
+    if (K == 3) {
+        if (i2) return SQ_PLAN_CALL(3, 2, 1);
+        if (o2) return SQ_PLAN_CALL(3, 1, 2);
+        return SQ_PLAN_CALL(3, 1, 1);
+    }
+    if (i2 && o4) return SQ_PLAN_CALL(1, 2, 4);
+    if (i2 && o2) return SQ_PLAN_CALL(1, 2, 2);
+    if (i2) return SQ_PLAN_CALL(1, 2, 1);
+    if (o2) return SQ_PLAN_CALL(1, 1, 2);
+    return SQ_PLAN_CALL(1, 1, 1);
+#undef SQ_PLAN_CALL
+}
+
+int launch_any(const __bf16 *x, const __bf16 *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin,
+               int Cout, int K, hipStream_t st) {
+    SQ_WGRAD_BF16_DISPATCH(launch, x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
 }
 
 bool ok_shape(int N, int H, int W, int Cin, int Cout, int K) {
@@ -238,11 +366,7 @@ bool ok_shape(int N, int H, int W, int Cin, int Cout, int K) {
 
 extern "C" int64_t sq_conv2d_nhwc_wgrad_workspace_bf16(int N, int H, int W, int Cin, int Cout, int K) {
     if (!ok_shape(N, H, W, Cin, Cout, K)) return -1;
-    int gx, tpb;
-    int64_t wsf;
-    if (K == 3) plan<3>(N, H, W, Cin, Cout, &gx, &tpb, &wsf);
-    else plan<1>(N, H, W, Cin, Cout, &gx, &tpb, &wsf);
-    return wsf * 4;
+    return plan_floats(N, H, W, Cin, Cout, K) * 4;
 }
 
 // dW (K,K,Cin,Cout) f32 and db (Cout) f32 from bf16 X (N,H,W,Cin) and bf16 dY (N,H,W,Cout).
@@ -254,6 +378,5 @@ extern "C" int sq_conv2d_nhwc_wgrad_bf16(const void *x, const void *dy, float *d
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(workspace);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *yb = reinterpret_cast<const __bf16 *>(dy);
-    return K == 3 ? launch<3>(xb, yb, dw, db, workspace, N, H, W, Cin, Cout, st)
-                  : launch<1>(xb, yb, dw, db, workspace, N, H, W, Cin, Cout, st);
+    return launch_any(xb, yb, dw, db, workspace, N, H, W, Cin, Cout, K, st);
 }
