@@ -329,6 +329,14 @@ int sq_act_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, int act,
  * dx = act'(y) * (mask ? dy / (1 - rate) : 0), y = the activation output that entered the dropout */
 int sq_act_dropout_bwd_bf16(const void *dy, const uint8_t *mask, const void *y, void *dx, int64_t n, float rate,
                             int act, void *stream);
+/* conv + bias + act + dropout in one kernel: the mask is the counter hash of sq_dropout_fwd_bf16 over the flat
+ * NHWC element index (same seed / step_dev semantics, same two roundings => same bits as the two kernels);
+ * no mask tensor is written.  sq_relu_scale_bwd_bf16 is the matching backward for act == ReLU:
+ * dx = y > 0 ? dy * scale : 0 with scale = 1 / (1 - rate)  (y > 0 <=> kept and active). */
+int sq_conv2d_nhwc_fwd_dropout_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H, int W,
+                                    int Cin, int Cout, int K, int act, float rate, uint32_t seed,
+                                    const int32_t *step_dev, void *stream);
+int sq_relu_scale_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, float scale, void *stream);
 /* dX of a convolution whose input was the ReLU output `gate` (same shape as dx): sq_conv2d_nhwc_fwd_bf16 of dy
  * with the transposed packed filter, passed only where gate > 0 (the upstream ReLU backward fused in) */
 int sq_conv2d_nhwc_dgrad_relu_bf16(const void *dy, const void *wp_t, const void *gate, void *dx, int N, int H, int W,

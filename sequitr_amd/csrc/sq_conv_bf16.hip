@@ -23,6 +23,24 @@ constexpr int TH = 16, TW = 16;
 
 __host__ __device__ constexpr int kp_for(int KS, int KC) { return ((KS * KS * KC + 31) / 32) * 32; }
 
+// dropout fused into the epilogue (training conv_block: relu(conv2) -> dropout, unet.py:265-277): the
+// element with flat NHWC index e is kept iff hash32(seed', e) >= thr -- the hash, the threshold and the two
+// roundings (bf16 activation, then * 1/(1-rate) -> bf16) are those of dropout_fwd_bf16_kernel, so the result
+// equals the separate kernels bit for bit.  thr == 0: no dropout.
+struct SqDropEpi {
+    unsigned thr;
+    float inv;
+    unsigned seed;
+    const int *step;
+};
+
+__device__ __forceinline__ unsigned conv_hash32(unsigned a, unsigned b) {       // = hash32 of sq_ops_bf16.hip
+    unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    h += b * 0x27D4EB2Fu; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
+
 template <int BN, int KS, int KC>
 struct CfgB {
     static constexpr int HALO_W = TW + KS - 1;
@@ -116,7 +134,7 @@ template <int BN, int KS, int KC>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const __bf16 *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
     __bf16 *__restrict__ y, int N, int H, int W, int Cin, int Cout, int act, int tiles_x, int tiles_y,
-    int ntiles, int tiles_per_block, const __bf16 *__restrict__ gate) {
+    int ntiles, int tiles_per_block, const __bf16 *__restrict__ gate, SqDropEpi drop) {
     using C = CfgB<BN, KS, KC>;
     constexpr int NR = BN / 16, PAD = KS / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -220,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
 #pragma unroll
         for (int nb = 0; nb < NR; ++nb) acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const unsigned dseed = drop.seed + (drop.step ? (unsigned)drop.step[0] * 0x9E3779B9u : 0u);
     const float slope = act == SQ_ACT_LEAKY ? 0.2f : 1.0f;
     const bool is_relu = act == SQ_ACT_RELU;
     auto actf = [&](float v) {
@@ -257,6 +276,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                 if (gate) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (float)gv[r][j] > 0.f ? o[j] : (__bf16)0.f;
+                }
+                if (drop.thr) {
+                    const unsigned e0 = offs[r] >> 1;          // flat element index (offsets are in bytes)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = conv_hash32(dseed, e0 + j) >= drop.thr ? (__bf16)((float)o[j] * drop.inv) : (__bf16)0.f;
                 }
                 const unsigned off = offs[r];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
@@ -347,7 +372,7 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
 
 template <int BN, int KS, int KC>
 int launch(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int N, int H, int W, int Cin, int Cout,
-           int act, hipStream_t st, const __bf16 *gate) {
+           int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
     using C = CfgB<BN, KS, KC>;
     static bool attr_set = false;
     auto kern = conv_mfma_bf16_kernel<BN, KS, KC>;
@@ -368,16 +393,16 @@ int launch(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int 
     if (tpb < 1) tpb = 1;
     const int gx = (ntiles + tpb - 1) / tpb;
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), C::LDS_BYTES, st, x, wp, bias, y, N, H, W, Cin, Cout, act,
-                       tiles_x, tiles_y, ntiles, tpb, gate);
+                       tiles_x, tiles_y, ntiles, tpb, gate, drop);
     return sq_check_launch("sq_conv2d_nhwc_fwd_bf16");
 }
 
 template <int KS, int KC>
 int dispatch_bn(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int N, int H, int W, int Cin,
-                int Cout, int act, hipStream_t st, const __bf16 *gate = nullptr) {
-    if (Cout >= 64) return launch<64, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate);
-    if (Cout > 16) return launch<32, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate);
-    return launch<16, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate);
+                int Cout, int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
+    if (Cout >= 64) return launch<64, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    if (Cout > 16) return launch<32, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    return launch<16, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
 }
 
 inline int kc_for(int Cin) { return Cin % 32 == 0 ? 32 : 16; }
@@ -421,7 +446,8 @@ extern "C" int sq_conv_pack_weights_multi_bf16(const float *base, void *out, con
 // conv_layer / weighted_conv2d on bf16 tensors: x (N,H,W,Cin) bf16, wp from sq_conv_pack_weights_bf16,
 // bias f32 or NULL, y (N,H,W,Cout) bf16.  Cin % 16 == 0, Cout % 4 == 0.
 static int conv_fwd_bf16_impl(const void *x, const void *wp, const float *bias, void *y, int N, int H, int W, int Cin,
-                              int Cout, int K, int act, void *stream, const void *gate) {
+                              int Cout, int K, int act, void *stream, const void *gate,
+                              const SqDropEpi &drop = SqDropEpi{0u, 1.f, 0u, nullptr}) {
     SQ_REQUIRE(x && wp && y, "sq_conv2d_nhwc_fwd_bf16: null tensor pointer");
     SQ_REQUIRE(N > 0 && H > 0 && W > 0 && (K == 1 || K == 3), "sq_conv2d_nhwc_fwd_bf16: bad shape / K");
     SQ_REQUIRE(Cin % 16 == 0 && Cin > 0 && Cout % 4 == 0 && Cout > 0,
@@ -437,15 +463,31 @@ static int conv_fwd_bf16_impl(const void *x, const void *wp, const float *bias, 
     const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *wb = reinterpret_cast<const __bf16 *>(wp);
     __bf16 *yb = reinterpret_cast<__bf16 *>(y);
     if (kc_for(Cin) == 32)
-        return K == 3 ? dispatch_bn<3, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb)
-                      : dispatch_bn<1, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb);
-    return K == 3 ? dispatch_bn<3, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb)
-                  : dispatch_bn<1, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb);
+        return K == 3 ? dispatch_bn<3, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb, drop)
+                      : dispatch_bn<1, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb, drop);
+    return K == 3 ? dispatch_bn<3, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb, drop)
+                  : dispatch_bn<1, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb, drop);
 }
 
 extern "C" int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H,
                                        int W, int Cin, int Cout, int K, int act, void *stream) {
     return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, K, act, stream, nullptr);
+}
+
+// conv + bias + act + dropout in one kernel (training): y = dropout(act(conv(x))) with the counter-hash mask of
+// sq_dropout_fwd_bf16 (seed, optional device step counter); no mask tensor is written -- for a ReLU the
+// backward can gate on y itself (y > 0 <=> kept and active), see sq_relu_scale_bwd_bf16.
+extern "C" int sq_conv2d_nhwc_fwd_dropout_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H,
+                                               int W, int Cin, int Cout, int K, int act, float rate, uint32_t seed,
+                                               const int32_t *step_dev, void *stream) {
+    SQ_REQUIRE(rate > 0.f && rate < 1.f, "sq_conv2d_nhwc_fwd_dropout_bf16: rate must be in (0, 1)");
+    SqDropEpi d;
+    d.thr = (unsigned)(rate * 4294967296.0);
+    d.inv = 1.0f / (1.0f - rate);
+    d.seed = seed;
+    d.step = step_dev;
+    SQ_REQUIRE(d.thr != 0u, "sq_conv2d_nhwc_fwd_dropout_bf16: rate too small for the 32-bit threshold");
+    return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, K, act, stream, nullptr, d);
 }
 
 // dX of a convolution whose INPUT was the ReLU output `gate` (N,H,W,Cout): the dgrad convolution of dy with

@@ -187,6 +187,18 @@ __global__ __launch_bounds__(256) void dropout_bwd_bf16_kernel(const bf16x8 *__r
     }
 }
 
+// backward of y = dropout(relu(z)) given only y: y > 0 <=> (kept and z > 0), so dx = y > 0 ? dy * scale : 0
+__global__ __launch_bounds__(256) void relu_scale_bwd_bf16_kernel(const bf16x8 *__restrict__ dy, const bf16x8 *__restrict__ y,
+                                                                   bf16x8 *__restrict__ dx, int64_t n8, float scale) {
+    SQ_GRID_STRIDE(i, n8) {
+        const bf16x8 g = dy[i], v = y[i];
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (float)v[j] > 0.f ? (__bf16)((float)g[j] * scale) : (__bf16)0.f;
+        dx[i] = r;
+    }
+}
+
 // dropout backward and the activation backward of the layer in front of it in ONE pass:
 // dx = act'(y) * (keep ? dy / (1 - rate) : 0), y = the activation's output (the dropout's input)
 __global__ __launch_bounds__(256) void act_dropout_bwd_bf16_kernel(const bf16x8 *__restrict__ dy,
@@ -458,6 +470,15 @@ extern "C" int sq_dropout_bwd_bf16(const void *dy, const uint8_t *mask, void *dx
                        reinterpret_cast<const bf16x8 *>(dy), reinterpret_cast<const uint2 *>(mask),
                        reinterpret_cast<bf16x8 *>(dx), n / 8, rate);
     return sq_check_launch("sq_dropout_bwd_bf16");
+}
+
+extern "C" int sq_relu_scale_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, float scale, void *stream) {
+    SQ_REQUIRE(dy && y && dx && n > 0 && n % 8 == 0, "sq_relu_scale_bwd_bf16: bad arguments (n %% 8 == 0)");
+    SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(y); SQ_REQUIRE_ALIGNED(dx);
+    hipLaunchKernelGGL(relu_scale_bwd_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const bf16x8 *>(dy), reinterpret_cast<const bf16x8 *>(y),
+                       reinterpret_cast<bf16x8 *>(dx), n / 8, scale);
+    return sq_check_launch("sq_relu_scale_bwd_bf16");
 }
 
 extern "C" int sq_act_dropout_bwd_bf16(const void *dy, const uint8_t *mask, const void *y, void *dx, int64_t n, float rate,

@@ -1,6 +1,7 @@
 """Differentiable wrappers for the bf16 path (BASELINE configs 3-5): bf16 activations, fp32 master
 weights / biases / gradients-of-weights.  First order only (the U-Net training graph); torch.autograd
 is the tape, every forward and gradient is a HIP kernel of ops_bf16.py."""
+import numpy as np
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -77,14 +78,18 @@ class _ConvBlock(torch.autograd.Function):
         first = x.dtype == torch.float32
         f = w1.shape[3]
         y1 = ob.conv3x3_first(x, w1, b1, act='relu') if first else ob.conv2d(x, ob.pack_weights(w1), b1, 3, f, act='relu')
-        y2 = ob.conv2d(y1, ob.pack_weights(w2), b2, 3, f, act='relu')
-        m = None
-        out = y2
-        if rate > 0.0:
-            out, m = ob.dropout_fwd(y2, rate, seed=seed, mask=mask, step_dev=step_dev)
+        m = y2 = None
+        if rate > 0.0 and mask is None:
+            # conv2 + ReLU + dropout in ONE kernel; neither y2 nor a mask is stored: out > 0 <=> kept and active
+            out = ob.conv2d_dropout(y1, ob.pack_weights(w2), b2, 3, f, 'relu', rate, seed=seed, step_dev=step_dev)
+        else:
+            y2 = ob.conv2d(y1, ob.pack_weights(w2), b2, 3, f, act='relu')
+            out = y2
+            if rate > 0.0:                                      # pinned masks (parity tests): separate kernels
+                out, m = ob.dropout_fwd(y2, rate, seed=seed, mask=mask, step_dev=step_dev)
         ctx.rate, ctx.first = rate, first
         ctx.sinks = (grad_sink(w1), grad_sink(b1), grad_sink(w2), grad_sink(b2))
-        ctx.save_for_backward(x, w1, w2, y1, y2, m)
+        ctx.save_for_backward(x, w1, w2, y1, y2 if m is not None else out, m)
         return out
 
     @staticmethod
@@ -94,7 +99,13 @@ class _ConvBlock(torch.autograd.Function):
         s1w, s1b, s2w, s2b = ctx.sinks
         f = w2.shape[3]
         dout = dout.contiguous()
-        d2 = ob.act_dropout_bwd(dout, m, y2, ctx.rate, 'relu') if m is not None else ob.act_bwd(dout, y2, 'relu')
+        if m is not None:
+            d2 = ob.act_dropout_bwd(dout, m, y2, ctx.rate, 'relu')
+        elif ctx.rate > 0.0:
+            inv = float(np.float32(1.0) / (np.float32(1.0) - np.float32(ctx.rate)))    # as the kernels compute it
+            d2 = ob.relu_scale_bwd(dout, y2, inv)                           # y2 holds the block output here
+        else:
+            d2 = ob.act_bwd(dout, y2, 'relu')
         dw2, db2 = ob.conv2d_wgrad(y1, d2, 3, want_bias=True, dw_out=s2w, db_out=s2b)
         d1 = ob.conv2d_dgrad_relu(d2, ob.pack_weights(w2, transform=True), y1, 3)
         if ctx.first:

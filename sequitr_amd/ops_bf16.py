@@ -54,6 +54,30 @@ def conv2d(x, wp, bias, K, Cout, act=None):
     return y
 
 
+def conv2d_dropout(x, wp, bias, K, Cout, act, rate, seed=0, step_dev=None):
+    """dropout(act(conv(x))) in one kernel; the mask is sq_dropout_fwd_bf16's hash and is not stored."""
+    _chk(x, "x", ndim=4), _chk(wp, "wp")
+    N, H, W, Cin = x.shape
+    if bias is not None:
+        _chk(bias, "bias", dtype=torch.float32)
+    y = torch.empty((N, H, W, Cout), dtype=BF16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_conv2d_nhwc_fwd_dropout_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, K,
+                                                  ACT[act], float(rate), int(seed) & 0xFFFFFFFF, _ptr(step_dev),
+                                                  _stream()), "sq_conv2d_nhwc_fwd_dropout_bf16")
+    return y
+
+
+def relu_scale_bwd(dy, y, scale):
+    """dx = y > 0 ? dy * scale : 0 -- backward of dropout(relu(.)) from its output alone."""
+    _chk(dy, "dy"), _chk(y, "y")
+    dx = torch.empty_like(dy)
+    lib = _lib.load()
+    _lib.check(lib.sq_relu_scale_bwd_bf16(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), float(scale), _stream()),
+               "sq_relu_scale_bwd_bf16")
+    return dx
+
+
 def conv2d_dgrad_relu(dy, wp_t, gate, K):
     """dX of a conv whose input was the ReLU output `gate`: conv(dy, wp_t) passed where gate > 0."""
     _chk(dy, "dy", ndim=4), _chk(wp_t, "wp_t"), _chk(gate, "gate", ndim=4)
