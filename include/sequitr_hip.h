@@ -255,6 +255,14 @@ int sq_mbstd_fwd_f32(const float *x, float *out, float *workspace, int N, int64_
 int sq_mosaic_pack_f32(const float *x, float *m, int N, int H, int W, int C, int R, int Cc, void *stream);
 int sq_mosaic_unpack_f32(const float *m, float *y, int N, int H, int W, int C, int R, int Cc, void *stream);
 
+/* tf.layers.dense with a long reduction and few rows (discriminator_network, gan.py:226-237: 8208 -> 512 on
+ * 32..96 samples): y (M,N) = act(x (M,K) @ fl(w (K,N) * wscale) + bias), the reduction split into 64-wide
+ * slices over thread blocks and the slices added in order (deterministic; not the convolution's single
+ * chain).  K % 4 == 0; workspace sq_dense_workspace_f32 bytes. */
+int64_t sq_dense_workspace_f32(int M, int K, int N);
+int sq_dense_fwd_f32(const float *x, const float *w, const float *bias, float *y, float *workspace, int M, int K, int N,
+                     float wscale, int act, void *stream);
+
 /* M (Ca,Cb) = sum_p a[p,:]^T b[p,:] with Ca <= 4, Cb % 4 == 0: weight gradient of to_image / from_image. */
 int64_t sq_wgrad1x1_small_workspace_f32(int64_t npix, int Ca, int Cb);
 int sq_wgrad1x1_small_f32(const float *a, const float *b, float *m, float *workspace, int64_t npix, int Ca, int Cb,

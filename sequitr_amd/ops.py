@@ -82,6 +82,26 @@ def mosaic_unpack(m, N, H, W, R, Cc):
     return y
 
 
+USE_DENSE = os.environ.get("SQ_DENSE", "1") != "0"        # A/B switch for the split-reduction dense kernel
+
+
+def dense(x, w, bias=None, act=None, wscale=1.0):
+    """y (M,N) = act(x (M,K) @ w (K,N) * wscale + bias): few rows, long reduction (sq_dense_fwd_f32)."""
+    _chk(x, "x", ndim=2), _chk(w, "w", ndim=2)
+    M, K = x.shape
+    N = w.shape[1]
+    if w.shape[0] != K:
+        raise ValueError("dense: weight %s does not match %d inputs" % (tuple(w.shape), K))
+    if bias is not None:
+        _chk(bias, "bias")
+    lib = _lib.load()
+    ws = _workspace(lib.sq_dense_workspace_f32(M, K, N), x.device)
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _lib.check(lib.sq_dense_fwd_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), M, K, N, float(wscale), ACT[act],
+                                   _stream()), "sq_dense_fwd_f32")
+    return y
+
+
 def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None):
     """KxK SAME conv + bias + activation.  x (N,H,W,Cin), w (K,K,Cin,Cout) HWIO.
     Batches of small images (H, W <= 8) run as one mosaic image (3x3) or as a flat pixel strip (1x1):
@@ -95,6 +115,8 @@ def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None):
         _chk(bias, "bias")
         if bias.numel() != Cout:
             raise ValueError("bias must have %d elements" % Cout)
+    if out is None and K == 1 and N * H * W <= 128 and Cin >= 1024 and Cin % 4 == 0 and USE_DENSE:
+        return dense(x.view(N * H * W, Cin), w.view(Cin, Cout), bias, act, wscale).view(N, H, W, Cout)
     if out is None and USE_MOSAIC and W < 16 and N * H > 1:
         P = N * H * W
         if K == 1 and P % 16 == 0:                            # pixels are independent: a free view

@@ -160,3 +160,23 @@ def test_small_image_batches_run_as_mosaic_bit_exact(N, H, W, Cin, Cout, K):
     ref = wt.grad.permute(2, 3, 1, 0).numpy()
     assert np.max(np.abs(dw.cpu().numpy() - ref)) <= 2e-5 * np.max(np.abs(ref))
     assert np.max(np.abs(db.cpu().numpy() - bt.grad.numpy())) <= 2e-5 * np.max(np.abs(bt.grad.numpy()))
+
+
+@pytest.mark.parametrize("M,K,N,act", [(32, 8208, 512, "leaky"), (96, 8208, 512, "leaky"), (5, 1028, 70, None),
+                                       (128, 2048, 256, "relu")])
+def test_dense_split_reduction_vs_fp64(M, K, N, act):
+    """tf.layers.dense of the discriminator (gan.py:226-237): split-reduction kernel vs fp64; also reached
+    through conv2d for a (N,1,1,F) tensor and a 1x1 filter."""
+    rng = np.random.default_rng(M + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = x.astype(np.float64) @ w.astype(np.float64) + b
+    if act == "leaky":
+        ref = np.where(ref > 0, ref, 0.2 * ref)
+    elif act == "relu":
+        ref = np.maximum(ref, 0)
+    y = ops.dense(dev(x), dev(w), dev(b), act=act).cpu().numpy()
+    assert np.max(np.abs(y - ref)) <= 2e-5 * np.max(np.abs(ref))
+    y2 = ops.conv2d(dev(x.reshape(M, 1, 1, K)), dev(w.reshape(1, 1, K, N)), dev(b), act=act).cpu().numpy()
+    assert_bit_exact(y2.reshape(M, N), y, "conv2d routes dense layers to the same kernel")
