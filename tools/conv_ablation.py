@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Ablation builds of the f32 conv kernel (timing only -- results are wrong by construction): where does the
+gap between the loop skeleton (91-95 % of the MFMA peak, tools/mfma_probe.hip) and the real kernel go?
+  python tools/conv_ablation.py build     # here (hipcc cross-compiles): tools/_exp/<variant>/libsequitr_hip.so
+  python tools/conv_ablation.py run       # on the GPU box: times the level-0/1/2 layers with every variant
+"""
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "sequitr_amd", "csrc", "sq_conv_f32_v2.hip")
+VARIANTS = {
+    "base": [],
+    "nostore": [("const unsigned off = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 4) : OOB;",
+                 "const unsigned off = OOB; (void)ok;")],
+    "noload": [("const unsigned off = inb ? (unsigned)(base + xrel[sl]) : OOB;", "const unsigned off = OOB; (void)inb; (void)base;")],
+}
+VARIANTS["noload_nostore"] = VARIANTS["nostore"] + VARIANTS["noload"]
+
+
+def build():
+    objs = [o for o in glob.glob(os.path.join(ROOT, "sequitr_amd", "_build", "*.o")) if not o.endswith("sq_conv_f32_v2.o")]
+    src = open(SRC).read()
+    for name, patches in VARIANTS.items():
+        d = os.path.join(ROOT, "tools", "_exp", name)
+        os.makedirs(d, exist_ok=True)
+        s = src
+        for a, b in patches:
+            assert a in s, (name, a)
+            s = s.replace(a, b)
+        fn = os.path.join(ROOT, "sequitr_amd", "csrc", "_exp_%s.hip" % name)
+        open(fn, "w").write(s)
+        try:
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
+                                   "-Wno-unused-value", "-c", fn, "-o", os.path.join(d, "v2.o")])
+        finally:
+            os.remove(fn)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o",
+                               os.path.join(d, "libsequitr_hip.so"), os.path.join(d, "v2.o")] + objs)
+        print("built", name)
+
+
+def run_one(name):
+    sys.path.insert(0, ROOT)
+    import torch
+    from sequitr_amd import _lib
+    if name != "prod":                                     # "prod" = the library as built in sequitr_amd/_build
+        _lib.LIB_PATH = os.path.join(ROOT, "tools", "_exp", name, "libsequitr_hip.so")
+    from sequitr_amd import ops
+    dev = "cuda:0"
+    out = []
+    for (n, h, ci, co) in [(32, 512, 16, 16), (32, 256, 32, 32), (32, 128, 64, 64), (32, 32, 256, 256)]:
+        x = torch.randn(n, h, h, ci, device=dev)
+        w = torch.randn(3, 3, ci, co, device=dev) * 0.05
+        b = torch.zeros(co, device=dev)
+        for _ in range(3):
+            ops.conv2d(x, w, b, act="relu")
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20):
+            ops.conv2d(x, w, b, act="relu")
+        e.record()
+        torch.cuda.synchronize()
+        us = s.elapsed_time(e) / 20 * 1e3
+        tf = 2.0 * n * h * h * 9 * ci * co / us / 1e6
+        out.append("%6.1f us %5.1f TF" % (us, tf))
+    print("%-16s %s" % (name, " | ".join(out)), flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    elif sys.argv[1] == "run":
+        for v in ["prod"] + list(VARIANTS):                  # one process per variant: the library is loaded once
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "one", v])
+    else:
+        run_one(sys.argv[2])

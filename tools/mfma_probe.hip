@@ -1,0 +1,114 @@
+// Micro-probe for the f32 MFMA convolution loop structure (gfx950): what fraction of the MFMA peak do
+// (A) bare v_mfma_f32_16x16x4_f32 chains, (B) + the per-step LDS fragment reads of the BN=16/32/64 conv tiles,
+// (C) + a block barrier / LDS commit every 36 steps reach at 1-4 blocks per CU?
+//   hipcc -O3 --offload-arch=gfx950 tools/mfma_probe.hip -o gpurun_out/mfma_probe && gpurun_out/mfma_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NR, int MODE>
+__global__ __launch_bounds__(256) void probe(float *out, int iters, int lds_floats) {
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kk = lane >> 4;
+    for (int i = tid; i < lds_floats; i += 256) smem[i] = 1.0f + (i & 7) * 0.125f;
+    __syncthreads();
+    f32x4 acc[4][NR];
+    for (int r = 0; r < 4; ++r)
+        for (int nb = 0; nb < NR; ++nb) acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float *xb = smem + ((4 * wv) * 18 + li) * 18 + kk;       // halo image, pixel stride 18
+    const float *wa = smem + 324 * 18 + kk * (NR * 16 + (NR > 1 ? 16 : 0)) + li;
+    const int BNS = NR * 16 + (NR > 1 ? 16 : 0);
+    float a0[NR], b0[4];
+    for (int nb = 0; nb < NR; ++nb) a0[nb] = 1.0f + nb;
+    for (int r = 0; r < 4; ++r) b0[r] = 0.5f + r;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int st = 0; st < 36; ++st) {
+            float a1[NR], b1[4];
+            if (MODE >= 1) {
+                const int tap = st / 4, s = st % 4, ky = tap / 3, kx = tap % 3;
+#pragma unroll
+                for (int nb = 0; nb < NR; ++nb) a1[nb] = wa[(tap * 16 + s * 4) * BNS + nb * 16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b1[r] = xb[((r + ky) * 18 + kx) * 18 + s * 4];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NR; ++nb)
+                    acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nb], b0[r], acc[r][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE >= 1) {
+#pragma unroll
+                for (int nb = 0; nb < NR; ++nb) a0[nb] = a1[nb];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b0[r] = b1[r];
+            }
+        }
+        if (MODE >= 2) {
+            __syncthreads();
+            // commit-like: 6 x ds_write_b64 pairs per thread into the halo image
+#pragma unroll
+            for (int sl = 0; sl < 6; ++sl) {
+                const int idx = tid + sl * 256;
+                if (idx < 1296) {
+                    float *d = smem + (idx / 4) * 18 + (idx % 4) * 4;
+                    *reinterpret_cast<float2 *>(d) = make_float2(1.0f, 1.25f);
+                    *reinterpret_cast<float2 *>(d + 2) = make_float2(1.5f, 1.75f);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float s = 0.f;
+    for (int r = 0; r < 4; ++r)
+        for (int nb = 0; nb < NR; ++nb) s += acc[r][nb][0] + acc[r][nb][3];
+    if (s == 12345.678f) out[0] = s;
+}
+
+template <int NR, int MODE>
+void run(const char *name, int occ) {
+    const int lds_floats = 324 * 18 + 144 * (NR * 16 + (NR > 1 ? 16 : 0));
+    const int lds = lds_floats * 4;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(probe<NR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    float *out;
+    hipMalloc(&out, 4);
+    const int iters = 400, blocks = 256 * occ;
+    hipEvent_t s, e;
+    hipEventCreate(&s);
+    hipEventCreate(&e);
+    hipLaunchKernelGGL((probe<NR, MODE>), dim3(blocks), dim3(256), lds, 0, out, 10, lds_floats);
+    hipDeviceSynchronize();
+    hipEventRecord(s);
+    hipLaunchKernelGGL((probe<NR, MODE>), dim3(blocks), dim3(256), lds, 0, out, iters, lds_floats);
+    hipEventRecord(e);
+    hipEventSynchronize(e);
+    float ms;
+    hipEventElapsedTime(&ms, s, e);
+    const double flops = (double)blocks * 4 * iters * 36 * 4 * NR * 2048.0;
+    printf("%-28s NR=%d occ=%d  %8.3f ms  %7.1f TFLOP/s  (%.1f%% of 157.3)\n", name, NR, occ, ms, flops / ms / 1e9,
+           flops / ms / 1e9 / 157.3 * 100);
+    hipFree(out);
+}
+
+int main() {
+    for (int occ = 1; occ <= 4; ++occ) {
+        run<1, 0>("A bare mfma", occ);
+        run<1, 1>("B +LDS fragments", occ);
+        run<1, 2>("C +barrier/commit", occ);
+    }
+    for (int occ = 1; occ <= 3; ++occ) {
+        run<2, 0>("A bare mfma", occ);
+        run<2, 1>("B +LDS fragments", occ);
+        run<2, 2>("C +barrier/commit", occ);
+    }
+    for (int occ = 1; occ <= 2; ++occ) {
+        run<4, 0>("A bare mfma", occ);
+        run<4, 1>("B +LDS fragments", occ);
+        run<4, 2>("C +barrier/commit", occ);
+    }
+    return 0;
+}
