@@ -42,12 +42,17 @@ class ConvTimer(object):
     such launch is bracketed by HIP events on the stream it is launched on (torch's current stream
     IS the launch stream).  FLOPs are the algorithmic ones of the convolutions the launch computes."""
 
-    NAMES = ("conv2d", "conv3x3_pool", "conv3x3_head", "conv3x3_first_block")
+    NAMES = ("conv2d", "conv3x3_pool", "conv3x3_head", "conv3x3_first_block", "convT_conv3x3")
 
-    def __init__(self, ops_mod):
+    def __init__(self, ops_mod, expected_launches=0):
         self.ops = ops_mod
         self.orig = {n: getattr(ops_mod, n) for n in self.NAMES}
         self.records = []        # (start_event, end_event, flops)
+        # events are created BEFORE the timed region: hipEventCreate in the launch path costs host time
+        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * expected_launches)]
+
+    def _event(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
 
     @staticmethod
     def _flops(name, a):
@@ -55,6 +60,10 @@ class ConvTimer(object):
         n, h, w = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
         if name == "conv3x3_first_block":                     # conv1 (1->16) + conv2 (16->16), one launch
             return mfma_conv_flops(n, h, w, 1, 16, 3) + mfma_conv_flops(n, h, w, 16, 16, 3)
+        if name == "convT_conv3x3":                           # transpose conv (32->16 at the skip's size) + 3x3 conv
+            sk = a[3]
+            n, h, w = int(sk.shape[0]), int(sk.shape[1]), int(sk.shape[2])
+            return 2.0 * n * h * w * 32 * 16 + mfma_conv_flops(n, h, w, 16, 16, 3)
         wt = a[1]
         cin, cout, k = int(wt.shape[2]), int(wt.shape[3]), int(wt.shape[0])
         if name == "conv2d" and not ((cin % 16 == 0 or cin == 8) and not (k == 1 and cout <= 4)):
@@ -72,7 +81,7 @@ class ConvTimer(object):
                 fl = self._flops(name, a)
                 if fl is None:
                     return orig(*a, **kw)
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s, e = self._event(), self._event()
                 s.record()
                 y = orig(*a, **kw)
                 e.record()
@@ -459,6 +468,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="training dtype (--mode train)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive rate (infer mode)")
     ap.add_argument("--graph", type=int, default=1, help="--mode train: replay the step as hipGraphs (1) or eager (0)")
     ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
     ap.add_argument("--mode", choices=["infer", "train", "gan", "centroids", "weightmap", "frontend"], default="infer",
@@ -509,7 +519,7 @@ def main():
     for _ in range(args.warmup):
         net.predict(x)
     barrier()
-    with ConvTimer(ops) as ct:
+    with ConvTimer(ops, expected_launches=20 * args.steps) as ct:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             net.predict(x)
@@ -557,7 +567,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(weights, params, gpu_net=net)
-        if world == 1:
+        if world == 1 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end_rate(net, x)
         print(json.dumps(out))
     if dist is not None:

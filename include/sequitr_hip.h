@@ -291,6 +291,15 @@ int sq_conv3x3_first_block_fwd_f32(const float *x, const float *w1, const float 
                                    const float *b2, float *y, float *pooled, int N, int H, int W,
                                    void *stream);
 
+/* conv_transpose_layer + bridge + first conv_layer of up0 (unet.py:299-322) for the level-0 shape: the
+ * transpose conv (32 -> 16 channels) and the bridge are evaluated for each tile's halo inside the 3x3
+ * convolution's staging; the up-scaled / merged tensor never reaches HBM.
+ *   x_low (N,H/2,W/2,32); wt (2,2,16,32) TF layout, bt (16) or NULL; skip (N,H,W,16); bridge SQ_BRIDGE_*;
+ *   w (3,3,16,16), bias (16) or NULL; y (N,H,W,16) = act(conv3x3(bridge(convT(x_low) + bt, skip)) + bias).
+ * Same bits as sq_convT2x2s2_nhwc_fwd_f32 followed by sq_conv2d_nhwc_fwd_f32. */
+int sq_convT_conv3x3_fwd_f32(const float *x_low, const float *wt, const float *bt, const float *skip, int bridge,
+                             const float *w, const float *bias, float *y, int N, int H, int W, int act, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * bf16 path (BASELINE configs 3-5: bf16 compute, fp32 master weights and accumulation).
  * bf16 tensors are passed as void* (2-byte elements, NHWC); biases / logits / weight grads stay f32.

@@ -16,6 +16,11 @@
 //   * FIRST: the 1 -> 16 channel first convolution of down0 (unet.py:238, conv_block conv1)
 //     is evaluated on the fly for the 18x18 halo of each tile (VALU, hidden under other waves'
 //     MFMAs) and never touches HBM: the level-0 block reads 4 B/pixel instead of 64.
+//   * UP: conv_transpose_layer + bridge of up0 (unet.py:312-319) are evaluated on the fly for the halo of the
+//     following conv: the block loads the SKIP halo (the usual prefetch) plus a 10x10x32 low-resolution patch,
+//     wave w computes parity class w of the 2x2/s2 transpose conv on the matrix cores (A = its 16x32 slice of
+//     the kernel, in registers) and merges it into the halo image in LDS.  The up-scaled / merged level-0
+//     tensor (537 MB per 32-tile batch) is never written or re-read and the HBM-bound convT launch disappears.
 #include "sq_common.h"
 
 struct SqConvEpi {
@@ -28,6 +33,10 @@ struct SqConvEpi {
     int store_y;
     const float *first_w;   // FIRST only: (3,3,1,16) and (16)
     const float *first_b;
+    const float *up_x;      // UP only: low-resolution input (N,H/2,W/2,32)
+    const float *up_w;      //          transpose-conv kernel (2,2,16,32) and bias (16)
+    const float *up_b;
+    int up_bridge;          //          SQ_BRIDGE_*: merged = bridge(convT(up_x), x)
 };
 
 namespace {
@@ -48,8 +57,13 @@ struct Cfg2 {
     static constexpr int IN_FLOATS = IN_W * IN_W;           // 400 (16-B multiple)
     static constexpr int HEAD_PS = 18;                      // head scratch: [16 pixels][16 ch + 2]: conflict-free reads
     static constexpr int HEAD_FLOATS = 4 * 16 * HEAD_PS;    // one 16x16 image per wave
+    static constexpr int UP_CIN = 32;                       // UP: channels of the low-resolution input
+    static constexpr int UP_W = TW / 2 + 2;                 // UP: 10x10 low-resolution patch under the 18x18 halo
+    static constexpr int UP_PS = UP_CIN + 2;                // its pixel stride: conflict-free B reads
+    static constexpr int UP_FLOATS = UP_W * UP_W * UP_PS;   // 3400 floats
     static constexpr int LDS_BYTES = (XS_FLOATS + WS_FLOATS) * 4;
     static constexpr int LDS_BYTES_FIRST = (XS_FLOATS + WS_FLOATS + IN_FLOATS) * 4;
+    static constexpr int LDS_BYTES_UP = (XS_FLOATS + WS_FLOATS + UP_FLOATS) * 4;
     static constexpr int QPP = KC / 4;                      // float4 per halo pixel
     static constexpr int XITEMS = HP * QPP;
     static constexpr int XSLOTS = (XITEMS + 255) / 256;
@@ -61,20 +75,22 @@ struct Cfg2 {
     static_assert((WS_FLOATS * 4) % 16 == 0, "input patch must start 16-B aligned");
 };
 
-template <int BN, int KS, int KC, bool FIRST>
-__global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2_kernel(
+template <int BN, int KS, int KC, int MODE>            // MODE 0 plain, 1 FIRST, 2 UP
+__global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
     float *__restrict__ y, int N, int H, int W, int Cin, int Cout, float wscale, int act,
     int tiles_x, int tiles_y, int ntiles, int tiles_per_block, SqConvEpi epi) {
     using C = Cfg2<BN, KS, KC>;
+    constexpr bool FIRST = MODE == 1, UP = MODE == 2;
     constexpr int NR = BN / 16;
     constexpr int PAD = KS / 2;
-    static_assert(!FIRST || (BN == 16 && KS == 3 && KC == 16), "FIRST is the 1->16->16 level-0 block");
+    static_assert(MODE == 0 || (BN == 16 && KS == 3 && KC == 16), "FIRST / UP are level-0 blocks (16 channels)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xs = smem;
     float *ws = smem + C::XS_FLOATS;
     float *xin = ws + C::WS_FLOATS;                         // FIRST only
-    float *head_scratch = ws + C::WS_FLOATS + (FIRST ? C::IN_FLOATS : 0);   // only when epi.head_w
+    float *xl = ws + C::WS_FLOATS;                          // UP only: low-resolution patch [100 px][34]
+    float *head_scratch = ws + C::WS_FLOATS + (FIRST ? C::IN_FLOATS : (UP ? C::UP_FLOATS : 0));   // only when epi.head_w
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
@@ -90,6 +106,7 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
     float4 xr[C::XSLOTS];
     float4 wr[C::WSLOTS];
     float inr[2];                                           // FIRST: 400 input pixels over 256 threads
+    float4 lr[4];                                           // UP: 100 px x 8 float4 of the low-res patch over 256 threads
 
     // Buffer resources: out-of-range offsets read as 0 / drop the store, so image borders,
     // ragged tiles and the "idx >= items" tail need no branches (hipcc otherwise wraps every
@@ -101,6 +118,8 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
         const_cast<float *>(w), 0, KS * KS * (FIRST ? 16 : Cin) * Cout * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
         y, 0, y ? (int)((size_t)N * H * W * Cout * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(epi.up_x), 0, UP ? (int)((size_t)N * (H / 2) * (W / 2) * C::UP_CIN * 4) : 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;   // tensors are < 2 GiB (checked on the host)
     const int CinW = FIRST ? 16 : Cin;      // input channels of the MFMA convolution
 
@@ -151,6 +170,20 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
                 xr[sl] = *reinterpret_cast<const float4 *>(&v);
             }
         }
+        if constexpr (UP) {
+            // low-resolution patch: rows 8 ty - 1 .. 8 ty + 8 (the 18 halo rows start at the odd row 16 ty - 1)
+            const int ly0 = ty * (TH / 2) - 1, lx0 = tx * (TW / 2) - 1, Hl = H >> 1, Wl = W >> 1;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int idx = tid + sl * 256, lp = idx >> 3, q = idx & 7;
+                const int ly = lp / C::UP_W, lx = lp % C::UP_W;
+                const bool inb = idx < C::UP_W * C::UP_W * 8 && (unsigned)(ly0 + ly) < (unsigned)Hl &&
+                                 (unsigned)(lx0 + lx) < (unsigned)Wl;
+                const unsigned off = inb ? (unsigned)((((n * Hl + ly0 + ly) * Wl + lx0 + lx) * C::UP_CIN + q * 4) * 4) : OOB;
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, off, 0, 0);
+                lr[sl] = *reinterpret_cast<const float4 *>(&v);
+            }
+        }
         if (want_w) {
             const int wbase = cc * Cout * 4;
 #pragma unroll
@@ -178,6 +211,17 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
                     float *d = xs + pix * C::PS + q * 4;
                     *reinterpret_cast<float2 *>(d) = make_float2(xr[sl].x, xr[sl].y);
                     *reinterpret_cast<float2 *>(d + 2) = make_float2(xr[sl].z, xr[sl].w);
+                }
+            }
+        }
+        if constexpr (UP) {
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int idx = tid + sl * 256, lp = idx >> 3, q = idx & 7;
+                if (idx < C::UP_W * C::UP_W * 8) {
+                    float *d = xl + lp * C::UP_PS + q * 4;
+                    *reinterpret_cast<float2 *>(d) = make_float2(lr[sl].x, lr[sl].y);
+                    *reinterpret_cast<float2 *>(d + 2) = make_float2(lr[sl].z, lr[sl].w);
                 }
             }
         }
@@ -233,6 +277,52 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
                 float *d = xs + pix * C::PS + 4 * kk;
                 *reinterpret_cast<float2 *>(d) = make_float2(v0, v1);
                 *reinterpret_cast<float2 *>(d + 2) = make_float2(v2, v3);
+            }
+        }
+    };
+
+    // ---- UP: merged = bridge(convT2x2s2(up_x) + bias, skip) for the 18x18 halo, in place in the halo image.
+    // Wave w owns parity class (a, b) = (w >> 1, w & 1) of the transpose conv: its 81 halo pixels in 6 column
+    // blocks of 16; per block 8 MFMA steps over the 32 input channels (one fmaf chain c = 0..31 per output,
+    // then + bias, then the bridge: exactly sq_convT2x2s2_nhwc_fwd_f32 / the oracle).  A = the class's 16x32
+    // kernel slice, held in registers for the whole launch.
+    float aw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 upb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (UP) {
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) aw[s8] = epi.up_w[(wv * 16 + li) * C::UP_CIN + 4 * s8 + kk];
+        if (epi.up_b) upb = *reinterpret_cast<const float4 *>(epi.up_b + 4 * kk);
+    }
+    auto up_conv = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+        const int pa = wv >> 1, pb = wv & 1;
+        // halo row hy has parity (hy + 1) & 1 (global row 16 ty - 1 + hy): class rows are hy = 2 jy + ((pa + 1) & 1)
+        const int oy = (pa + 1) & 1, ox = (pb + 1) & 1;
+#pragma nounroll
+        for (int blk = 0; blk < 6; ++blk) {
+            const int j = blk * 16 + li, jc = j < 81 ? j : 80;
+            const int hy = 2 * (jc / 9) + oy, hx = 2 * (jc % 9) + ox;
+            const float *src = xl + (((hy + 1) >> 1) * C::UP_W + ((hx + 1) >> 1)) * C::UP_PS + kk;
+            f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s8], src[4 * s8], c1, 0, 0, 0);
+            const int gy = ty * TH - 1 + hy, gx = tx * TW - 1 + hx;
+            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            if (j < 81) {
+                float *d = xs + (hy * C::HALO_W + hx) * C::PS + 4 * kk;
+                const float2 s01 = *reinterpret_cast<const float2 *>(d), s23 = *reinterpret_cast<const float2 *>(d + 2);
+                const float u[4] = {c1[0] + upb.x, c1[1] + upb.y, c1[2] + upb.z, c1[3] + upb.w};
+                const float sk[4] = {s01.x, s01.y, s23.x, s23.y};
+                float m[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = epi.up_bridge == SQ_BRIDGE_ADD ? u[e] + sk[e]
+                                  : (epi.up_bridge == SQ_BRIDGE_MUL ? u[e] * sk[e]
+                                  : (epi.up_bridge == SQ_BRIDGE_SUB ? u[e] - sk[e] : u[e]));
+                    m[e] = inside ? v : 0.f;                // outside the image = the conv's zero padding
+                }
+                *reinterpret_cast<float2 *>(d) = make_float2(m[0], m[1]);
+                *reinterpret_cast<float2 *>(d + 2) = make_float2(m[2], m[3]);
             }
         }
     };
@@ -363,6 +453,10 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
         first_conv(t_begin);
         __syncthreads();
     }
+    if constexpr (UP) {
+        up_conv(t_begin);
+        __syncthreads();
+    }
 
     int tile = t_begin, chunk = 0;
     for (int it = 0; it < nitems; ++it) {
@@ -408,6 +502,10 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
                 __syncthreads();        // the 20x20 patch is complete
                 first_conv(ntile);
             }
+            if constexpr (UP) {
+                __syncthreads();        // skip halo and low-resolution patch are complete
+                up_conv(ntile);
+            }
         }
         if (chunk == nchunk - 1) epilogue(tile);
         if (has_next) __syncthreads();
@@ -416,14 +514,15 @@ __global__ __launch_bounds__(256, (Cfg2<BN, KS, KC>::OCC)) void conv_mfma_f32_v2
     }
 }
 
-template <int BN, int KS, int KC, bool FIRST>
+template <int BN, int KS, int KC, int MODE>
 int launch_v2(const float *x, const float *w, const float *bias, float *y, int N, int H, int W, int Cin,
               int Cout, float wscale, int act, const SqConvEpi &epi, hipStream_t st) {
     using C = Cfg2<BN, KS, KC>;
     static bool attr_set = false;
-    auto kern = conv_mfma_f32_v2_kernel<BN, KS, KC, FIRST>;
-    constexpr int lds_max = (FIRST ? C::LDS_BYTES_FIRST : C::LDS_BYTES) + C::HEAD_FLOATS * 4;
-    const int lds = (FIRST ? C::LDS_BYTES_FIRST : C::LDS_BYTES) + (epi.head_w ? C::HEAD_FLOATS * 4 : 0);
+    auto kern = conv_mfma_f32_v2_kernel<BN, KS, KC, MODE>;
+    constexpr int lds_base = MODE == 1 ? C::LDS_BYTES_FIRST : (MODE == 2 ? C::LDS_BYTES_UP : C::LDS_BYTES);
+    constexpr int lds_max = lds_base + C::HEAD_FLOATS * 4;
+    const int lds = lds_base + (epi.head_w ? C::HEAD_FLOATS * 4 : 0);
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) {
@@ -436,7 +535,7 @@ int launch_v2(const float *x, const float *w, const float *bias, float *y, int N
     const int ntiles = tiles_x * tiles_y * N;
     const int gy = (Cout + BN - 1) / BN;
     // persistent grid: about OCC resident blocks per CU over both grid dimensions
-    int want = (256 * C::OCC + gy - 1) / gy;
+    int want = (256 * (MODE == 2 ? 3 : C::OCC) + gy - 1) / gy;
     if (want < 1) want = 1;
     int tpb = (ntiles + want - 1) / want;
     if (tpb < 1) tpb = 1;
@@ -531,4 +630,26 @@ extern "C" int sq_conv3x3_first_block_fwd_f32(const float *x, const float *w1, c
     epi.first_w = w1; epi.first_b = b1;
     return launch_v2<16, 3, 16, true>(x, w2, b2, y, N, H, W, 1, 16, 1.0f, SQ_ACT_RELU, epi,
                                       reinterpret_cast<hipStream_t>(stream));
+}
+
+// conv_transpose_layer + bridge + first conv_layer of up0 (unet.py:299-322) in one kernel, for the level-0
+// shape (transpose conv 32 -> 16 channels, 3x3 conv 16 -> 16): y = act(conv3x3(bridge(convT2x2s2(x_low) + bt,
+// skip)) + bias).  x_low (N,H/2,W/2,32); wt (2,2,16,32) TF layout; skip, y (N,H,W,16); bridge = SQ_BRIDGE_*.
+// Bit-identical to sq_convT2x2s2_nhwc_fwd_f32 followed by sq_conv2d_nhwc_fwd_f32.
+extern "C" int sq_convT_conv3x3_fwd_f32(const float *x_low, const float *wt, const float *bt, const float *skip,
+                                        int bridge, const float *w, const float *bias, float *y, int N, int H, int W,
+                                        int act, void *stream) {
+    SQ_REQUIRE(x_low && wt && skip && w && y, "sq_convT_conv3x3_fwd_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "sq_convT_conv3x3_fwd_f32: H, W must be even");
+    SQ_REQUIRE(bridge >= SQ_BRIDGE_NONE && bridge <= SQ_BRIDGE_SUB, "sq_convT_conv3x3_fwd_f32: bad bridge %d", bridge);
+    SQ_REQUIRE(fits32(N, H, W, 16), "sq_convT_conv3x3_fwd_f32: tensors must be < 2 GiB");
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_convT_conv3x3_fwd_f32: bad activation %d", act);
+    SQ_REQUIRE_ALIGNED(x_low); SQ_REQUIRE_ALIGNED(skip); SQ_REQUIRE_ALIGNED(w); SQ_REQUIRE_ALIGNED(y);
+    if (bias) SQ_REQUIRE_ALIGNED(bias);
+    if (bt) SQ_REQUIRE_ALIGNED(bt);
+    SqConvEpi epi = {};
+    epi.store_y = 1;
+    epi.up_x = x_low; epi.up_w = wt; epi.up_b = bt; epi.up_bridge = bridge;
+    return launch_v2<16, 3, 16, 2>(skip, w, bias, y, N, H, W, 16, 16, 1.0f, act, epi,
+                                   reinterpret_cast<hipStream_t>(stream));
 }

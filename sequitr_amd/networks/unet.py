@@ -270,6 +270,7 @@ class UNet2D(UNet):
         self._builds = 0                                      # host-side step salt when no device counter is set
         self.dropout_masks = None
         self.fuse = bool(params.get('fuse', True))          # fused inference kernels (same bits)
+        self.fuse_up = bool(params.get('fuse_up', True))    # ... incl. convT+bridge inside up0's first conv
         # optional BN between conv and ReLU (tf.layers.batch_normalization defaults)
         self.up_kernel = tuple(params.get('up_kernel', (2, 2)))   # transpose-conv kernel: (2,2) default or (3,3)
         if self.up_kernel not in ((2, 2), (3, 3)):
@@ -464,10 +465,14 @@ class UNet2D(UNet):
         for i in reversed(range(L - 1)):                           # decoder
             s = 'UNet/up%d' % i
             wt, bt = self._v(s + '/upscale', 'kernel', (2, 2, f[i], f[i + 1])), self._v(s + '/upscale', 'bias', (f[i],))
-            merged = ops.convT2x2s2(net[-1], wt, bt, skip=net[i], bridge=self.bridge_type)
             w1, b1 = self._v(s + '/conv1', 'kernel', (3, 3, f[i], f[i])), self._v(s + '/conv1', 'bias', (f[i],))
             w2, b2 = self._v(s + '/conv2', 'kernel', (3, 3, f[i], f[i])), self._v(s + '/conv2', 'bias', (f[i],))
-            c1 = ops.conv2d(merged, w1, b1, act='relu')
+            if f[i] == 16 and f[i + 1] == 32 and self.fuse_up:
+                # level 0: transpose conv + bridge are computed in the staging of conv1 (never reach HBM)
+                c1 = ops.convT_conv3x3(net[-1], wt, bt, net[i], self.bridge_type, w1, b1, act='relu')
+            else:
+                merged = ops.convT2x2s2(net[-1], wt, bt, skip=net[i], bridge=self.bridge_type)
+                c1 = ops.conv2d(merged, w1, b1, act='relu')
             if i == 0 and head_fused:
                 wh = self._v('UNet/to_image', 'kernel', (1, 1, f[0], self.n_outputs))
                 bh = self._v('UNet/to_image', 'bias', (self.n_outputs,))

@@ -620,6 +620,26 @@ def conv3x3_head(x, w, bias, head_w, head_b, act="relu", want_mask=True):
     return logits, mask
 
 
+def convT_conv3x3(x_low, wt, bt, skip, bridge, w, bias, act="relu"):
+    """up0 of the U-Net in one kernel: act(conv3x3(bridge(convT2x2s2(x_low) + bt, skip)) + bias) for the
+    level-0 shape (x_low (N,H/2,W/2,32), wt (2,2,16,32), skip (N,H,W,16), w (3,3,16,16))."""
+    _chk(x_low, "x_low", ndim=4), _chk(wt, "wt", ndim=4), _chk(skip, "skip", ndim=4), _chk(w, "w", ndim=4)
+    N, H, W, C = skip.shape
+    if C != 16 or tuple(x_low.shape) != (N, H // 2, W // 2, 32) or tuple(wt.shape) != (2, 2, 16, 32) \
+            or tuple(w.shape) != (3, 3, 16, 16) or H % 2 or W % 2:
+        raise ValueError("convT_conv3x3 is the level-0 block: x_low (N,H/2,W/2,32), skip (N,H,W,16)")
+    if bt is not None:
+        _chk(bt, "bt")
+    if bias is not None:
+        _chk(bias, "bias")
+    y = torch.empty((N, H, W, 16), dtype=torch.float32, device=skip.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_convT_conv3x3_fwd_f32(_ptr(x_low), _ptr(wt), _ptr(bt), _ptr(skip), BRIDGE[bridge], _ptr(w),
+                                           _ptr(bias), _ptr(y), N, H, W, ACT[act], _stream()),
+               "sq_convT_conv3x3_fwd_f32")
+    return y
+
+
 def conv3x3_first_block(x, w1, b1, w2, b2, want_pool=True):
     """down0 conv_block for a 1-channel input: relu(conv2(relu(conv1(x)))) -> (y, pooled or None)."""
     _chk(x, "x", ndim=4), _chk(w1, "w1", ndim=4), _chk(w2, "w2", ndim=4), _chk(b1, "b1"), _chk(b2, "b2")

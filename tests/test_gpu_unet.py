@@ -170,3 +170,24 @@ def test_up_kernel_3x3_transpose_conv_bit_exact_and_trainable():
     g = t.grads()
     for k in rgrads:
         assert np.max(np.abs(g[k] - rgrads[k])) <= 1e-3 * np.max(np.abs(rgrads[k])) + 1e-7, k
+
+
+@pytest.mark.parametrize("bridge", ["eltwise_mul", "eltwise_add", "eltwise_sub", None])
+@pytest.mark.parametrize("shape", [(2, 32, 32), (1, 48, 80), (3, 16, 16)])
+def test_convT_bridge_conv_fused_kernel_bit_exact(bridge, shape):
+    """sq_convT_conv3x3_fwd_f32 (up0: transpose conv + bridge inside the conv's staging) vs the oracle's
+    convT -> bridge -> conv, bit for bit, incl. ragged tiles and image borders."""
+    from oracle import c_oracle as co
+    from tests.util import rand_weights
+    N, H, W = shape
+    rng = np.random.default_rng(H + W)
+    xl = rng.standard_normal((N, H // 2, W // 2, 32)).astype(np.float32)
+    skip = rng.standard_normal((N, H, W, 16)).astype(np.float32)
+    wt = rand_weights(1, (2, 2, 16, 32), 0.2)
+    bt = rand_weights(2, (16,), 0.1)
+    w = rand_weights(3, (3, 3, 16, 16))
+    b = rand_weights(4, (16,), 0.1)
+    d = lambda a: torch.from_numpy(a).to("cuda:0")
+    y = ops.convT_conv3x3(d(xl), d(wt), d(bt), d(skip), bridge, d(w), d(b), act="relu")
+    merged = co.convT2x2s2(xl, wt, bt, skip=skip if bridge else None, bridge=bridge)
+    assert_bit_exact(y.cpu().numpy(), co.conv2d(merged, w, b, act="relu"), "fused up block (%s)" % bridge)
