@@ -468,6 +468,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="training dtype (--mode train)")
+    ap.add_argument("--fuse-up", type=int, default=1, help="1 = convT+bridge of up0 inside its first conv (infer mode)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive rate (infer mode)")
     ap.add_argument("--graph", type=int, default=1, help="--mode train: replay the step as hipGraphs (1) or eager (0)")
     ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
@@ -503,7 +504,7 @@ def main():
     from sequitr_amd.networks.unet import UNet2D, init_unet_weights
 
     params = {"shape": (TILE, TILE), "num_inputs": 1, "num_outputs": 2, "filters": FILTERS,
-              "bridge": "eltwise_mul", "device": str(dev), "fuse": bool(args.fuse)}
+              "bridge": "eltwise_mul", "device": str(dev), "fuse": bool(args.fuse), "fuse_up": bool(args.fuse_up)}
     weights = init_unet_weights(params, seed=0)
     net = UNet2D(params, "infer")
     net.load_state_dict(weights)
