@@ -27,7 +27,8 @@ import numpy as np
 
 logger = logging.getLogger('worker_process')
 
-NET_KEYS = ('name', 'filters', 'dropout', 'num_inputs', 'num_outputs', 'shape', 'bridge', 'kernel', 'seed')
+NET_KEYS = ('name', 'filters', 'dropout', 'num_inputs', 'num_outputs', 'shape', 'bridge', 'kernel', 'seed', 'dtype',
+            'batch_norm', 'up_kernel')
 
 
 def _resolve_device(params, options):
@@ -226,8 +227,9 @@ def SERVER_train(params, options):
     """Train the U-Net on a stack of tiles with the weight-map-weighted softmax cross-entropy.
 
     params: images (.npy (N,H,W[,C]) float), labels (.npy (N,H,W) class indices or one-hot), weights
-    (.npy (N,H,W[,1]); when absent computed with ImageWeightMap(w0, sigma) on the host,
-    sequitr/pipeline.py:455-479), plus the NetConfiguration keys (name, shape, num_outputs,
+    (.npy (N,H,W[,1]); when absent computed with ImageWeightMap(w0, sigma), sequitr/pipeline.py:455-479, on
+    the GPU -- sq_weightmap_edt_f32 -- and kept there), dtype ('f32' | 'bf16' activations), plus the
+    NetConfiguration keys (name, shape, num_outputs,
     learning_rate, num_epochs, batch_size, dropout, filters, bridge, warm_start ...).
     Under torchrun (WORLD_SIZE > 1) the tiles shard across ranks and gradients are all-reduced over
     RCCL once per step.  Rank 0 saves ``weights.npz`` + ``net.config`` into the next numbered folder
@@ -236,7 +238,7 @@ def SERVER_train(params, options):
     import torch
     from . import utils
     from .parallel import shard_range
-    from .pipeline import ImageWeightMap
+    from .weightmap import device_weightmaps
     from .train import UNetTrainer
 
     device = _resolve_device(params, options)
@@ -256,10 +258,9 @@ def SERVER_train(params, options):
     onehot = _onehot(np.load(params['labels'], allow_pickle=False), config.num_outputs)
     if params.get('weights'):
         wmap = np.load(params['weights'], allow_pickle=False).reshape(onehot.shape[:3] + (1,)).astype(np.float32)
-    else:
-        pipe = ImageWeightMap(w0=params.get('w0', 10.), sigma=params.get('sigma', 5.))
-        fg = onehot[..., 1:].sum(-1).astype(np.float32)
-        wmap = np.stack([pipe(t.copy()) for t in fg]).astype(np.float32)
+    else:                                                      # EDT weight maps on the device, left in HBM
+        fg = onehot[..., 1:].sum(-1)
+        wmap = device_weightmaps(fg, params.get('w0', 10.), params.get('sigma', 5.), device=device)
 
     net_p = _net_params(params, device)
     net_p.setdefault('shape', tuple(x.shape[1:3]))
@@ -284,7 +285,8 @@ def SERVER_train(params, options):
             idx = np.sort(order[s * batch:(s + 1) * batch])
             xb = torch.from_numpy(np.ascontiguousarray(x[idx], dtype=np.float32)).to(device)
             yb = torch.from_numpy(np.ascontiguousarray(onehot[idx])).to(device)
-            wb = torch.from_numpy(np.ascontiguousarray(wmap[idx])).to(device)
+            wb = (wmap[torch.from_numpy(idx).to(device)].contiguous() if isinstance(wmap, torch.Tensor)
+                  else torch.from_numpy(np.ascontiguousarray(wmap[idx])).to(device))
             losses.append(float(trainer.step(xb, yb, wb).item()))
             if max_steps and len(losses) >= max_steps:
                 break
