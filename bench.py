@@ -578,8 +578,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "U-Net 2-class inference, batch=32 512x512x1 tiles per GPU, fp32 "
-                                   "(BASELINE.json configs[1]); logits + uint8 argmax mask",
-                       "filters": list(FILTERS), "bridge": "eltwise_mul", "tiles_per_gpu": BATCH,
+                                   "(BASELINE.json configs[1]: filters 16-32-64-128-256, eltwise_mul bridge); "
+                                   "logits + uint8 argmax mask",
+                       "tiles_per_gpu": BATCH,
                        "parity": "logits and masks bit-exact vs oracle/sq_oracle.c (tests/test_gpu_unet.py)"},
             "roofline": {
                 "bound": "mfma",
