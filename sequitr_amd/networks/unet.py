@@ -500,6 +500,40 @@ class UNet2D(UNet):
         return self._mask
 
 
+class GraphedPredict(object):
+    """UNet2D.predict captured as one hipGraph for a fixed batch shape (inference is GPU-bound, but one graph
+    launch per batch instead of ~25 kernel launches makes the host side immune to scheduling jitter: a
+    loaded host was observed to starve the queue).  Same kernels, same bits as the eager path."""
+
+    def __init__(self, net, batch_shape, warmup=2):
+        if net.training:
+            raise RuntimeError('GraphedPredict captures the inference graph (mode infer / eval)')
+        self.net = net
+        self.x = torch.zeros(tuple(batch_shape), dtype=torch.float32, device=net.device)
+        side = torch.cuda.Stream(device=net.device)
+        side.wait_stream(torch.cuda.current_stream(net.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                net.predict(self.x)
+        torch.cuda.current_stream(net.device).wait_stream(side)
+        torch.cuda.synchronize(net.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.mask = net.predict(self.x)
+            self.logits = net.logits()
+
+    def __call__(self, features):
+        """features: array / tensor of the captured shape; returns (mask, logits) static device tensors
+        (overwritten by the next call)."""
+        if isinstance(features, np.ndarray):
+            features = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32))
+        if tuple(features.shape) != tuple(self.x.shape):
+            raise ValueError('captured for %s, got %s' % (tuple(self.x.shape), tuple(features.shape)))
+        self.x.copy_(features, non_blocking=True)
+        self.graph.replay()
+        return self.mask, self.logits
+
+
 class UNet2DBf16(UNet2D):
     """The same graph with bf16 activations in HBM (BASELINE configs 3-5: bf16 compute, fp32 master
     weights and fp32 accumulation).  The image enters as f32 (one channel), every activation between

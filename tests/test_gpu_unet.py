@@ -191,3 +191,18 @@ def test_convT_bridge_conv_fused_kernel_bit_exact(bridge, shape):
     y = ops.convT_conv3x3(d(xl), d(wt), d(bt), d(skip), bridge, d(w), d(b), act="relu")
     merged = co.convT2x2s2(xl, wt, bt, skip=skip if bridge else None, bridge=bridge)
     assert_bit_exact(y.cpu().numpy(), co.conv2d(merged, w, b, act="relu"), "fused up block (%s)" % bridge)
+
+
+def test_graphed_predict_equals_eager():
+    from sequitr_amd.networks.unet import GraphedPredict
+    params = {"shape": (64, 64)}
+    net, w = make(params, seed=1)
+    g = GraphedPredict(net, (3, 64, 64, 1))
+    for seed in (0, 1):
+        x = tiles(seed, 3, 64, 64)
+        mask, logits = g(x)
+        ref_mask = net.predict(x).clone()
+        assert_bit_exact(logits.cpu().numpy(), net.logits().cpu().numpy(), "graph logits")
+        assert torch.equal(mask, ref_mask)
+    with pytest.raises(ValueError):
+        g(tiles(0, 2, 64, 64))
