@@ -22,7 +22,7 @@ from scipy import ndimage
 from scipy.spatial import Delaunay
 
 
-class ImagePipeline(object):
+class ImagePipeline:
     """Chain of ImagePipe objects applied in order (pipeline.py:42-98)."""
 
     def __init__(self, pipeline=None):
@@ -98,7 +98,7 @@ def load_image_pipeline(filename):
     return ImagePipeline(pipes)
 
 
-class ImagePipe(object):
+class ImagePipe:
     """Base pipe (pipeline.py:162-189)."""
 
     def __init__(self):
@@ -128,7 +128,7 @@ class ImageResize(ImagePipe):
     """pipeline.py:195-221.  scipy.ndimage.zoom stands in for skimage.transform.resize."""
 
     def __init__(self, size=(1024, 1024), order=0):
-        ImagePipe.__init__(self)
+        super().__init__()
         self.size = size
         self.order = order
 
@@ -144,7 +144,7 @@ class ImageFlip(ImagePipe):
     """The four mirror states in sequence (pipeline.py:226-241)."""
 
     def __init__(self):
-        ImagePipe.__init__(self)
+        super().__init__()
         self.flips = [[], [np.fliplr], [np.flipud], [np.fliplr, np.flipud]]
 
     def pipe(self, image):
@@ -161,7 +161,7 @@ class ImageBlur(ImagePipe):
     ``__len__`` reads a non-existent attribute, SURVEY A.5 -- surface kept, defect not)."""
 
     def __init__(self, sigma=0.5):
-        ImagePipe.__init__(self)
+        super().__init__()
         self.sigma = sigma
 
     def pipe(self, image):
@@ -174,7 +174,7 @@ class ImageOutliers(ImagePipe):
     """Hot-pixel removal against a median filter (pipeline.py:266-295)."""
 
     def __init__(self, sigma=2, threshold=5.):
-        ImagePipe.__init__(self)
+        super().__init__()
         self.sigma = sigma
         self.threshold = threshold
 
@@ -192,7 +192,7 @@ class ImageRotate(ImagePipe):
     """pipeline.py:298-333.  scipy.ndimage.rotate stands in for skimage.transform.rotate."""
 
     def __init__(self, rotations=16, order=0, max_theta=360):
-        ImagePipe.__init__(self)
+        super().__init__()
         self.rotations = rotations
         self.max_theta = max_theta
         self.order = order
@@ -216,7 +216,7 @@ class ImageNorm(ImagePipe):
     tile normalisation contract of the network input."""
 
     def __init__(self):
-        ImagePipe.__init__(self)
+        super().__init__()
         self.epsilon = 1e-99
 
     def pipe(self, image):
@@ -230,7 +230,7 @@ class ImageBGSubtract(ImagePipe):
     """Second-order polynomial background, least squares over all pixels (pipeline.py:360-405)."""
 
     def __init__(self):
-        ImagePipe.__init__(self)
+        super().__init__()
 
     def pipe(self, image):
         rows, cols = image.shape[0], image.shape[1]
@@ -246,7 +246,7 @@ class ImageSample(ImagePipe):
     """Random square ROIs with remembered positions (pipeline.py:408-451)."""
 
     def __init__(self, samples=16, ROI_size=(512, 512)):
-        ImagePipe.__init__(self)
+        super().__init__()
         self.samples = samples
         self.ROI_size = ROI_size
         self.im_size = None
@@ -278,7 +278,7 @@ class ImageWeightMap(ImagePipe):
     w0 * (1 - img) * exp(-d^2 / (2 sigma^2 + 1e-99)) + img + 1; float64 out."""
 
     def __init__(self, w0=10., sigma=5.):
-        ImagePipe.__init__(self)
+        super().__init__()
         self.w0 = w0
         self.sigma = sigma
 
@@ -297,7 +297,7 @@ class ImageWeightMap2(ImagePipe):
     OUTSIDE = 1024.
 
     def __init__(self, w0=10., sigma=5.):
-        ImagePipe.__init__(self)
+        super().__init__()
         self.w0 = w0
         self.sigma = sigma
 

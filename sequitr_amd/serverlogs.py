@@ -10,9 +10,13 @@ from time import gmtime, strftime
 from . import core
 
 
+_STAMP = "(%Y-%m-%d)_%H-%M-%S"                                 # serverlogs.py:30-32: LOG_(date)_time.txt
+_LINE = '[%(levelname)s][%(asctime)s] %(message)s'
+_DATE = '%Y/%m/%d %I:%M:%S %p'
+
+
 def generate_log_filename():
-    """ Return a timestamped log filename (serverlogs.py:30-32) """
-    return "LOG_" + strftime("(%Y-%m-%d)_%H-%M-%S", gmtime()) + ".txt"
+    return "LOG_{0}.txt".format(strftime(_STAMP, gmtime()))
 
 
 def setup_logging(filepath=None, log_name='server_process'):
@@ -23,44 +27,40 @@ def setup_logging(filepath=None, log_name='server_process'):
         raise IOError('LOG_DIR filepath does not exist: {0:s}'.format(filepath))
     if log_name not in core.DEFAULT_LOGGER_PROCESSES:
         raise ValueError('Log_name should be in {0:s}.'.format(str(core.DEFAULT_LOGGER_PROCESSES)))
-    log_file = os.path.join(filepath, generate_log_filename())
-    fmt = logging.Formatter('[%(levelname)s][%(asctime)s] %(message)s', datefmt='%Y/%m/%d %I:%M:%S %p')
-    logger = logging.getLogger(log_name)
-    for handler in (logging.FileHandler(log_file), logging.StreamHandler()):
-        handler.setFormatter(fmt)
-        logger.addHandler(handler)
-    logger.setLevel(logging.DEBUG)
-    return log_file
+    target = os.path.join(filepath, generate_log_filename())
+    log = logging.getLogger(log_name)
+    log.setLevel(logging.DEBUG)
+    layout = logging.Formatter(_LINE, datefmt=_DATE)
+    for sink in (logging.FileHandler(target), logging.StreamHandler()):
+        sink.setFormatter(layout)
+        log.addHandler(sink)
+    return target
 
 
 def shutdown_logging(log_name='worker_process'):
     """Detach and close this process's handlers (lets tests and servers reuse the name)."""
-    logger = logging.getLogger(log_name)
-    for h in list(logger.handlers):
-        logger.removeHandler(h)
-        h.close()
+    log = logging.getLogger(log_name)
+    while log.handlers:
+        sink = log.handlers[0]
+        log.removeHandler(sink)
+        sink.close()
 
 
 def get_logger(loggers=core.DEFAULT_LOGGER_PROCESSES):
     """ First configured logger of server / worker process, else None (serverlogs.py:81-91) """
-    for name in loggers:
-        logger = logging.getLogger(name)
-        if logger.handlers:
-            return logger
-    return None
+    configured = (logging.getLogger(n) for n in loggers)
+    return next((lg for lg in configured if lg.handlers), None)
 
 
 def exception_logger(function):
     """Log any exception of the wrapped call and return None instead of raising."""
     @functools.wraps(function)
-    def wrapper(*args, **kwargs):
-        logger = get_logger()
+    def guarded(*args, **kwargs):
         try:
             return function(*args, **kwargs)
         except Exception:
-            err = "There was an exception in: {0:s}".format(function.__name__)
-            if logger is not None:
-                logger.exception(err)
-            else:
-                print(err)
-    return wrapper
+            where = "There was an exception in: {0:s}".format(function.__name__)
+            sink = get_logger()
+            (sink.exception if sink is not None else print)(where)
+            return None
+    return guarded
