@@ -14,6 +14,7 @@ tiles instead of a TFRecord (TFRecord IO is out of scope); checkpoints are ``mod
 the minibatch-stdev statistic (0.26 M elements) and the (N,)-sized loss algebra run as torch
 tensor ops -- everything that touches an image-sized tensor is a hand-written HIP kernel.
 """
+import json
 import logging
 import os
 
@@ -432,13 +433,36 @@ class GenerativeAdverserialNetwork(object):
         return x
 
     # -- train, gan.py:782-870 ---------------------------------------------------------------------------
+    def checkpoint_name(self, level):
+        """per-level checkpoint, the reference's ``model_(HxW).ckpt`` (gan.py:864-867) as an .npz"""
+        return "model_{0:s}.npz".format(str(self.get_size(level)).replace(', ', 'x'))
+
+    def latest_checkpoint(self):
+        """(level, path) of the highest level with a checkpoint in output_dir, or (None, None).  The
+        reference restores a hard-coded ``model_(1024x1024).ckpt`` / start_network 7 (gan.py:811-816,
+        SURVEY A.5); here ``restore = True`` resumes from whatever level was last completed."""
+        if not self.output_dir:
+            return None, None
+        for level in reversed(range(self.num_levels)):
+            fn = os.path.join(self.output_dir, self.checkpoint_name(level))
+            if os.path.exists(fn):
+                return level, fn
+        return None, None
+
     def train(self, max_steps_per_phase=None):
         if not self.initialized:
             raise Exception("Networks have not been initialized. Please run .build()")
         if self.output_dir:
             utils.check_and_makedir(self.output_dir)
         step_id = 0
-        for n in range(0, len(self.networks)):
+        start_network = 0
+        if self.restore:
+            level, fn = self.latest_checkpoint()
+            if fn is not None:
+                self.load_checkpoint(fn)
+                start_network = level + 1
+                logger.info('Restored {0:s}; resuming at level {1:d}'.format(fn, start_network))
+        for n in range(start_network, len(self.networks)):
             self.set_level(n)
             iters = self.num_iterations_this_level
             if max_steps_per_phase:
@@ -453,13 +477,38 @@ class GenerativeAdverserialNetwork(object):
                         self.g_solver(x, z, fade)
                     logger.info('{0} {1} {2} {3}'.format(self.global_step, phase, self.get_size(n), fade))
             if self.output_dir:
-                sz_fn = str(self.get_size(n)).replace(', ', 'x')
-                np.savez(os.path.join(self.output_dir, "model_{0:s}.npz".format(sz_fn)), **self.store.state_dict())
+                np.savez(os.path.join(self.output_dir, self.checkpoint_name(n)), **self.store.state_dict())
 
     def load_checkpoint(self, filename):
         with np.load(filename, allow_pickle=False) as z:
             self.store.load_state_dict({k: z[k] for k in z.files})
         self.initialized = True
+
+    def convert_checkpoint_to_model(self, level=None):
+        """gan.py:874-903: turn a training checkpoint into an inference model.  Restores the checkpoint
+        of `level` (default: the highest one present) and writes ``output_dir/export/``: ``weights.npz`` with
+        the GENERATOR variables only and ``model.json`` naming the signature the reference's SavedModel has
+        (inputs Z, alpha -> output Gz).  Returns the export folder."""
+        if not self.initialized:
+            self.build()
+        if level is None:
+            level, filename = self.latest_checkpoint()
+            if filename is None:
+                raise IOError('No checkpoint found in {0}'.format(self.output_dir))
+        else:
+            filename = os.path.join(self.output_dir, self.checkpoint_name(level))
+        logger.info('Converting {0:s} to model...'.format(filename))
+        self.load_checkpoint(filename)
+        export_dir = os.path.join(self.output_dir, 'export')
+        utils.check_and_makedir(export_dir)
+        gen = {k: v for k, v in self.store.state_dict().items() if k.startswith('GAN/generator/')}
+        np.savez(os.path.join(export_dir, 'weights.npz'), **gen)
+        with open(os.path.join(export_dir, 'model.json'), 'w') as f:
+            json.dump({'inputs': {'Z': [None, 1, 1, 512], 'alpha': []},
+                       'outputs': {'Gz': [None] + list(self.get_size(level)) + [self.num_channels]},
+                       'level': int(level), 'filters': [int(c) for c in self.filters[:level + 1]],
+                       'source_checkpoint': os.path.basename(filename)}, f, indent=2)
+        return export_dir
 
     def predict(self, latent=None, level=None, alpha=1.0):
         """Generate images from latent vectors (N,1,1,512) at `level` (default: the last)."""
