@@ -519,3 +519,68 @@ class GenerativeAdverserialNetwork(object):
         with torch.no_grad():
             _, out = self.generator(z, self.filters[:(level + 1)])
         return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# command line, gan.py:1040-1125 (the reference's __main__ with its hard-coded paths as arguments)
+# ---------------------------------------------------------------------------------------------------
+def to_rgb(Gz):
+    """Generated (N,H,W,2) images -> uint8 RGB (N,H,W,3): channels [1, 0, 1], ((1 + x/3) * 127.5) clipped
+    to 0..255 (gan.py:1117-1125)."""
+    Gz = np.asarray(Gz)
+    rgb = np.concatenate([Gz[..., 1:2], Gz[..., 0:1], Gz[..., 1:2]], axis=-1)
+    return ((1. + rgb / 3.) * 127.5).clip(0, 255).astype('uint8')
+
+
+def get_run_number(folder):
+    """highest <n> of the GAN<n> run folders in `folder`, 0 when there is none (gan.py:1072-1077)"""
+    runs = [f for f in os.listdir(folder) if os.path.isdir(os.path.join(folder, f)) and f.startswith('GAN')
+            and f[3:].isdigit()]
+    return max([int(r[3:]) for r in runs]) if runs else 0
+
+
+def main(argv=None):
+    import argparse
+    p = argparse.ArgumentParser(description='Sequitr: Progressive GAN')
+    p.add_argument('--workdir', required=True, help='Path to job directory')
+    p.add_argument('--num_epochs', type=int, default=100, help='Specify the number of epochs per expansion')
+    p.add_argument('--num_levels', type=int, default=8, help='Specify the number of expansions from (4,4) start')
+    p.add_argument('--batch_size', type=int, default=32, help='Specify the batch size')
+    p.add_argument('--train', action='store_true', help='Train the model if this flag is present')
+    p.add_argument('--restore', action='store_true', help='Continue training a model')
+    p.add_argument('--training_data', default=None, help='.npy stack (N,H,W,C); synthetic tiles when absent')
+    p.add_argument('--samples', type=int, default=512, help='images to export when predicting')
+    args = p.parse_args(argv)
+
+    config = GAN2DConfiguration()
+    config.num_levels = args.num_levels
+    config.num_epochs_per_level = args.num_epochs
+    config.batch_size = args.batch_size
+    config.training_data = args.training_data
+    params = config.to_params()
+    if args.train:
+        gan = GenerativeAdverserialNetwork(params, TRAIN)
+        gan.restore = args.restore
+        gan.output_dir = args.workdir if args.restore else os.path.join(
+            args.workdir, "GAN{0:d}".format(get_run_number(args.workdir) + 1))
+        gan.build()
+        gan.train()
+        return gan.convert_checkpoint_to_model()
+    gan = GenerativeAdverserialNetwork(params, None)
+    gan.output_dir = args.workdir
+    gan.build()
+    with np.load(os.path.join(args.workdir, 'export', 'weights.npz'), allow_pickle=False) as z:
+        gan.store.load_state_dict({k: z[k] for k in z.files})
+    n = args.samples
+    Z = np.zeros((n, 1, 1, 512))
+    for i in range(n):                                          # the reference's latent walk (gan.py:1110-1112)
+        Z[i, 0, 0, :] = np.sin((i / 256.) + np.arange(512) / 64.)
+    from ..weightmap import imsave
+    rgb = to_rgb(gan.predict(latent=Z).cpu().numpy())
+    for i in range(n):
+        imsave(os.path.join(args.workdir, 'export_{}.tif'.format(i)), rgb[i])
+    return args.workdir
+
+
+if __name__ == "__main__":
+    main()

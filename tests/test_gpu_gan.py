@@ -252,3 +252,19 @@ def test_restore_and_convert_checkpoint_to_model(tmp_path):
     assert torch.equal(k.predict(latent=np.ones((1, 1, 1, 512), np.float32)),
                        h.predict(latent=np.ones((1, 1, 1, 512), np.float32)))
     assert tuple(ref_img.shape) == (1, 16, 16, 2)
+
+
+def test_cli_train_then_predict_exports_tiffs(tmp_path):
+    """python -m sequitr_amd.networks.gan --train ... / predict (gan.py:1040-1125): run folder numbering,
+    export/ model, export_<i>.tif with the reference's RGB mapping."""
+    import os
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "GAN3"))
+    export = gan.main(["--workdir", work, "--train", "--num_levels", "2", "--num_epochs", "1", "--batch_size", "4"])
+    assert export == os.path.join(work, "GAN4", "export") and os.path.exists(os.path.join(export, "weights.npz"))
+    out = gan.main(["--workdir", os.path.join(work, "GAN4"), "--num_levels", "2", "--batch_size", "4", "--samples", "3"])
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(out, "export_2.tif")))
+    assert img.shape == (8, 8, 3) and img.dtype == np.uint8 and np.array_equal(img[..., 0], img[..., 2])
+    x = np.array([[[[-3.0, 0.0]]], [[[3.0, 9.0]]]])
+    assert gan.to_rgb(x).tolist() == [[[[127, 0, 127]]], [[[255, 255, 255]]]]
