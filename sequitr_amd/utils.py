@@ -229,3 +229,12 @@ def load_model_weights(model_dir):
     """{variable name: ndarray} from a numbered model dir (numpy.load, no pickle)."""
     with np.load(os.path.join(model_dir, WEIGHTS_FILE), allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
+
+
+def __getattr__(name):
+    """``utils.CentroidWriter`` (sequitr/utils.py:479-578) lives in sequitr_amd.centroids: it needs the HIP
+    library, which this module must not import just to read a config."""
+    if name == 'CentroidWriter':
+        from .centroids import CentroidWriter
+        return CentroidWriter
+    raise AttributeError("module {0!r} has no attribute {1!r}".format(__name__, name))
