@@ -11,6 +11,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "sequitr_amd", "csrc", "sq_conv_f32_v2.hip")
+WSRC = os.path.join(ROOT, "sequitr_amd", "csrc", "sq_conv_wgrad_f32.hip")
+WGRAD_VARIANTS = {
+    "wg_base": [],
+    "wg_noload": [("raw_buffer_load_b128(xrsrc, inb ? (unsigned)(xbase + xrel[sl]) : OOB, 0, 0)",
+                   "raw_buffer_load_b128(xrsrc, inb ? OOB : OOB, 0, 0)"),
+                  ("raw_buffer_load_b128(yrsrc, inb ? (unsigned)(ybase + yrel[sl]) : OOB, 0, 0)",
+                   "raw_buffer_load_b128(yrsrc, inb ? OOB : OOB, 0, 0)")],
+}
 VARIANTS = {
     "base": [],
     "nostore": [("const unsigned off = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 4) : OOB;",
@@ -21,9 +29,14 @@ VARIANTS["noload_nostore"] = VARIANTS["nostore"] + VARIANTS["noload"]
 
 
 def build():
-    objs = [o for o in glob.glob(os.path.join(ROOT, "sequitr_amd", "_build", "*.o")) if not o.endswith("sq_conv_f32_v2.o")]
-    src = open(SRC).read()
-    for name, patches in VARIANTS.items():
+    _build(SRC, "sq_conv_f32_v2.o", VARIANTS)
+    _build(WSRC, "sq_conv_wgrad_f32.o", WGRAD_VARIANTS)
+
+
+def _build(src_file, obj_name, variants):
+    objs = [o for o in glob.glob(os.path.join(ROOT, "sequitr_amd", "_build", "*.o")) if not o.endswith(obj_name)]
+    src = open(src_file).read()
+    for name, patches in variants.items():
         d = os.path.join(ROOT, "tools", "_exp", name)
         os.makedirs(d, exist_ok=True)
         s = src
@@ -51,6 +64,22 @@ def run_one(name):
     from sequitr_amd import ops
     dev = "cuda:0"
     out = []
+    if name.startswith("wg_"):
+        for (n, h, ci, co) in [(16, 512, 16, 16), (16, 256, 32, 32), (16, 128, 64, 64), (16, 32, 256, 256)]:
+            x = torch.randn(n, h, h, ci, device=dev)
+            dy = torch.randn(n, h, h, co, device=dev)
+            for _ in range(3):
+                ops.conv2d_wgrad(x, dy, 3)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(20):
+                ops.conv2d_wgrad(x, dy, 3)
+            e.record()
+            torch.cuda.synchronize()
+            us = s.elapsed_time(e) / 20 * 1e3
+            out.append("%6.1f us %5.1f TF" % (us, 2.0 * n * h * h * 9 * ci * co / us / 1e6))
+        print("%-16s %s" % (name, " | ".join(out)), flush=True)
+        return
     for (n, h, ci, co) in [(32, 512, 16, 16), (32, 256, 32, 32), (32, 128, 64, 64), (32, 32, 256, 256)]:
         x = torch.randn(n, h, h, ci, device=dev)
         w = torch.randn(3, 3, ci, co, device=dev) * 0.05
@@ -73,7 +102,7 @@ if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
     elif sys.argv[1] == "run":
-        for v in ["prod"] + list(VARIANTS):                  # one process per variant: the library is loaded once
+        for v in ["prod"] + list(VARIANTS) + list(WGRAD_VARIANTS):   # one process per variant: the library is loaded once
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "one", v])
     else:
         run_one(sys.argv[2])
