@@ -73,7 +73,11 @@ def test_first_conv_bf16():
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,K", [(2, 32, 48, 16, 16, 3), (1, 32, 32, 32, 64, 3), (2, 21, 19, 16, 32, 3),
-                                              (1, 16, 16, 64, 256, 1), (1, 16, 16, 128, 128, 3)])
+                                              (1, 16, 16, 64, 256, 1), (1, 16, 16, 128, 128, 3),
+                                              # every channel-block shape of the dispatcher, ragged tiles, >1 tile per block
+                                              (2, 20, 27, 32, 48, 3), (1, 17, 9, 16, 32, 3), (2, 12, 12, 64, 128, 1),
+                                              (1, 7, 7, 32, 32, 1), (3, 40, 24, 48, 16, 3), (1, 9, 33, 16, 16, 1),
+                                              (9, 32, 32, 32, 16, 3)])
 def test_wgrad_bf16(N, H, W, Cin, Cout, K):
     x, dy = tiles(9, N, H, W, Cin), tiles(10, N, H, W, Cout)
     xb, dyb = bf16_round(x), bf16_round(dy)

@@ -35,6 +35,12 @@ CONV_CASES = [
     (1, 16, 16, 16, 2, 1, None),         # to_image head via the generic entry
     (1, 8, 8, 512, 512, 3, "leaky"),     # GAN deep layer
     (1, 16, 16, 64, 32, 1, None),        # 1x1 through the MFMA path
+    (3, 17, 33, 16, 24, 3, "relu"),      # Cout not a multiple of 16: masked channel tail in the epilogue
+    (1, 40, 40, 48, 40, 3, "leaky"),     # three input chunks, ragged output block
+    (5, 16, 16, 32, 20, 1, None),        # 1x1, odd batch, Cout tail
+    (37, 16, 16, 16, 16, 3, "relu"),     # more tiles than one persistent block run divides evenly
+    (1, 1, 100, 16, 16, 3, "relu"),      # a single row
+    (1, 100, 1, 16, 32, 3, None),        # a single column
 ]
 
 
