@@ -341,6 +341,14 @@ int sq_cast_bf16_to_f32(const void *x, float *y, int64_t n, void *stream);
 /* bf16 variants of the streaming ops (C % 8 == 0 / n % 8 == 0): same semantics as the f32 entries */
 int sq_maxpool2x2_fwd_bf16(const void *x, void *y, int N, int H, int W, int C, void *stream);
 int sq_maxpool2x2_bwd_bf16(const void *x, const void *dy, void *dx, int N, int H, int W, int C, void *stream);
+/* decoder junction backward in one pass (merged = bridge(up, skip), unet.py:312-319): g (N,H,W,4C) = d_up in the
+ * space-to-depth layout sq_conv2d_nhwc_wgrad_bf16 / the 1x1 dgrad of the transpose conv consume, dskip
+ * (N,2H,2W,C) = gradient of the skip operand.  H, W = the LOW-resolution side; up / skip needed for eltwise_mul. */
+int sq_bridge_bwd_s2d_bf16(const void *dy, const void *up, const void *skip, void *g, void *dskip, int N, int H, int W,
+                           int C, int bridge, void *stream);
+/* max-pool backward + the other gradient of the pooled tensor (the U-Net skip path): dx = scatter(dy) + add */
+int sq_maxpool2x2_bwd_add_bf16(const void *x, const void *dy, const void *add, void *dx, int N, int H, int W, int C,
+                               void *stream);
 int sq_act_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, int act, void *stream);
 /* dropout backward + the backward of the activation in front of it, one pass:
  * dx = act'(y) * (mask ? dy / (1 - rate) : 0), y = the activation output that entered the dropout */

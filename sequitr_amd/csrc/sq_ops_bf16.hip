@@ -136,6 +136,82 @@ __global__ __launch_bounds__(256) void bridge_bwd_bf16_kernel(const bf16x8 *__re
     }
 }
 
+// Decoder junction backward (merged = bridge(up, skip), up = transpose conv output): one pass writes
+//   g    (N,H,W,4C): d_up already in the space-to-depth layout the transpose-conv backward consumes
+//                    (g[n,i,j,(2a+b)C + c] = d_up[n,2i+a,2j+b,c]), and
+//   dskip (N,2H,2W,C): the gradient of the skip operand.
+// Same arithmetic and rounding as bridge_bwd_bf16_kernel followed by space_to_depth2.
+__global__ __launch_bounds__(256) void bridge_bwd_s2d_bf16_kernel(const bf16x8 *__restrict__ dy, const bf16x8 *__restrict__ up,
+                                                                   const bf16x8 *__restrict__ skip, bf16x8 *__restrict__ g,
+                                                                   bf16x8 *__restrict__ dskip, int N, int H, int W, int C8,
+                                                                   int op) {
+    const int64_t total = (int64_t)N * 2 * H * 2 * W * C8;      // H, W = the LOW-resolution side
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C8);
+        int64_t t = i / C8;
+        const int x = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int y = (int)(t % (2 * H));
+        const int n = (int)(t / (2 * H));
+        const bf16x8 gy = dy[i];
+        bf16x8 da, db;
+        if (op == SQ_BRIDGE_MUL) {
+            const bf16x8 u = up[i], v = skip[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                da[j] = (__bf16)((float)gy[j] * (float)v[j]);
+                db[j] = (__bf16)((float)gy[j] * (float)u[j]);
+            }
+        } else {
+            da = gy;
+            db = gy;
+            if (op == SQ_BRIDGE_SUB) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) db[j] = (__bf16)(-(float)gy[j]);
+            }
+        }
+        dskip[i] = db;
+        const int ab = (y & 1) * 2 + (x & 1);
+        g[((((int64_t)n * H + (y >> 1)) * W + (x >> 1)) * 4 + ab) * C8 + c] = da;
+    }
+}
+
+// max-pool backward that also adds a second gradient of the pooled tensor's INPUT (the skip path of the
+// U-Net): dx = scatter(dy) + add, the bf16 sum torch's gradient accumulation would form in its own kernel
+__global__ __launch_bounds__(256) void maxpool_bwd_add_bf16_kernel(const bf16x8 *__restrict__ x, const bf16x8 *__restrict__ dy,
+                                                                    const bf16x8 *__restrict__ add, bf16x8 *__restrict__ dx,
+                                                                    int N, int H, int W, int C8) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int64_t total = (int64_t)N * Ho * Wo * C8;
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C8);
+        int64_t t = i / C8;
+        const int xo = (int)(t % Wo);
+        t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int64_t b00 = (((int64_t)n * H + 2 * yo) * W + 2 * xo) * C8 + c;
+        const int64_t b01 = b00 + C8, b10 = b00 + (int64_t)W * C8, b11 = b10 + C8;
+        const bf16x8 a = x[b00], b = x[b01], d = x[b10], e = x[b11], gy = dy[i];
+        const bf16x8 sa = add[b00], sb = add[b01], sd = add[b10], se = add[b11];
+        bf16x8 ra, rb, rd, re;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float m = (float)a[j];
+            int k = 0;
+            if ((float)b[j] > m) { m = (float)b[j]; k = 1; }
+            if ((float)d[j] > m) { m = (float)d[j]; k = 2; }
+            if ((float)e[j] > m) { m = (float)e[j]; k = 3; }
+            const float gg = (float)gy[j];
+            ra[j] = (__bf16)((k == 0 ? gg : 0.f) + (float)sa[j]);
+            rb[j] = (__bf16)((k == 1 ? gg : 0.f) + (float)sb[j]);
+            rd[j] = (__bf16)((k == 2 ? gg : 0.f) + (float)sd[j]);
+            re[j] = (__bf16)((k == 3 ? gg : 0.f) + (float)se[j]);
+        }
+        dx[b00] = ra; dx[b01] = rb; dx[b10] = rd; dx[b11] = re;
+    }
+}
+
 __device__ __forceinline__ unsigned hash32(unsigned a, unsigned b) {          // same hash as the f32 dropout
     unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
@@ -426,6 +502,30 @@ extern "C" int sq_maxpool2x2_bwd_bf16(const void *x, const void *dy, void *dx, i
                        SQ_ST(stream), reinterpret_cast<const bf16x8 *>(x), reinterpret_cast<const bf16x8 *>(dy),
                        reinterpret_cast<bf16x8 *>(dx), N, H, W, C / 8);
     return sq_check_launch("sq_maxpool2x2_bwd_bf16");
+}
+extern "C" int sq_maxpool2x2_bwd_add_bf16(const void *x, const void *dy, const void *add, void *dx, int N, int H, int W,
+                                          int C, void *stream) {
+    SQ_REQUIRE(x && dy && add && dx, "sq_maxpool2x2_bwd_add_bf16: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0,
+               "sq_maxpool2x2_bwd_add_bf16: H, W even, C %% 8 == 0");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(add); SQ_REQUIRE_ALIGNED(dx);
+    hipLaunchKernelGGL(maxpool_bwd_add_bf16_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0,
+                       SQ_ST(stream), reinterpret_cast<const bf16x8 *>(x), reinterpret_cast<const bf16x8 *>(dy),
+                       reinterpret_cast<const bf16x8 *>(add), reinterpret_cast<bf16x8 *>(dx), N, H, W, C / 8);
+    return sq_check_launch("sq_maxpool2x2_bwd_add_bf16");
+}
+extern "C" int sq_bridge_bwd_s2d_bf16(const void *dy, const void *up, const void *skip, void *g, void *dskip, int N, int H,
+                                      int W, int C, int bridge, void *stream) {
+    SQ_REQUIRE(dy && g && dskip, "sq_bridge_bwd_s2d_bf16: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "sq_bridge_bwd_s2d_bf16: C %% 8 == 0");
+    SQ_REQUIRE(bridge >= SQ_BRIDGE_ADD && bridge <= SQ_BRIDGE_SUB, "sq_bridge_bwd_s2d_bf16: bad bridge %d", bridge);
+    SQ_REQUIRE(bridge != SQ_BRIDGE_MUL || (up && skip), "sq_bridge_bwd_s2d_bf16: eltwise_mul needs both forward operands");
+    SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(g); SQ_REQUIRE_ALIGNED(dskip);
+    hipLaunchKernelGGL(bridge_bwd_s2d_bf16_kernel, dim3(grid_for((int64_t)N * 4 * H * W * (C / 8))), dim3(256), 0,
+                       SQ_ST(stream), reinterpret_cast<const bf16x8 *>(dy), reinterpret_cast<const bf16x8 *>(up),
+                       reinterpret_cast<const bf16x8 *>(skip), reinterpret_cast<bf16x8 *>(g),
+                       reinterpret_cast<bf16x8 *>(dskip), N, H, W, C / 8, bridge);
+    return sq_check_launch("sq_bridge_bwd_s2d_bf16");
 }
 extern "C" int sq_act_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, int act, void *stream) {
     SQ_REQUIRE(dy && y && dx && n > 0 && n % 8 == 0, "sq_act_bwd_bf16: bad arguments (n %% 8 == 0)");

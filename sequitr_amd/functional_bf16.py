@@ -123,20 +123,70 @@ def conv_block(x, w1, b1, w2, b2, rate=0.0, seed=0, mask=None, step_dev=None):
 
 
 class _MaxPool(torch.autograd.Function):
+    """2x2/s2 max pool.  `box` (a dict shared with the decoder junction that also consumes x, or None): when
+    the junction has left the skip gradient in box['dskip'] -- its backward always runs first, it is downstream
+    of everything below this pool -- the pool's backward adds it in the same pass and x receives ONE gradient
+    instead of two that autograd would have to sum in an extra kernel."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, box):
         ctx.save_for_backward(x)
+        ctx.box = box
         return ob.maxpool2x2(x)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return ob.maxpool2x2_bwd(x, dy.contiguous())
+        other = ctx.box.pop('dskip', None) if ctx.box is not None else None
+        if other is not None:
+            return ob.maxpool2x2_bwd_add(x, dy.contiguous(), other), None
+        return ob.maxpool2x2_bwd(x, dy.contiguous()), None
 
 
-def maxpool2x2(x):
-    return _MaxPool.apply(x)
+def maxpool2x2(x, box=None):
+    return _MaxPool.apply(x, box)
+
+
+class _UpJunction(torch.autograd.Function):
+    """conv_transpose_layer + bridge of a decoder level (unet.py:312-319) as one tape entry: the forward is
+    the two kernels as before; the backward produces d_up directly in the space-to-depth layout the
+    transpose-conv gradients consume (one pass instead of bridge backward + space-to-depth) and, when the
+    skip tensor's pool shares a `box`, hands d_skip to that pool's backward instead of to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, skip, kind, box):
+        up = ob.convT2x2s2(x, ob.to_bf16(w), bias)
+        merged = ob.bridge(up, skip, kind)
+        keep = kind == 'eltwise_mul'
+        ctx.save_for_backward(x, w, up if keep else None, skip if keep else None)
+        ctx.kind, ctx.box, ctx.has_bias = kind, box, bias is not None
+        ctx.sinks = (grad_sink(w), grad_sink(bias))
+        return merged
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dm):
+        x, w, up, skip = ctx.saved_tensors
+        Cout, Cin = w.shape[2], w.shape[3]
+        g, dskip = ob.bridge_bwd_s2d(dm.contiguous(), up, skip, ctx.kind)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            packs = getattr(w, '_sq_packs', None) or {}
+            wp = packs.get('convT_dgrad')
+            if wp is None:
+                wp = ob.pack_weights(w.reshape(1, 1, 4 * Cout, Cin))
+            dx = ob.conv2d(g, wp, None, 1, Cin)
+        dwp, dbp = ob.conv2d_wgrad(x, g, 1, want_bias=ctx.has_bias)
+        dw, db = convT_param_grads(dwp, dbp if ctx.has_bias else None, Cin, Cout, ctx.sinks)
+        if ctx.box is not None and ctx.needs_input_grad[3]:
+            ctx.box['dskip'] = dskip                            # picked up by the skip tensor's pool backward
+            dskip = None
+        return dx, dw, db, dskip, None, None
+
+
+def up_junction(x, w, bias, skip, kind, box=None):
+    return _UpJunction.apply(x, w, bias, skip, kind, box)
 
 
 class _ConvT(torch.autograd.Function):

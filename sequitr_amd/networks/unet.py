@@ -542,7 +542,8 @@ class UNet2DBf16(UNet2D):
 
     def __init__(self, params, mode=PREDICT):
         UNet2D.__init__(self, dict(params, fuse=False), mode)
-        self.fuse_block = bool(params.get('fuse_block', True))   # conv_block as one tape entry (training)
+        self.fuse_block = bool(params.get('fuse_block', True))   # conv_block / decoder junction as single tape entries
+        self._skip_boxes = {}
         if self.n_inputs != 1:
             raise ValueError('the bf16 graph takes a single-channel f32 image (num_inputs == 1)')
         if self.batch_norm:
@@ -590,6 +591,12 @@ class UNet2DBf16(UNet2D):
         return FB.convT2x2s2(x, self._kernel((2, 2, filters, x.shape[-1])), self._bias(filters))
 
     def pool_layer(self, x):
+        if self.training and self.fuse_block:
+            # the same tensor is the skip operand of a decoder junction later: share a box with it so the
+            # junction's skip gradient is added inside this pool's backward (FB._MaxPool)
+            box = {}
+            self._skip_boxes[id(x)] = (x, box)
+            return FB.maxpool2x2(x, box)
         return FB.maxpool2x2(x)
 
     def dropout_layer(self, x):
@@ -600,4 +607,20 @@ class UNet2DBf16(UNet2D):
         return FB.dropout(x, self.dropout, seed=self._dropout_seed(step_dev), mask=mask, step_dev=step_dev)
 
     def up_layer(self, x, filters, bridge, name=None):
-        return UNet.up_layer(self, x, filters, bridge, name=name)
+        fused = (self.training and self.fuse_block and self.up_kernel == (2, 2)
+                 and type(self).conv_transpose_layer is UNet2DBf16.conv_transpose_layer
+                 and self.bridge is self._default_bridge and self.bridge_type in ('eltwise_add', 'eltwise_mul', 'eltwise_sub'))
+        if not fused:
+            return UNet.up_layer(self, x, filters, bridge, name=name)
+        with self.variable_scope('up{0:d}'.format(name)):
+            with self.variable_scope('upscale'):
+                w, b = self._kernel((2, 2, filters, x.shape[-1])), self._bias(filters)
+            entry = self._skip_boxes.get(id(bridge))
+            box = entry[1] if entry is not None and entry[0] is bridge else None
+            merged = FB.up_junction(x, w, b, bridge, self.bridge_type, box)
+            out = self.conv_block(merged, filters)
+        return out
+
+    def build(self, features):
+        self._skip_boxes = {}
+        return UNet2D.build(self, features)

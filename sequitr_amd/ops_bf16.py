@@ -293,6 +293,29 @@ def convT2x2s2(x, w_bf16, bias, skip=None, bridge_kind=None):
     return y
 
 
+def bridge_bwd_s2d(dy, up, skip, kind):
+    """(g (N,H,W,4C) = d_up in space-to-depth layout, dskip) of merged = bridge(up, skip); dy (N,2H,2W,C)."""
+    _chk(dy, "dy", ndim=4)
+    N, H2, W2, C = dy.shape
+    g = torch.empty((N, H2 // 2, W2 // 2, 4 * C), dtype=BF16, device=dy.device)
+    dskip = torch.empty_like(dy)
+    lib = _lib.load()
+    _lib.check(lib.sq_bridge_bwd_s2d_bf16(_ptr(dy), _ptr(up), _ptr(skip), _ptr(g), _ptr(dskip), N, H2 // 2, W2 // 2, C,
+                                         BRIDGE[kind], _stream()), "sq_bridge_bwd_s2d_bf16")
+    return g, dskip
+
+
+def maxpool2x2_bwd_add(x, dy, add):
+    """max-pool backward plus a second gradient of x (same shape as x), one pass."""
+    _chk(x, "x", ndim=4), _chk(dy, "dy", ndim=4), _chk(add, "add", ndim=4)
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.sq_maxpool2x2_bwd_add_bf16(_ptr(x), _ptr(dy), _ptr(add), _ptr(dx), N, H, W, C, _stream()),
+               "sq_maxpool2x2_bwd_add_bf16")
+    return dx
+
+
 def space_to_depth2(dy):
     """(N,2H,2W,C) bf16 -> (N,H,W,4C): a pure permutation, run by the f32 kernel on bf16 pairs."""
     _chk(dy, "dy", ndim=4)
