@@ -375,6 +375,7 @@ int launch(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int 
            int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
     using C = CfgB<BN, KS, KC>;
     static bool attr_set = false;
+    static int occ = 2;                                         // resident blocks per CU (registers / LDS)
     auto kern = conv_mfma_bf16_kernel<BN, KS, KC>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -382,12 +383,18 @@ int launch(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int 
             sq_set_error("conv_mfma_bf16: cannot reserve %d bytes of LDS", C::LDS_BYTES);
             return SQ_ELAUNCH;
         }
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, C::LDS_BYTES) ==
+                hipSuccess && nb >= 1)
+            occ = nb > 8 ? 8 : nb;
         attr_set = true;
     }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int ntiles = tiles_x * tiles_y * N;
     const int gy = (Cout + BN - 1) / BN;
-    int want = (256 * 2 + gy - 1) / gy;
+    // persistent grid: every block slot the CU can hold (these kernels are latency / HBM bound at C <= 32:
+    // the tiles in flight, not the MFMA rate, set their speed)
+    int want = (256 * occ + gy - 1) / gy;
     if (want < 1) want = 1;
     int tpb = (ntiles + want - 1) / want;
     if (tpb < 1) tpb = 1;
