@@ -1,4 +1,6 @@
-import torch, time, sys
+import sys
+
+import torch
 sys.path.insert(0,'/root/repo')
 from sequitr_amd import ops_bf16 as ob
 dev='cuda:0'
