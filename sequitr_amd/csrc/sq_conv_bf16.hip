@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         if (nchk == nchunk) { nchk = 0; ntile = tile + 1; }
         const bool has_next = it + 1 < nitems;
         if (has_next) issue(ntile, nchk, restage_w);
+        __builtin_amdgcn_s_setprio(0);                          // see sq_conv_f32_v2.hip: low priority while only feeding MFMA
 #pragma unroll
         for (int s = 0; s < C::NSTEP; ++s) {
             bf16x8 a[NR], b[4];
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                 for (int nb = 0; nb < NR; ++nb)
                     acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nb], b[r], acc[r][nb], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(3);
         if (has_next) {
             __syncthreads();
             commit(restage_w);
