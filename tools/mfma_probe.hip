@@ -34,12 +34,20 @@ __global__ __launch_bounds__(256) void probe(float *out, int iters, int lds_floa
 #pragma unroll
                 for (int r = 0; r < 4; ++r) b1[r] = xb[((r + ky) * 18 + kx) * 18 + s * 4];
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (MODE != 3) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int nb = 0; nb < NR; ++nb)
                     acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nb], b0[r], acc[r][nb], 0, 0, 0);
+            if (MODE == 3) {
+                // interleave: one MFMA, then up to two LDS reads, ... (the reads issue under the MFMA's 32 cycles)
+#pragma unroll
+                for (int g = 0; g < 4 * NR; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (MODE >= 1) {
 #pragma unroll
@@ -99,13 +107,16 @@ int main() {
         run<1, 0>("A bare mfma", occ);
         run<1, 1>("B +LDS fragments", occ);
         run<1, 2>("C +barrier/commit", occ);
+        run<1, 3>("D LDS reads interleaved", occ);
     }
     for (int occ = 1; occ <= 3; ++occ) {
+        run<2, 3>("D LDS reads interleaved", occ);
         run<2, 0>("A bare mfma", occ);
         run<2, 1>("B +LDS fragments", occ);
         run<2, 2>("C +barrier/commit", occ);
     }
     for (int occ = 1; occ <= 2; ++occ) {
+        run<4, 3>("D LDS reads interleaved", occ);
         run<4, 0>("A bare mfma", occ);
         run<4, 1>("B +LDS fragments", occ);
         run<4, 2>("C +barrier/commit", occ);
