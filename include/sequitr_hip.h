@@ -404,6 +404,11 @@ int sq_conv3x3_first_wgrad_bf16(const float *x, const void *dy, float *dw, float
 int64_t sq_mask_centroids_workspace(int N, int H, int W);
 int sq_mask_centroids_u8(const uint8_t *mask, int N, int H, int W, void *workspace, int32_t *count, float *out,
                          int32_t *keys, int max_out, void *stream);
+/* volumetric form (CentroidWriter.write on (N,Z,X,Y) input, utils.py:511-521, after its swapaxes(1,-1)):
+ * mask (N,D0,D1,D2), 6-connectivity; rows [frame, x, y, z, class] = centre along (D0, D1, D2);
+ * workspace: sq_mask_centroids_workspace(N*D0, D1, D2). */
+int sq_volume_centroids_u8(const uint8_t *mask, int N, int D0, int D1, int D2, void *workspace, int32_t *count,
+                           float *out, int32_t *keys, int max_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * EDT weight maps (the step in front of the training hot path).

@@ -11,6 +11,14 @@ import numpy as np
 from scipy.ndimage import label, center_of_mass
 
 
+def _cartesian(coords, volumetric):
+    if volumetric:                                              # utils.py:514-516
+        x, y, z = zip(*coords)
+        return x, y, z
+    x, y = zip(*coords)                                         # utils.py:524-527
+    return x, y, [0.0] * len(x)
+
+
 def frame_centroids(out, i):
     classes = [x for x in np.unique(out) if x > 0]                     # utils.py:541
     this_frame = []
@@ -20,12 +28,12 @@ def frame_centroids(out, i):
         coords = center_of_mass(out, matrix, labels)                   # utils.py:550
         if len(coords) < 1:
             continue
-        x, y = zip(*coords)                                            # planar get_cartesian_coords, utils.py:525-527
+        x, y, z = _cartesian(coords, out.ndim == 3)
         this_class = np.zeros((len(x), 5), dtype='float32')
         this_class[:, 0] = i
         this_class[:, 1] = x
         this_class[:, 2] = y
-        this_class[:, 3] = 0.0
+        this_class[:, 3] = z
         this_class[:, 4] = c
         this_frame.append(this_class)
     if this_frame:
@@ -34,8 +42,11 @@ def frame_centroids(out, i):
 
 
 def mask_centroids(segmented):
-    """segmented (N,H,W) integer class labels -> list of N arrays (k_i, 5) float32."""
+    """segmented (N,H,W), or volumetric (N,Z,X,Y) as CentroidWriter.write receives it -> list of N arrays
+    (k_i, 5) float32.  Volumes are axis-swapped exactly as the reference does (utils.py:519-521)."""
     segmented = np.asarray(segmented)
-    if segmented.ndim != 3:
-        raise ValueError("planar (N,H,W) input only")
+    if segmented.ndim == 4:
+        segmented = np.swapaxes(segmented, 1, -1)
+    elif segmented.ndim != 3:
+        raise ValueError("Incorrect image data shape.")
     return [frame_centroids(segmented[i], i) for i in range(segmented.shape[0])]

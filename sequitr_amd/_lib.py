@@ -55,6 +55,8 @@ SIGNATURES = {
     "sq_dense_workspace_f32": (c_int64, [c_int, c_int, c_int]),
     "sq_dense_fwd_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "sq_convT_conv3x3_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "sq_volume_centroids_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p]),
     "sq_mosaic_pack_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "sq_mosaic_unpack_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "sq_zero_insert2x_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -21,19 +21,24 @@ _MAX_OUT = 1 << 18
 
 
 def mask_centroids(mask, as_numpy=True):
-    """mask: (N,H,W) uint8 class labels on the GPU.  Returns a list of N (k_i, 5) float32 arrays
-    [frame, x, y, 0, class] (x = row centre, y = column centre), ordered as CentroidWriter.write."""
+    """mask: uint8 class labels on the GPU, planar (N,H,W) or volumetric (N,D0,D1,D2) -- for volumes pass the
+    array as CentroidWriter.write sees it after its swapaxes(1,-1) (utils.py:521).  Returns a list of N
+    (k_i, 5) float32 arrays [frame, x, y, z, class] (planar: x = row centre, y = column centre, z = 0;
+    volumetric: centres along D0, D1, D2), ordered as CentroidWriter.write orders them."""
     if not isinstance(mask, torch.Tensor):
         raise TypeError("mask must be a torch.Tensor in GPU memory")
     if not mask.is_cuda:
         raise _lib.SequitrHipError("mask must live in GPU memory (no CPU fallback exists)")
-    if mask.dtype != torch.uint8 or mask.dim() != 3 or not mask.is_contiguous():
-        raise ValueError("mask must be a contiguous (N,H,W) uint8 tensor")
-    N, H, W = mask.shape
+    if mask.dtype != torch.uint8 or mask.dim() not in (3, 4) or not mask.is_contiguous():
+        raise ValueError("mask must be a contiguous (N,H,W) or (N,D0,D1,D2) uint8 tensor")
+    volumetric = mask.dim() == 4
+    N = mask.shape[0]
+    planes = mask.shape[1] if volumetric else 1
+    H, W = mask.shape[-2], mask.shape[-1]
     lib = _lib.load()
-    nbytes = lib.sq_mask_centroids_workspace(N, H, W)
+    nbytes = lib.sq_mask_centroids_workspace(N * planes, H, W)
     if nbytes < 0:
-        raise ValueError("mask of %d x %d x %d pixels is too large for one call" % (N, H, W))
+        raise ValueError("mask %s is too large for one call" % (tuple(mask.shape),))
     dev = mask.device
     ws = torch.empty((nbytes + 15) // 16 * 4, dtype=torch.int32, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -41,9 +46,13 @@ def mask_centroids(mask, as_numpy=True):
     while True:
         out = torch.empty((max_out, 5), dtype=torch.float32, device=dev)
         keys = torch.empty((max_out,), dtype=torch.int32, device=dev)
-        _lib.check(lib.sq_mask_centroids_u8(mask.data_ptr(), N, H, W, ws.data_ptr(), count.data_ptr(), out.data_ptr(),
-                                            keys.data_ptr(), max_out, torch.cuda.current_stream().cuda_stream),
-                   "sq_mask_centroids_u8")
+        st = torch.cuda.current_stream().cuda_stream
+        if volumetric:
+            _lib.check(lib.sq_volume_centroids_u8(mask.data_ptr(), N, planes, H, W, ws.data_ptr(), count.data_ptr(),
+                                                  out.data_ptr(), keys.data_ptr(), max_out, st), "sq_volume_centroids_u8")
+        else:
+            _lib.check(lib.sq_mask_centroids_u8(mask.data_ptr(), N, H, W, ws.data_ptr(), count.data_ptr(), out.data_ptr(),
+                                                keys.data_ptr(), max_out, st), "sq_mask_centroids_u8")
         n = int(count.item())
         if n <= max_out:
             break
@@ -83,17 +92,20 @@ class CentroidWriter(object):
 
     def write(self, segmented, device=None):
         if isinstance(segmented, np.ndarray):
-            if segmented.ndim == 4:
-                raise NotImplementedError('volumetric (N,Z,X,Y) input is not on the GPU path yet')
             dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
             segmented = torch.from_numpy(np.ascontiguousarray(segmented, dtype=np.uint8)).to(dev)
-        if segmented.dim() != 3:
+        if segmented.dim() == 4:
+            im_type = "Volumetric"                               # default input is N,Z,X,Y (utils.py:519-521)
+            segmented = segmented.transpose(1, 3).contiguous()
+        elif segmented.dim() == 3:
+            im_type = "Image"
+        else:
             logger.error("Incorrect image data shape.")
             raise ValueError("Incorrect image data shape.")
         frames = mask_centroids(segmented)
         for i, coords in enumerate(frames):
             if i % 100 == 0:
-                logger.info('Written out {0:d} of {1:d} frames (Image)...'.format(i, len(frames)))
+                logger.info('Written out {0:d} of {1:d} frames ({2:s})...'.format(i, len(frames), im_type))
             self.add_frame(i, coords)
         return frames
 

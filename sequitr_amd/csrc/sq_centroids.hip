@@ -83,8 +83,9 @@ __global__ __launch_bounds__(256) void cc_rowscan_kernel(const uint8_t *__restri
             parent[g] = s.v ? base + start : -1;
             if (s.v && start == col) {                          // a root is always the first pixel of a run
                 cnt[g] = 0u;
-                sums[2 * (size_t)g] = 0ULL;
-                sums[2 * (size_t)g + 1] = 0ULL;
+                sums[3 * (size_t)g] = 0ULL;
+                sums[3 * (size_t)g + 1] = 0ULL;
+                sums[3 * (size_t)g + 2] = 0ULL;
             }
         }
         prev_last = __shfl(s.v, 63);
@@ -92,17 +93,19 @@ __global__ __launch_bounds__(256) void cc_rowscan_kernel(const uint8_t *__restri
     }
 }
 
+// planes: 1 for images; for volumes every frame is `planes` consecutive (H, W) planes and voxels are also
+// linked to the same-class voxel of the previous plane (6-connectivity, scipy's default 3-D structure)
 __global__ __launch_bounds__(256) void cc_merge_kernel(const uint8_t *__restrict__ mask, int *__restrict__ parent,
-                                                       int N, int H, int W) {
-    const int64_t total = (int64_t)N * H * W;
+                                                       int64_t total, int planes, int H, int W) {
+    const int64_t HW = (int64_t)H * W;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(g % W), rowi = (int)((g / W) % H);
+        const int col = (int)(g % W), rowi = (int)((g / W) % H), plane = (int)((g / HW) % planes);
         const int v = mask[g];
-        if (v == 0 || rowi == 0) continue;
-        if (mask[g - W] != v) continue;
-        // the pixel to the left makes the same link when it is in my run and also sits under the upper run
-        if (col > 0 && mask[g - 1] == v && mask[g - W - 1] == v) continue;
-        cc_unite(parent, (int)g, (int)(g - W));
+        if (v == 0) continue;
+        const bool left_same = col > 0 && mask[g - 1] == v;
+        // the pixel to the left makes the same link when it is in my run and also touches the same neighbour run
+        if (rowi > 0 && mask[g - W] == v && !(left_same && mask[g - W - 1] == v)) cc_unite(parent, (int)g, (int)(g - W));
+        if (plane > 0 && mask[g - HW] == v && !(left_same && mask[g - HW - 1] == v)) cc_unite(parent, (int)g, (int)(g - HW));
     }
 }
 
@@ -115,12 +118,13 @@ __global__ __launch_bounds__(256) void cc_compress_kernel(int *__restrict__ pare
 
 __global__ __launch_bounds__(256) void cc_accumulate_kernel(const uint8_t *__restrict__ mask,
                                                             const int *__restrict__ parent, unsigned *__restrict__ cnt,
-                                                            u64 *__restrict__ sums, int rows, int H, int W) {
+                                                            u64 *__restrict__ sums, int rows, int planes, int H,
+                                                            int W) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const uint8_t *row = mask + (size_t)r * W;
-    const int base = r * W, rowi = r % H;
+    const int base = r * W, rowi = r % H, plane = (r / H) % planes;
     int prev_last = 0;
     for (int c0 = 0; c0 < W; c0 += 64) {
         const SegScan s = seg_scan(row, W, c0, lane, prev_last);
@@ -130,8 +134,9 @@ __global__ __launch_bounds__(256) void cc_accumulate_kernel(const uint8_t *__res
             const unsigned len = (unsigned)(lane - j + 1);
             const int root = parent[base + c0 + lane];
             atomicAdd(&cnt[root], len);
-            atomicAdd(&sums[2 * (size_t)root], (u64)len * (u64)rowi);
-            atomicAdd(&sums[2 * (size_t)root + 1], (u64)len * (u64)(2 * c0 + lane + j) / 2ULL);
+            atomicAdd(&sums[3 * (size_t)root], (u64)len * (u64)rowi);
+            atomicAdd(&sums[3 * (size_t)root + 1], (u64)len * (u64)(2 * c0 + lane + j) / 2ULL);
+            if (planes > 1) atomicAdd(&sums[3 * (size_t)root + 2], (u64)len * (u64)plane);
         }
         prev_last = __shfl(s.v, 63);
     }
@@ -139,9 +144,9 @@ __global__ __launch_bounds__(256) void cc_accumulate_kernel(const uint8_t *__res
 
 __global__ __launch_bounds__(256) void cc_emit_kernel(const uint8_t *__restrict__ mask, const int *__restrict__ parent,
                                                       const unsigned *__restrict__ cnt, const u64 *__restrict__ sums,
-                                                      int N, int H, int W, int *__restrict__ count,
-                                                      float *__restrict__ out, int *__restrict__ keys, int max_out) {
-    const int64_t total = (int64_t)N * H * W;
+                                                      int64_t total, int planes, int H, int W,
+                                                      int *__restrict__ count, float *__restrict__ out,
+                                                      int *__restrict__ keys, int max_out) {
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
         if (parent[g] != (int)g) continue;
         const int idx = atomicAdd(count, 1);
@@ -149,10 +154,18 @@ __global__ __launch_bounds__(256) void cc_emit_kernel(const uint8_t *__restrict_
         const double c = (double)mask[g];
         // scipy.ndimage.center_of_mass(out, labels, index): sum(out * grid) / sum(out) in float64, out == c
         const double norm = c * (double)cnt[g];
-        out[5 * (size_t)idx + 0] = (float)(g / ((int64_t)H * W));
-        out[5 * (size_t)idx + 1] = (float)(c * (double)sums[2 * (size_t)g] / norm);
-        out[5 * (size_t)idx + 2] = (float)(c * (double)sums[2 * (size_t)g + 1] / norm);
-        out[5 * (size_t)idx + 3] = 0.0f;
+        const float crow = (float)(c * (double)sums[3 * (size_t)g] / norm);
+        const float ccol = (float)(c * (double)sums[3 * (size_t)g + 1] / norm);
+        out[5 * (size_t)idx + 0] = (float)(g / ((int64_t)planes * H * W));
+        if (planes > 1) {                                       // (x, y, z) = the three axes of the volume in order
+            out[5 * (size_t)idx + 1] = (float)(c * (double)sums[3 * (size_t)g + 2] / norm);
+            out[5 * (size_t)idx + 2] = crow;
+            out[5 * (size_t)idx + 3] = ccol;
+        } else {
+            out[5 * (size_t)idx + 1] = crow;
+            out[5 * (size_t)idx + 2] = ccol;
+            out[5 * (size_t)idx + 3] = 0.0f;
+        }
         out[5 * (size_t)idx + 4] = (float)c;
         keys[idx] = (int)g;
     }
@@ -165,33 +178,45 @@ inline unsigned cc_grid(int64_t items) {
 
 }  // namespace
 
+static int centroids_launch(const uint8_t *mask, int N, int planes, int H, int W, void *workspace, int32_t *count, float *out,
+                            int32_t *keys, int max_out, void *stream, const char *who) {
+    SQ_REQUIRE(mask && workspace && count && out && keys && max_out > 0, "%s: null pointer", who);
+    SQ_REQUIRE(N > 0 && planes > 0 && H > 0 && W > 0 && (int64_t)N * planes * H * W < ((int64_t)1 << 31),
+               "%s: the mask must have fewer than 2^31 elements", who);
+    SQ_REQUIRE((((uintptr_t)workspace) & 15u) == 0, "%s: workspace must be 16-byte aligned", who);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)N * planes * H * W;
+    unsigned long long *sums = reinterpret_cast<unsigned long long *>(workspace);     // 8-byte items first
+    int *parent = reinterpret_cast<int *>(sums + 3 * total);
+    unsigned *cnt = reinterpret_cast<unsigned *>(parent + total);
+    const int rows = N * planes * H;
+    if (hipMemsetAsync(count, 0, sizeof(int32_t), st) != hipSuccess) {
+        sq_set_error("%s: cannot clear the counter", who);
+        return SQ_ELAUNCH;
+    }
+    hipLaunchKernelGGL(cc_rowscan_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, mask, parent, cnt, sums, rows, W);
+    hipLaunchKernelGGL(cc_merge_kernel, dim3(cc_grid(total)), dim3(256), 0, st, mask, parent, total, planes, H, W);
+    hipLaunchKernelGGL(cc_compress_kernel, dim3(cc_grid(total)), dim3(256), 0, st, parent, total);
+    hipLaunchKernelGGL(cc_accumulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, mask, parent, cnt, sums, rows, planes, H,
+                       W);
+    hipLaunchKernelGGL(cc_emit_kernel, dim3(cc_grid(total)), dim3(256), 0, st, mask, parent, cnt, sums, total, planes, H, W,
+                       count, out, keys, max_out);
+    return sq_check_launch(who);
+}
+
 extern "C" int64_t sq_mask_centroids_workspace(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0 || (int64_t)N * H * W >= ((int64_t)1 << 31)) return -1;
-    return (int64_t)N * H * W * (4 + 4 + 16);                  // parent, count, (sum row, sum col)
+    return (int64_t)N * H * W * (4 + 4 + 24);                  // parent, count, three coordinate sums
 }
 
 extern "C" int sq_mask_centroids_u8(const uint8_t *mask, int N, int H, int W, void *workspace, int32_t *count,
                                     float *out, int32_t *keys, int max_out, void *stream) {
-    SQ_REQUIRE(mask && workspace && count && out && keys && max_out > 0, "sq_mask_centroids_u8: null pointer");
-    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && (int64_t)N * H * W < ((int64_t)1 << 31),
-               "sq_mask_centroids_u8: N*H*W must be in (0, 2^31)");
-    SQ_REQUIRE((((uintptr_t)workspace) & 15u) == 0, "sq_mask_centroids_u8: workspace must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t total = (int64_t)N * H * W;
-    // 16-byte sums first so every array stays aligned
-    unsigned long long *sums = reinterpret_cast<unsigned long long *>(workspace);
-    int *parent = reinterpret_cast<int *>(sums + 2 * total);
-    unsigned *cnt = reinterpret_cast<unsigned *>(parent + total);
-    const int rows = N * H;
-    if (hipMemsetAsync(count, 0, sizeof(int32_t), st) != hipSuccess) {
-        sq_set_error("sq_mask_centroids_u8: cannot clear the counter");
-        return SQ_ELAUNCH;
-    }
-    hipLaunchKernelGGL(cc_rowscan_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, mask, parent, cnt, sums, rows, W);
-    hipLaunchKernelGGL(cc_merge_kernel, dim3(cc_grid(total)), dim3(256), 0, st, mask, parent, N, H, W);
-    hipLaunchKernelGGL(cc_compress_kernel, dim3(cc_grid(total)), dim3(256), 0, st, parent, total);
-    hipLaunchKernelGGL(cc_accumulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, mask, parent, cnt, sums, rows, H, W);
-    hipLaunchKernelGGL(cc_emit_kernel, dim3(cc_grid(total)), dim3(256), 0, st, mask, parent, cnt, sums, N, H, W, count, out,
-                       keys, max_out);
-    return sq_check_launch("sq_mask_centroids_u8");
+    return centroids_launch(mask, N, 1, H, W, workspace, count, out, keys, max_out, stream, "sq_mask_centroids_u8");
+}
+
+// volumes: mask (N, D0, D1, D2) uint8, 6-connectivity; rows [frame, x, y, z, class] with (x, y, z) the centre along
+// (D0, D1, D2); workspace = sq_mask_centroids_workspace(N * D0, D1, D2)
+extern "C" int sq_volume_centroids_u8(const uint8_t *mask, int N, int D0, int D1, int D2, void *workspace, int32_t *count,
+                                      float *out, int32_t *keys, int max_out, void *stream) {
+    return centroids_launch(mask, N, D0, D1, D2, workspace, count, out, keys, max_out, stream, "sq_volume_centroids_u8");
 }
