@@ -186,3 +186,22 @@ def test_dense_split_reduction_vs_fp64(M, K, N, act):
     assert np.max(np.abs(y - ref)) <= 2e-5 * np.max(np.abs(ref))
     y2 = ops.conv2d(dev(x.reshape(M, 1, 1, K)), dev(w.reshape(1, 1, K, N)), dev(b), act=act).cpu().numpy()
     assert_bit_exact(y2.reshape(M, N), y, "conv2d routes dense layers to the same kernel")
+
+
+def test_tensors_over_2gib_take_the_64bit_kernel_and_keep_the_bits():
+    """>= 2 GiB operands cannot use 32-bit buffer offsets: the dispatcher falls back to the one-tile-per-block
+    kernel with 64-bit addressing.  Batch independence gives the check: every image of the big batch equals the
+    same image convolved on its own (which runs the pipelined kernel)."""
+    N, H, W, C = 130, 512, 512, 16                              # 130 * 512 * 512 * 16 * 4 B = 2.03 GiB
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(0)
+    x = torch.randn((N, H, W, C), device="cuda:0", generator=g)
+    w = dev(rand_weights(5, (3, 3, C, C)))
+    b = dev(rand_weights(6, (C,), 0.1))
+    assert x.numel() * 4 >= 2 ** 31
+    y = ops.conv2d(x, w, b, act="relu")
+    for n in (0, 77, 129):
+        one = ops.conv2d(x[n:n + 1].contiguous(), w, b, act="relu")
+        assert torch.equal(y[n:n + 1], one), n
+    del x, y
+    torch.cuda.empty_cache()
