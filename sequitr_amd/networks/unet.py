@@ -408,9 +408,15 @@ class UNet2D(UNet):
         self._mask = None
         self._dropout_calls = 0
         self._builds += 1
-        if self.fuse and self._fusable():
+        if self.fuse and self._fusable() and self._fits_fused(features):
             return self._build_fused(features)
         return UNet.build(self, features)
+
+    def _fits_fused(self, features):
+        """the fused kernels address with 32-bit buffer offsets: the largest activation must stay below 2 GiB
+        (bigger batches run hook by hook, where conv2d switches to its 64-bit kernel)"""
+        n = int(np.prod(features.shape)) // max(1, self.width * self.height * self.n_inputs)
+        return n * self.width * self.height * max(self.filters[0], 2 * self.n_outputs) * 4 < (1 << 31)
 
     # -- fused inference graph ---------------------------------------------------------------
     _HOOKS = ('conv_layer', 'conv_layer_1x1', 'conv_transpose_layer', 'pool_layer', 'max_pool_layer',

@@ -206,3 +206,18 @@ def test_graphed_predict_equals_eager():
         assert torch.equal(mask, ref_mask)
     with pytest.raises(ValueError):
         g(tiles(0, 2, 64, 64))
+
+
+def test_batches_over_2gib_fall_back_to_the_hook_path_with_the_same_masks():
+    """130 tiles of 512x512: the level-0 activation is 2.03 GiB, past the fused kernels' 32-bit offsets."""
+    params = {"shape": (512, 512), "filters": (16, 32)}
+    net, _ = make(params, seed=2)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(1)
+    x = torch.randn((130, 512, 512, 1), device="cuda:0", generator=g)
+    assert not net._fits_fused(x) and net._fits_fused(x[:32])
+    big = net.predict(x).clone()
+    for lo in (0, 96):
+        assert torch.equal(net.predict(x[lo:lo + 32].contiguous()), big[lo:lo + 32])
+    del x, big
+    torch.cuda.empty_cache()
