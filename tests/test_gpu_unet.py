@@ -221,3 +221,15 @@ def test_batches_over_2gib_fall_back_to_the_hook_path_with_the_same_masks():
         assert torch.equal(net.predict(x[lo:lo + 32].contiguous()), big[lo:lo + 32])
     del x, big
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("shape", [(32, 80), (112, 48)])
+def test_rectangular_tiles_fused_and_hook_paths_bit_exact(shape):
+    for fuse in (True, False):
+        params = {"shape": shape, "fuse": fuse}
+        net, w = make(params, seed=7)
+        x = tiles(3, 2, shape[0], shape[1])
+        mask = net.predict(x)
+        ref = unet_oracle.unet_forward(x, w, params)
+        assert_bit_exact(net.logits().cpu().numpy(), ref, "logits %s fuse=%s" % (shape, fuse))
+        assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "mask")
