@@ -81,7 +81,7 @@ int sq_avgpool2x2_fwd_f32(const float *x, float *y, int N, int H, int W, int C, 
  * bias, then bridge(upscale, skip).
  *   x (N,H,W,Cin)  w (2,2,Cout,Cin)  bias (Cout) or NULL
  *   skip (N,2H,2W,Cout) or NULL when bridge == SQ_BRIDGE_NONE   y (N,2H,2W,Cout)
- * Cin % 16 == 0, Cout % 16 == 0.
+ * Cin % 16 == 0, Cout % 4 == 0.
  */
 int sq_convT2x2s2_nhwc_fwd_f32(const float *x, const float *w, const float *bias,
                                const float *skip, float *y, int N, int H, int W,

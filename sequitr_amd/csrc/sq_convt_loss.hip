@@ -31,7 +31,9 @@ __global__ __launch_bounds__(256) void convT2x2_mfma_f32_kernel(
     const int srow = tid >> 2, sq = tid & 3;  // staging: 64 rows x 4 float4
     for (int cc = 0; cc < Cin; cc += 16) {
         {
-            const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)(r0 + srow) * Cin + cc + sq * 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + srow < 4 * Cout)                           // ragged last row block (Cout % 16 != 0)
+                v = *reinterpret_cast<const float4 *>(w + (size_t)(r0 + srow) * Cin + cc + sq * 4);
             float *d = as + srow * CT_PS + sq * 4;
             *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.y);
             *reinterpret_cast<float2 *>(d + 2) = make_float2(v.z, v.w);
@@ -59,6 +61,7 @@ __global__ __launch_bounds__(256) void convT2x2_mfma_f32_kernel(
     }
 
     const int rho = r0 + 16 * wv + 4 * kk;
+    if (rho >= 4 * Cout) return;                                // after the last barrier: safe to leave
     const int ab = rho / Cout, o = rho % Cout;
     const int a = ab >> 1, b = ab & 1;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -157,15 +160,15 @@ extern "C" int sq_convT2x2s2_nhwc_fwd_f32(const float *x, const float *w, const 
                                           int Cout, int bridge, void *stream) {
     SQ_REQUIRE(x && w && y, "sq_convT2x2s2_nhwc_fwd_f32: null tensor pointer");
     SQ_REQUIRE(N > 0 && H > 0 && W > 0, "sq_convT2x2s2_nhwc_fwd_f32: bad shape");
-    SQ_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0 && Cin > 0 && Cout > 0,
-               "sq_convT2x2s2_nhwc_fwd_f32: Cin=%d and Cout=%d must be multiples of 16", Cin, Cout);
+    SQ_REQUIRE(Cin % 16 == 0 && Cout % 4 == 0 && Cin > 0 && Cout > 0,
+               "sq_convT2x2s2_nhwc_fwd_f32: Cin=%d must be a multiple of 16, Cout=%d of 4", Cin, Cout);
     SQ_REQUIRE(bridge >= SQ_BRIDGE_NONE && bridge <= SQ_BRIDGE_SUB, "sq_convT2x2s2_nhwc_fwd_f32: bad bridge %d", bridge);
     SQ_REQUIRE(bridge == SQ_BRIDGE_NONE || skip, "sq_convT2x2s2_nhwc_fwd_f32: bridge needs a skip tensor");
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(w); SQ_REQUIRE_ALIGNED(y);
     if (bias) SQ_REQUIRE_ALIGNED(bias);
     if (skip) SQ_REQUIRE_ALIGNED(skip);
     const int64_t P = (int64_t)N * H * W;
-    dim3 grid((unsigned)((P + 63) / 64), (unsigned)(4 * Cout / 64));
+    dim3 grid((unsigned)((P + 63) / 64), (unsigned)((4 * Cout + 63) / 64));
     hipLaunchKernelGGL(convT2x2_mfma_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        x, w, bias, skip, y, P, H, W, Cin, Cout, bridge);
     return sq_check_launch("sq_convT2x2s2_nhwc_fwd_f32");

@@ -70,7 +70,7 @@ def test_pools_bit_exact(C):
     assert_bit_exact(ops.avgpool2x2(dev(x)).cpu().numpy(), co.avgpool2x2(x), "avgpool")
 
 
-@pytest.mark.parametrize("Cin,Cout", [(32, 16), (64, 32), (256, 128)])
+@pytest.mark.parametrize("Cin,Cout", [(32, 16), (64, 32), (256, 128), (16, 8), (48, 24), (32, 20)])
 @pytest.mark.parametrize("bridge", [None, "eltwise_add", "eltwise_mul", "eltwise_sub"])
 def test_convT_bridge_bit_exact(Cin, Cout, bridge):
     x = tiles(4, 2, 9, 13, Cin)                 # P = 234 pixels: ragged vs the 64-pixel block

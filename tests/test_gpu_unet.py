@@ -233,3 +233,15 @@ def test_rectangular_tiles_fused_and_hook_paths_bit_exact(shape):
         ref = unet_oracle.unet_forward(x, w, params)
         assert_bit_exact(net.logits().cpu().numpy(), ref, "logits %s fuse=%s" % (shape, fuse))
         assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "mask")
+
+
+@pytest.mark.parametrize("filters", [(32, 64, 128), (8, 16, 32), (16, 64), (48, 96)])
+def test_other_filter_schedules_bit_exact(filters):
+    """filter counts other than the default: no FIRST / head / UP fusion at 32+, no fused path at all for 8."""
+    params = {"shape": (32, 32), "filters": filters, "num_outputs": 3}
+    net, w = make(params, seed=9)
+    x = tiles(4, 2, 32, 32)
+    mask = net.predict(x)
+    ref = unet_oracle.unet_forward(x, w, params)
+    assert_bit_exact(net.logits().cpu().numpy(), ref, "logits %s" % (filters,))
+    assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "mask")
