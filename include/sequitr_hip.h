@@ -263,7 +263,7 @@ int64_t sq_dense_workspace_f32(int M, int K, int N);
 int sq_dense_fwd_f32(const float *x, const float *w, const float *bias, float *y, float *workspace, int M, int K, int N,
                      float wscale, int act, void *stream);
 
-/* M (Ca,Cb) = sum_p a[p,:]^T b[p,:] with Ca <= 4, Cb % 4 == 0: weight gradient of to_image / from_image. */
+/* M (Ca,Cb) = sum_p a[p,:]^T b[p,:] with Ca <= 7, Cb % 4 == 0: weight gradient of to_image / from_image. */
 int64_t sq_wgrad1x1_small_workspace_f32(int64_t npix, int Ca, int Cb);
 int sq_wgrad1x1_small_f32(const float *a, const float *b, float *m, float *workspace, int64_t npix, int Ca, int Cb,
                           void *stream);

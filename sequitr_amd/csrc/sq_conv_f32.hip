@@ -280,7 +280,10 @@ int launch_small(const float *x, const float *w, const float *bias, float *logit
     case 2: hipLaunchKernelGGL(conv1x1_small_f32_kernel<2>, dim3(nb), dim3(256), 0, st, x, w, bias, logits, mask, npix, Cin, wscale, act); break;
     case 3: hipLaunchKernelGGL(conv1x1_small_f32_kernel<3>, dim3(nb), dim3(256), 0, st, x, w, bias, logits, mask, npix, Cin, wscale, act); break;
     case 4: hipLaunchKernelGGL(conv1x1_small_f32_kernel<4>, dim3(nb), dim3(256), 0, st, x, w, bias, logits, mask, npix, Cin, wscale, act); break;
-    default: sq_set_error("%s: Cout=%d unsupported (1..4)", what, Cout); return SQ_EINVAL;
+    case 5: hipLaunchKernelGGL(conv1x1_small_f32_kernel<5>, dim3(nb), dim3(256), 0, st, x, w, bias, logits, mask, npix, Cin, wscale, act); break;
+    case 6: hipLaunchKernelGGL(conv1x1_small_f32_kernel<6>, dim3(nb), dim3(256), 0, st, x, w, bias, logits, mask, npix, Cin, wscale, act); break;
+    case 7: hipLaunchKernelGGL(conv1x1_small_f32_kernel<7>, dim3(nb), dim3(256), 0, st, x, w, bias, logits, mask, npix, Cin, wscale, act); break;
+    default: sq_set_error("%s: Cout=%d unsupported (1..7)", what, Cout); return SQ_EINVAL;
     }
     return sq_check_launch(what);
 }
@@ -312,7 +315,7 @@ extern "C" int sq_conv2d_nhwc_fwd_f32(const float *x, const float *w, const floa
     SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_conv2d_nhwc_fwd_f32: bad activation %d", act);
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(w); SQ_REQUIRE_ALIGNED(y);
     if (bias) SQ_REQUIRE_ALIGNED(bias);
-    if (K == 1 && Cout <= 4 && Cin % 4 == 0)
+    if (K == 1 && Cout <= 7 && Cin % 4 == 0)                  // class heads (the reference allows up to 5 classes)
         return launch_small(x, w, bias, y, nullptr, (int64_t)N * H * W, Cin, Cout, wscale, act, st,
                             "sq_conv2d_nhwc_fwd_f32(1x1)");
     SQ_REQUIRE(Cout % 4 == 0, "sq_conv2d_nhwc_fwd_f32: Cout=%d must be a multiple of 4", Cout);
@@ -322,6 +325,15 @@ extern "C" int sq_conv2d_nhwc_fwd_f32(const float *x, const float *w, const floa
     if (Cin == 2)
         return K == 3 ? launch_direct<2, 3>(x, w, bias, y, N, H, W, Cout, wscale, act, st)
                       : launch_direct<2, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
+    if (K == 1 && Cin >= 3 && Cin <= 7) {                       // dgrad of a 3..7-class head
+        switch (Cin) {
+        case 3: return launch_direct<3, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
+        case 4: return launch_direct<4, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
+        case 5: return launch_direct<5, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
+        case 6: return launch_direct<6, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
+        default: return launch_direct<7, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
+        }
+    }
     // the pipelined kernel addresses tensors through 32-bit buffer offsets: < 2 GiB each
     const bool fits32 = (size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31);
     if ((Cin % 16 == 0 || Cin == 8) && conv_impl() == 2 && fits32)
@@ -332,7 +344,7 @@ extern "C" int sq_conv2d_nhwc_fwd_f32(const float *x, const float *w, const floa
     if (Cin == 8)
         return K == 3 ? dispatch_bn<3, 8>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st)
                       : dispatch_bn<1, 8>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st);
-    sq_set_error("sq_conv2d_nhwc_fwd_f32: Cin=%d unsupported (1, 2, 8 or a multiple of 16)", Cin);
+    sq_set_error("sq_conv2d_nhwc_fwd_f32: Cin=%d unsupported (1, 2, 8, a multiple of 16, or 3..7 for K = 1)", Cin);
     return SQ_EINVAL;
 }
 

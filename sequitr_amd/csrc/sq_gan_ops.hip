@@ -382,15 +382,15 @@ extern "C" int sq_mbstd_fwd_f32(const float *x, float *out, float *workspace, in
 }
 
 extern "C" int64_t sq_wgrad1x1_small_workspace_f32(int64_t npix, int Ca, int Cb) {
-    if (npix <= 0 || Ca < 1 || Ca > 4 || Cb <= 0 || Cb % 4) return -1;
+    if (npix <= 0 || Ca < 1 || Ca > 7 || Cb <= 0 || Cb % 4) return -1;
     return (int64_t)small_blocks(npix) * Ca * Cb * 4;
 }
 
 extern "C" int sq_wgrad1x1_small_f32(const float *a, const float *b, float *m, float *workspace, int64_t npix,
                                      int Ca, int Cb, void *stream) {
     SQ_REQUIRE(a && b && m && workspace, "sq_wgrad1x1_small_f32: null pointer");
-    SQ_REQUIRE(npix > 0 && Ca >= 1 && Ca <= 4 && Cb > 0 && Cb % 4 == 0,
-               "sq_wgrad1x1_small_f32: Ca=%d (1..4), Cb=%d (multiple of 4)", Ca, Cb);
+    SQ_REQUIRE(npix > 0 && Ca >= 1 && Ca <= 7 && Cb > 0 && Cb % 4 == 0,
+               "sq_wgrad1x1_small_f32: Ca=%d (1..7), Cb=%d (multiple of 4)", Ca, Cb);
     SQ_REQUIRE_ALIGNED(b);
     const int nb = small_blocks(npix);
     hipStream_t st = SQ_ST(stream);
@@ -399,7 +399,10 @@ extern "C" int sq_wgrad1x1_small_f32(const float *a, const float *b, float *m, f
     case 1: hipLaunchKernelGGL(wgrad1x1_small_kernel<1>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
     case 2: hipLaunchKernelGGL(wgrad1x1_small_kernel<2>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
     case 3: hipLaunchKernelGGL(wgrad1x1_small_kernel<3>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
-    default: hipLaunchKernelGGL(wgrad1x1_small_kernel<4>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
+    case 4: hipLaunchKernelGGL(wgrad1x1_small_kernel<4>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
+    case 5: hipLaunchKernelGGL(wgrad1x1_small_kernel<5>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
+    case 6: hipLaunchKernelGGL(wgrad1x1_small_kernel<6>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
+    default: hipLaunchKernelGGL(wgrad1x1_small_kernel<7>, dim3(nb), dim3(256), lds, st, a, b, workspace, npix, Cb); break;
     }
     int rc = sq_check_launch("sq_wgrad1x1_small_f32");
     if (rc) return rc;

@@ -619,7 +619,8 @@ extern "C" int sq_conv1x1_head_fwd_bf16(const void *x, const float *w, const flo
     case 2: hipLaunchKernelGGL(head_fwd_bf16_kernel<2>, dim3(nb), dim3(256), 0, st, BF(x), w, bias, logits, mask, npix, Cin); break;
     case 3: hipLaunchKernelGGL(head_fwd_bf16_kernel<3>, dim3(nb), dim3(256), 0, st, BF(x), w, bias, logits, mask, npix, Cin); break;
     case 4: hipLaunchKernelGGL(head_fwd_bf16_kernel<4>, dim3(nb), dim3(256), 0, st, BF(x), w, bias, logits, mask, npix, Cin); break;
-    default: sq_set_error("sq_conv1x1_head_fwd_bf16: Cout=%d unsupported (1..4)", Cout); return SQ_EINVAL;
+    case 5: hipLaunchKernelGGL(head_fwd_bf16_kernel<5>, dim3(nb), dim3(256), 0, st, BF(x), w, bias, logits, mask, npix, Cin); break;
+    default: sq_set_error("sq_conv1x1_head_fwd_bf16: Cout=%d unsupported (1..5)", Cout); return SQ_EINVAL;
     }
     return sq_check_launch("sq_conv1x1_head_fwd_bf16");
 }
@@ -632,13 +633,28 @@ extern "C" int64_t sq_conv1x1_head_bwd_workspace_bf16(int64_t npix, int Cin, int
 extern "C" int sq_conv1x1_head_bwd_bf16(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db,
                                         float *workspace, int64_t npix, int Cin, int Cout, void *stream) {
     SQ_REQUIRE(x && w && dz && dw && workspace && npix > 0, "sq_conv1x1_head_bwd_bf16: null pointer");
-    SQ_REQUIRE((Cin == 16 || Cin == 32) && Cout >= 1 && Cout <= 2, "sq_conv1x1_head_bwd_bf16: Cin=%d (16|32), Cout=%d (1..2)", Cin, Cout);
+    SQ_REQUIRE((Cin == 16 || Cin == 32) && Cout >= 1 && Cout <= 5, "sq_conv1x1_head_bwd_bf16: Cin=%d (16|32), Cout=%d (1..5)", Cin, Cout);
     const int nb = head_blocks(npix);
     hipStream_t st = SQ_ST(stream);
-    if (Cin == 16 && Cout == 1) hipLaunchKernelGGL((head_bwd_bf16_kernel<16, 1>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix);
-    else if (Cin == 16) hipLaunchKernelGGL((head_bwd_bf16_kernel<16, 2>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix);
-    else if (Cout == 1) hipLaunchKernelGGL((head_bwd_bf16_kernel<32, 1>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix);
-    else hipLaunchKernelGGL((head_bwd_bf16_kernel<32, 2>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix);
+#define SQ_HEAD_BWD(CI, CO) hipLaunchKernelGGL((head_bwd_bf16_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix)
+    if (Cin == 16) {
+        switch (Cout) {
+        case 1: SQ_HEAD_BWD(16, 1); break;
+        case 2: SQ_HEAD_BWD(16, 2); break;
+        case 3: SQ_HEAD_BWD(16, 3); break;
+        case 4: SQ_HEAD_BWD(16, 4); break;
+        default: SQ_HEAD_BWD(16, 5); break;
+        }
+    } else {
+        switch (Cout) {
+        case 1: SQ_HEAD_BWD(32, 1); break;
+        case 2: SQ_HEAD_BWD(32, 2); break;
+        case 3: SQ_HEAD_BWD(32, 3); break;
+        case 4: SQ_HEAD_BWD(32, 4); break;
+        default: SQ_HEAD_BWD(32, 5); break;
+        }
+    }
+#undef SQ_HEAD_BWD
     int rc = sq_check_launch("sq_conv1x1_head_bwd_bf16");
     if (rc) return rc;
     const int nw = Cin * Cout;

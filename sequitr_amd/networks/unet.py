@@ -346,9 +346,9 @@ class UNet2D(UNet):
 
     def conv_layer_1x1(self, x, filters):
         w, b = self._kernel((1, 1, x.shape[-1], filters)), self._bias(filters)
-        small = filters <= 4 and x.shape[-1] % 4 == 0
+        small = filters <= 7 and x.shape[-1] % 4 == 0
         if self.training:
-            if small and x.shape[-1] in (8, 16, 32):
+            if small and filters <= 4 and x.shape[-1] in (8, 16, 32):
                 return F.conv1x1_head(x, w, b)
             return F.conv2d(x, w, b, act=None)
         if small:
@@ -489,7 +489,7 @@ class UNet2D(UNet):
         if logits is None:
             wh = self._v('UNet/to_image', 'kernel', (1, 1, f[0], self.n_outputs))
             bh = self._v('UNet/to_image', 'bias', (self.n_outputs,))
-            if self.n_outputs <= 4:
+            if self.n_outputs <= 7:
                 logits, self._mask = ops.conv1x1_argmax(net[-1], wh, bh)
             else:
                 logits = ops.conv2d(net[-1], wh, bh, act=None)

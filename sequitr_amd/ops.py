@@ -574,11 +574,11 @@ def conv_wgrad_raw(x, dy, K, want_bias=False, dw_out=None, db_out=None):
     if dw_out is not None or db_out is not None:
         raise _lib.SequitrHipError("conv wgrad: gradient destinations need the MFMA kernel (Cin=%d Cout=%d)" % (Cin, Cout))
     npix = N * H * W
-    if K == 1 and Cin <= 4 and Cout % 4 == 0:                      # from_image: image side is the input
+    if K == 1 and Cin <= 7 and Cout % 4 == 0:                      # from_image: image side is the input
         dw = wgrad1x1_small(x, dy).view(1, 1, Cin, Cout)
         db = wgrad1x1_small(_ones(npix, 1, x.device), dy).view(Cout) if want_bias else None
         return dw, db
-    if K == 1 and Cout <= 4 and Cin % 4 == 0:                      # to_image: image side is the output
+    if K == 1 and Cout <= 7 and Cin % 4 == 0:                      # to_image / class heads: image side is the output
         dw = wgrad1x1_small(dy, x).t().contiguous().view(1, 1, Cin, Cout)
         db = wgrad1x1_small(dy, _ones(npix, 4, x.device))[:, 0].contiguous() if want_bias else None
         return dw, db

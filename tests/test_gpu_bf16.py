@@ -277,3 +277,29 @@ def test_pack_plan_equals_the_single_packs():
             assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (name, key)
             checked += 1
     assert checked >= 20
+
+
+@pytest.mark.parametrize("cfg", [{"filters": (16, 32), "num_outputs": 3}, {"filters": (16, 32), "num_outputs": 5},
+                                 {"filters": (32, 64), "num_outputs": 2}, {"filters": (16, 32), "bridge": "eltwise_add"}])
+def test_bf16_training_other_configurations_match_the_emulation(cfg):
+    """class counts up to 5 and other schedules / bridges through the bf16 graph (fused tape entries on):
+    loss close to the fp64 graph's and gradients aligned with it."""
+    from oracle import torch_ref as tr
+    from sequitr_amd.train import UNetTrainer
+    params = dict({"shape": (32, 32), "dropout": 0.0, "device": "cuda:0", "seed": 3, "dtype": "bf16"}, **cfg)
+    nout = params.get("num_outputs", 2)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 32, 32, 1)).astype(np.float32)
+    lab = rng.integers(0, nout, (2, 32, 32))
+    onehot = (lab[..., None] == np.arange(nout)).astype(np.uint8)
+    wmap = (1 + rng.random((2, 32, 32, 1))).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to("cuda:0")
+    t = UNetTrainer(params, learning_rate=0.01)
+    w0 = t.state_dict()
+    loss = t.forward_backward(d(x), d(onehot), d(wmap))
+    rloss, rgrads, _ = tr.unet_loss_and_grads(x, onehot, wmap, w0, params)
+    assert abs(loss.item() - rloss) <= 2e-2 * abs(rloss)
+    g = t.grads()
+    num = sum(float((g[k].astype(np.float64) * rgrads[k]).sum()) for k in rgrads)
+    den = np.sqrt(sum(float((g[k].astype(np.float64) ** 2).sum()) for k in rgrads) * sum(float((rgrads[k] ** 2).sum()) for k in rgrads))
+    assert num / den > 0.97, num / den

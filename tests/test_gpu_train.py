@@ -264,3 +264,26 @@ def test_direct_gradient_sinks_equal_autograd_accumulation(dtype):
     gb = b.grads()
     for k in gb:
         assert np.array_equal(a_first[k], gb[k]), k
+
+
+@pytest.mark.parametrize("cfg", [{"filters": (8, 16), "num_outputs": 2}, {"filters": (48, 96), "num_outputs": 3},
+                                 {"filters": (16, 32), "num_outputs": 5}, {"filters": (16, 32), "bridge": "concat"},
+                                 {"filters": (16, 32), "bridge": None}])
+def test_training_other_configurations_vs_fp64(cfg):
+    """filter schedules, class counts (the reference allows up to 5, weightmap.py:60-61) and bridges other than
+    the default: loss and gradients vs the fp64 graph."""
+    params = dict({"shape": (32, 32), "dropout": 0.0, "device": "cuda:0", "seed": 2}, **cfg)
+    nout = params.get("num_outputs", 2)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 32, 32, 1)).astype(np.float32)
+    lab = rng.integers(0, nout, (2, 32, 32))
+    onehot = (lab[..., None] == np.arange(nout)).astype(np.uint8)
+    wmap = (1 + rng.random((2, 32, 32, 1))).astype(np.float32)
+    t = UNetTrainer(params, learning_rate=0.01)
+    w0 = t.state_dict()
+    loss = t.forward_backward(dev(x), dev(onehot), dev(wmap))
+    rloss, rgrads, _ = tr.unet_loss_and_grads(x, onehot, wmap, w0, params)
+    assert abs(loss.item() - rloss) <= 2e-5 * abs(rloss)
+    g = t.grads()
+    for k in rgrads:
+        assert np.max(np.abs(g[k] - rgrads[k])) <= 1e-3 * np.max(np.abs(rgrads[k])) + 1e-7, k

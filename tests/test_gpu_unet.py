@@ -245,3 +245,15 @@ def test_other_filter_schedules_bit_exact(filters):
     ref = unet_oracle.unet_forward(x, w, params)
     assert_bit_exact(net.logits().cpu().numpy(), ref, "logits %s" % (filters,))
     assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "mask")
+
+
+@pytest.mark.parametrize("nout", [1, 3, 5, 7])
+def test_class_counts_up_to_seven_bit_exact(nout):
+    """the reference's label pipeline carries up to 5 classes (weightmap.py:60-61, unet.py:396-398)"""
+    params = {"shape": (32, 48), "filters": (16, 32), "num_outputs": nout}
+    net, w = make(params, seed=nout)
+    x = tiles(nout, 2, 32, 48)
+    mask = net.predict(x)
+    ref = unet_oracle.unet_forward(x, w, params)
+    assert_bit_exact(net.logits().cpu().numpy(), ref, "logits")
+    assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "mask")
