@@ -257,3 +257,15 @@ def test_class_counts_up_to_seven_bit_exact(nout):
     ref = unet_oracle.unet_forward(x, w, params)
     assert_bit_exact(net.logits().cpu().numpy(), ref, "logits")
     assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "mask")
+
+
+def test_one_by_one_kernel_configuration_bit_exact():
+    """`kernel` = (1,1) (base.py hyper-parameter): every conv runs through the 1x1 kernels, hook path only."""
+    params = {"shape": (32, 32), "filters": (16, 32), "kernel": (1, 1)}
+    net, w = make(params, seed=21)
+    assert w["UNet/down0/conv1/kernel"].shape == (1, 1, 1, 16)
+    x = tiles(2, 2, 32, 32)
+    mask = net.predict(x)
+    ref = unet_oracle.unet_forward(x, w, params)
+    assert_bit_exact(net.logits().cpu().numpy(), ref, "logits")
+    assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "mask")
