@@ -60,7 +60,7 @@ const char *sq_last_error(void);
  * KxK (K = 1 or 3) SAME stride-1 convolution + bias + activation.
  *   x (N,H,W,Cin)  w (K,K,Cin,Cout)  bias (Cout) or NULL  y (N,H,W,Cout)
  * wscale: runtime equalised-LR scale, w' = fl(w*wscale) (gan.py:75-79); 1.0f for the U-Net.
- * Supported: Cin in {1,2} or Cin % 8 == 0; Cout % 4 == 0, or Cout <= 4 with K == 1.
+ * Supported: Cin in 1..8 or Cin % 16 == 0; Cout % 4 == 0, or Cout <= 7 with K == 1 and Cin % 4 == 0.
  */
 int sq_conv2d_nhwc_fwd_f32(const float *x, const float *w, const float *bias, float *y,
                            int N, int H, int W, int Cin, int Cout, int K,
@@ -92,7 +92,7 @@ int sq_bridge_fwd_f32(const float *a, const float *b, float *y, int64_t n, int b
 
 /*
  * to_image head of UNet.build (sequitr/networks/unet.py:252-253) fused with the
- * prediction argmax: 1x1 conv Cin -> Cout (Cout <= 4) writes f32 logits and the
+ * prediction argmax: 1x1 conv Cin -> Cout (Cout <= 7) writes f32 logits and the
  * uint8 class mask (ties -> lowest index) in one pass.  mask may be NULL.
  */
 int sq_conv1x1_argmax_fwd_f32(const float *x, const float *w, const float *bias,
@@ -133,7 +133,7 @@ int sq_wsoftmax_ce_fwd_bwd_f32(const float *logits, const uint8_t *onehot, const
 int sq_conv_weight_transform_f32(const float *w, float *wt, int K, int Cin, int Cout, void *stream);
 
 /* dW (K,K,Cin,Cout) and db (Cout, may be NULL) of the KxK SAME convolution from X (N,H,W,Cin)
- * and dY (N,H,W,Cout).  Cin in {1 (K=3 only), 8} or Cin % 16 == 0; Cout % 4 == 0.
+ * and dY (N,H,W,Cout).  Cin in 1..7 (K=3 only), 8, or Cin % 16 == 0; Cout % 4 == 0.
  * workspace: sq_conv2d_nhwc_wgrad_workspace_f32(...) bytes (returns -1 for unsupported shapes). */
 int64_t sq_conv2d_nhwc_wgrad_workspace_f32(int N, int H, int W, int Cin, int Cout, int K);
 int sq_conv2d_nhwc_wgrad_f32(const float *x, const float *dy, float *dw, float *db, float *workspace,
@@ -324,9 +324,10 @@ int sq_conv_pack_weights_multi_bf16(const float *base, void *out, const int32_t 
 int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H, int W,
                             int Cin, int Cout, int K, int act, void *stream);
 
-/* first conv of down0 in the bf16 graph: f32 (N,H,W,1) image -> bf16 (N,H,W,Cout), 3x3, f32 HWIO weights. */
+/* first conv of down0 in the bf16 graph: f32 (N,H,W,Cin) image, Cin 1..7 -> bf16 (N,H,W,Cout), 3x3, f32 HWIO
+ * weights (`num_inputs`, unet.py:131). */
 int sq_conv3x3_first_fwd_bf16(const float *x, const float *w, const float *bias, void *y, int N, int H, int W,
-                              int Cout, int act, void *stream);
+                              int Cin, int Cout, int act, void *stream);
 
 /* dW (K,K,Cin,Cout) f32 and db (Cout, may be NULL) f32 from bf16 X (N,H,W,Cin) and bf16 dY (N,H,W,Cout);
  * Cin % 16 == 0, Cout % 16 == 0.  Transposing LDS reads (ds_read_b64_tr_b16) feed the MFMA. */
@@ -386,10 +387,11 @@ int64_t sq_conv1x1_head_bwd_workspace_bf16(int64_t npix, int Cin, int Cout);
 int sq_conv1x1_head_bwd_bf16(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db,
                              float *workspace, int64_t npix, int Cin, int Cout, void *stream);
 
-/* weight gradient of the first (1 -> Cout) 3x3 convolution from the f32 image and a bf16 dY */
-int64_t sq_conv3x3_first_wgrad_workspace_bf16(int N, int H, int W, int Cout);
+/* weight gradient of the first (Cin -> Cout, Cin 1..7) 3x3 convolution from the f32 image and a bf16 dY:
+ * dW (3,3,Cin,Cout) f32, db (Cout) f32 or NULL */
+int64_t sq_conv3x3_first_wgrad_workspace_bf16(int N, int H, int W, int Cin, int Cout);
 int sq_conv3x3_first_wgrad_bf16(const float *x, const void *dy, float *dw, float *db, float *workspace, int N,
-                                int H, int W, int Cout, void *stream);
+                                int H, int W, int Cin, int Cout, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Mask -> connected components -> centroids (the step after the hot path).

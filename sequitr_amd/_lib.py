@@ -86,7 +86,7 @@ SIGNATURES = {
     "sq_conv_packed_weights_elems_bf16": (c_int64, [c_int] * 3),
     "sq_conv_pack_weights_bf16": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_float, c_int, c_void_p]),
     "sq_conv2d_nhwc_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
-    "sq_conv3x3_first_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "sq_conv3x3_first_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "sq_conv2d_nhwc_wgrad_workspace_bf16": (c_int64, [c_int] * 6),
     "sq_conv2d_nhwc_wgrad_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "sq_cast_f32_to_bf16": (c_int, [c_void_p] * 2 + [c_int64, c_void_p]),
@@ -109,8 +109,8 @@ SIGNATURES = {
     "sq_conv1x1_head_fwd_bf16": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
     "sq_conv1x1_head_bwd_workspace_bf16": (c_int64, [c_int64, c_int, c_int]),
     "sq_conv1x1_head_bwd_bf16": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]),
-    "sq_conv3x3_first_wgrad_workspace_bf16": (c_int64, [c_int] * 4),
-    "sq_conv3x3_first_wgrad_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "sq_conv3x3_first_wgrad_workspace_bf16": (c_int64, [c_int] * 5),
+    "sq_conv3x3_first_wgrad_bf16": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
 }
 
 _lib = None

@@ -328,22 +328,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     }
 }
 
-// first layer (Cin = 1, f32 image in): direct 3x3 conv, 16 output channels per thread, bf16 out
+// first layer (Cin = 1..7, f32 image in): direct 3x3 conv, 16 output channels per thread, bf16 out;
+// one fmaf chain per output in (tap, channel) order, as the f32 direct kernel
+template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                const float *__restrict__ bias, __bf16 *__restrict__ y,
                                                                int N, int H, int W, int Cout, int act, int tiles_x,
                                                                int tiles_y) {
     constexpr int HW = TW + 2;
-    __shared__ float xs[HW * HW];
-    __shared__ float wsh[9 * 16];
+    __shared__ float xs[HW * HW * CIN];
+    __shared__ float wsh[9 * CIN * 16];
     const int tid = threadIdx.x, sp = blockIdx.x;
     const int tx = sp % tiles_x, ty = (sp / tiles_x) % tiles_y, n = sp / (tiles_x * tiles_y);
     const int x0 = tx * TW, y0 = ty * TH, n0 = blockIdx.y * 16;
-    for (int idx = tid; idx < HW * HW; idx += 256) {
-        const int gy = y0 - 1 + idx / HW, gx = x0 - 1 + idx % HW;
-        xs[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)n * H + gy) * W + gx] : 0.f;
+    for (int idx = tid; idx < HW * HW * CIN; idx += 256) {
+        const int pix = idx / CIN, c = idx % CIN;
+        const int gy = y0 - 1 + pix / HW, gx = x0 - 1 + pix % HW;
+        xs[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[(((size_t)n * H + gy) * W + gx) * CIN + c] : 0.f;
     }
-    for (int idx = tid; idx < 144; idx += 256) wsh[idx] = (n0 + idx % 16 < Cout) ? w[(idx / 16) * Cout + n0 + idx % 16] : 0.f;
+    for (int idx = tid; idx < 9 * CIN * 16; idx += 256)
+        wsh[idx] = (n0 + idx % 16 < Cout) ? w[(size_t)(idx / 16) * Cout + n0 + idx % 16] : 0.f;
     __syncthreads();
     const int py = tid >> 4, px = tid & 15;
     float a[16];
@@ -351,9 +355,12 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
     for (int o = 0; o < 16; ++o) a[o] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const float xv = xs[(py + t / 3) * HW + px + t % 3];
 #pragma unroll
-        for (int o = 0; o < 16; ++o) a[o] = __builtin_fmaf(wsh[t * 16 + o], xv, a[o]);
+        for (int c = 0; c < CIN; ++c) {
+            const float xv = xs[((py + t / 3) * HW + px + t % 3) * CIN + c];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) a[o] = __builtin_fmaf(wsh[(t * CIN + c) * 16 + o], xv, a[o]);
+        }
     }
     const int gy = y0 + py, gx = x0 + px;
     if (gy < H && gx < W) {
@@ -508,15 +515,22 @@ extern "C" int sq_conv2d_nhwc_dgrad_relu_bf16(const void *dy, const void *wp_t, 
     return conv_fwd_bf16_impl(dy, wp_t, nullptr, dx, N, H, W, Cin, Cout, K, SQ_ACT_NONE, stream, gate);
 }
 
-// first conv of down0 in the bf16 graph: f32 single-channel image in, bf16 activation out.
+// first conv of down0 in the bf16 graph: f32 image (1..7 channels) in, bf16 activation out.
 extern "C" int sq_conv3x3_first_fwd_bf16(const float *x, const float *w, const float *bias, void *y, int N, int H,
-                                         int W, int Cout, int act, void *stream) {
-    SQ_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0,
-               "sq_conv3x3_first_fwd_bf16: bad arguments (Cout %% 8 == 0)");
+                                         int W, int Cin, int Cout, int act, void *stream) {
+    SQ_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 7 && Cout > 0 && Cout % 8 == 0,
+               "sq_conv3x3_first_fwd_bf16: bad arguments (Cin 1..7, Cout %% 8 == 0)");
     SQ_REQUIRE_ALIGNED(y);
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    hipLaunchKernelGGL(conv_first_bf16_kernel, dim3((unsigned)(tiles_x * tiles_y) * N, (Cout + 15) / 16), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), x, w, bias, reinterpret_cast<__bf16 *>(y), N, H, W, Cout,
-                       act, tiles_x, tiles_y);
+    const dim3 grid((unsigned)(tiles_x * tiles_y) * N, (Cout + 15) / 16);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    __bf16 *yo = reinterpret_cast<__bf16 *>(y);
+#define SQ_FIRST(C)                                                                                                \
+    case C:                                                                                                        \
+        hipLaunchKernelGGL(conv_first_bf16_kernel<C>, grid, dim3(256), 0, st, x, w, bias, yo, N, H, W, Cout, act,  \
+                           tiles_x, tiles_y);                                                                      \
+        break;
+    switch (Cin) { SQ_FIRST(1) SQ_FIRST(2) SQ_FIRST(3) SQ_FIRST(4) SQ_FIRST(5) SQ_FIRST(6) SQ_FIRST(7) }
+#undef SQ_FIRST
     return sq_check_launch("sq_conv3x3_first_fwd_bf16");
 }

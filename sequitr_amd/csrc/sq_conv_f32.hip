@@ -325,14 +325,13 @@ extern "C" int sq_conv2d_nhwc_fwd_f32(const float *x, const float *w, const floa
     if (Cin == 2)
         return K == 3 ? launch_direct<2, 3>(x, w, bias, y, N, H, W, Cout, wscale, act, st)
                       : launch_direct<2, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
-    if (K == 1 && Cin >= 3 && Cin <= 7) {                       // dgrad of a 3..7-class head
-        switch (Cin) {
-        case 3: return launch_direct<3, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
-        case 4: return launch_direct<4, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
-        case 5: return launch_direct<5, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
-        case 6: return launch_direct<6, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
-        default: return launch_direct<7, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
-        }
+    if (Cin >= 3 && Cin <= 7) {                                 // multi-channel tiles (K = 3); dgrad of a 3..7-class head (K = 1)
+#define SQ_DIRECT(C)                                                                                \
+    case C:                                                                                         \
+        return K == 3 ? launch_direct<C, 3>(x, w, bias, y, N, H, W, Cout, wscale, act, st)          \
+                      : launch_direct<C, 1>(x, w, bias, y, N, H, W, Cout, wscale, act, st);
+        switch (Cin) { SQ_DIRECT(3) SQ_DIRECT(4) SQ_DIRECT(5) SQ_DIRECT(6) SQ_DIRECT(7) }
+#undef SQ_DIRECT
     }
     // the pipelined kernel addresses tensors through 32-bit buffer offsets: < 2 GiB each
     const bool fits32 = (size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31);
@@ -344,7 +343,7 @@ extern "C" int sq_conv2d_nhwc_fwd_f32(const float *x, const float *w, const floa
     if (Cin == 8)
         return K == 3 ? dispatch_bn<3, 8>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st)
                       : dispatch_bn<1, 8>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, st);
-    sq_set_error("sq_conv2d_nhwc_fwd_f32: Cin=%d unsupported (1, 2, 8, a multiple of 16, or 3..7 for K = 1)", Cin);
+    sq_set_error("sq_conv2d_nhwc_fwd_f32: Cin=%d unsupported (1..8 or a multiple of 16)", Cin);
     return SQ_EINVAL;
 }
 

@@ -305,31 +305,34 @@ int launch_dispatch(const float *x, const float *dy, float *dw, float *db, float
     SQ_WGRAD_DISPATCH(launch, x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
 }
 
-// ---- first layer (Cin == 1, 3x3): the 9 taps ride the 16 MFMA rows ---------------------------------
-//   A[i = tap][k = pixel] = X[pixel + tap] (rows 9..15 zero), B[k][j = co] = dY[pixel][co]
-// partials: [gridDim.x][10][Cout]  (9 taps + the bias row); blockIdx.y = 16-channel co group.
-template <typename TY>
+// ---- first layer (Cin = 1..7, 3x3): the 9 taps ride the 16 MFMA rows, one accumulator per input channel ------
+//   A[i = tap][k = pixel] = X[pixel + tap][c] (rows 9..15 zero), B[k][j = co] = dY[pixel][co]
+// partials: [gridDim.x][9*CIN + 1][Cout]  (row tap*CIN + c as in dW, then the bias row); blockIdx.y = 16-channel co group.
+template <typename TY, int CIN>
 __global__ __launch_bounds__(256) void conv_wgrad_cin1_f32_kernel(
     const float *__restrict__ x, const TY *__restrict__ dy, float *__restrict__ partials, int N, int H, int W,
     int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block) {
-    constexpr int HW = TW + 2;
-    __shared__ float xs[HW * HW + 8];
+    constexpr int HW = TW + 2, ROWS = 9 * CIN + 1;
+    __shared__ float xs[HW * HW * CIN + 8];
     __shared__ __attribute__((aligned(16))) float ys[TH * TW * 16];
-    __shared__ float red[4][10 * 16];
+    __shared__ float red[4][ROWS * 16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
     const int co0 = blockIdx.y * 16;
     const int t_begin = blockIdx.x * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
     const int ky = li / 3, kx = li % 3;
     const bool live_row = li < 9;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW, y0 = ty * TH;
-        for (int idx = tid; idx < HW * HW; idx += 256) {
-            const int gy = y0 - 1 + idx / HW, gx = x0 - 1 + idx % HW;
-            xs[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)n * H + gy) * W + gx] : 0.f;
+        for (int idx = tid; idx < HW * HW * CIN; idx += 256) {
+            const int pix = idx / CIN, c = idx % CIN;
+            const int gy = y0 - 1 + pix / HW, gx = x0 - 1 + pix % HW;
+            xs[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[(((size_t)n * H + gy) * W + gx) * CIN + c] : 0.f;
         }
         for (int idx = tid; idx < TH * TW * 4; idx += 256) {
             const int pix = idx >> 2, q = idx & 3;
@@ -351,10 +354,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_cin1_f32_kernel(
 #pragma unroll 4
         for (int ks = 0; ks < 16; ++ks) {
             const int r = 4 * wv + (ks >> 2), g = ks & 3;
-            const float a = live_row ? xs[(r + ky) * HW + 4 * g + kk + kx] : 0.f;
             const float b = ys[(r * TW + 4 * g + kk) * 16 + li];
             bsum += b;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            const float *xp = xs + ((r + ky) * HW + 4 * g + kk + kx) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float a = live_row ? xp[c] : 0.f;
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -362,28 +369,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_cin1_f32_kernel(
     bsum += __shfl_xor(bsum, 32);
     // D: rows (taps) 4*kk + j, column (co) li
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (4 * kk + j < 9) red[wv][(4 * kk + j) * 16 + li] = acc[j];
-    if (kk == 0) red[wv][9 * 16 + li] = bsum;
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * kk + j < 9) red[wv][((4 * kk + j) * CIN + c) * 16 + li] = acc[c][j];
+    if (kk == 0) red[wv][9 * CIN * 16 + li] = bsum;
     __syncthreads();
-    if (tid < 160) {
-        const int row = tid / 16, c = tid % 16;
+    for (int t = tid; t < ROWS * 16; t += 256) {
+        const int row = t / 16, c = t % 16;
         if (co0 + c < Cout)
-            partials[((size_t)blockIdx.x * 10 + row) * Cout + co0 + c] =
-                ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+            partials[((size_t)blockIdx.x * ROWS + row) * Cout + co0 + c] =
+                ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
     }
 }
 
+// rows = 9*Cin + 1
 __global__ __launch_bounds__(256) void conv_wgrad_cin1_finish_kernel(const float *__restrict__ partials,
                                                                       float *__restrict__ dw, float *__restrict__ db,
-                                                                      int nblk, int Cout, int G) {
+                                                                      int nblk, int Cout, int G, int rows) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t / G, g = t % G;
-    if (i >= 10 * Cout) return;
-    const float s = sq_group_reduce(partials + i, (size_t)10 * Cout, nblk, g, G);
+    if (i >= rows * Cout) return;
+    const float s = sq_group_reduce(partials + i, (size_t)rows * Cout, nblk, g, G);
     if (g != 0) return;
-    if (i < 9 * Cout) dw[i] = s;
-    else if (db) db[i - 9 * Cout] = s;
+    if (i < (rows - 1) * Cout) dw[i] = s;
+    else if (db) db[i - (rows - 1) * Cout] = s;
 }
 
 int cin1_grid(int N, int H, int W, int *tpb_out) {
@@ -395,16 +405,41 @@ int cin1_grid(int N, int H, int W, int *tpb_out) {
 }
 
 bool shape_ok(int N, int H, int W, int Cin, int Cout, int K) {
-    if (Cin == 1 && K == 3 && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 4 == 0) return true;
+    if (Cin >= 1 && Cin <= 7 && K == 3 && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 4 == 0) return true;
     return N > 0 && H > 0 && W > 0 && (K == 1 || K == 3) && (Cin % 16 == 0 || Cin == 8) && Cin > 0 &&
            Cout > 0 && Cout % 4 == 0 && (size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31);
+}
+
+template <typename TY>
+int launch_cin_small(const float *x, const TY *dy, float *dw, float *db, float *workspace, int N, int H, int W, int Cin,
+                     int Cout, hipStream_t st, const char *who) {
+    int tpb;
+    const int gx = cin1_grid(N, H, W, &tpb);
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const dim3 grid(gx, (Cout + 15) / 16);
+#define SQ_CIN_SMALL(C)                                                                                              \
+    case C:                                                                                                          \
+        hipLaunchKernelGGL((conv_wgrad_cin1_f32_kernel<TY, C>), grid, dim3(256), 0, st, x, dy, workspace, N, H, W,   \
+                           Cout, tiles_x, tiles_y, tiles_x * tiles_y * N, tpb);                                      \
+        break;
+    switch (Cin) {
+        SQ_CIN_SMALL(1) SQ_CIN_SMALL(2) SQ_CIN_SMALL(3) SQ_CIN_SMALL(4) SQ_CIN_SMALL(5) SQ_CIN_SMALL(6) SQ_CIN_SMALL(7)
+    default: sq_set_error("%s: Cin=%d unsupported (1..7)", who, Cin); return SQ_EINVAL;
+    }
+#undef SQ_CIN_SMALL
+    int rc = sq_check_launch(who);
+    if (rc) return rc;
+    const int G = sq_group_size(gx), rows = 9 * Cin + 1;
+    hipLaunchKernelGGL(conv_wgrad_cin1_finish_kernel, dim3((rows * Cout * G + 255) / 256), dim3(256), 0, st, workspace, dw,
+                       db, gx, Cout, G, rows);
+    return sq_check_launch(who);
 }
 
 }  // namespace
 
 extern "C" int64_t sq_conv2d_nhwc_wgrad_workspace_f32(int N, int H, int W, int Cin, int Cout, int K) {
     if (!shape_ok(N, H, W, Cin, Cout, K)) return -1;
-    if (Cin == 1) return (int64_t)cin1_grid(N, H, W, nullptr) * 10 * Cout * 4;
+    if (Cin <= 7) return (int64_t)cin1_grid(N, H, W, nullptr) * (9 * Cin + 1) * Cout * 4;
     return ws_dispatch(N, H, W, Cin, Cout, K) * 4;
 }
 
@@ -414,46 +449,24 @@ extern "C" int sq_conv2d_nhwc_wgrad_f32(const float *x, const float *dy, float *
     SQ_REQUIRE(x && dy && dw && workspace, "sq_conv2d_nhwc_wgrad_f32: null pointer");
     SQ_REQUIRE(shape_ok(N, H, W, Cin, Cout, K),
                "sq_conv2d_nhwc_wgrad_f32: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d K=%d "
-               "(Cin 8 or %%16, Cout %%4, K 1|3, tensors < 2 GiB)", N, H, W, Cin, Cout, K);
+               "(Cin 1..7 with K 3, 8 or %%16; Cout %%4; K 1|3; tensors < 2 GiB)", N, H, W, Cin, Cout, K);
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(workspace);
-    if (Cin == 1) {
-        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        int tpb;
-        const int gx = cin1_grid(N, H, W, &tpb);
-        const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-        hipLaunchKernelGGL(conv_wgrad_cin1_f32_kernel<float>, dim3(gx, (Cout + 15) / 16), dim3(256), 0, st, x, dy, workspace,
-                           N, H, W, Cout, tiles_x, tiles_y, tiles_x * tiles_y * N, tpb);
-        int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_f32(cin1)");
-        if (rc) return rc;
-        const int G = sq_group_size(gx);
-        hipLaunchKernelGGL(conv_wgrad_cin1_finish_kernel, dim3((10 * Cout * G + 255) / 256), dim3(256), 0, st, workspace,
-                           dw, db, gx, Cout, G);
-        return sq_check_launch("sq_conv2d_nhwc_wgrad_f32(cin1 finish)");
-    }
+    if (Cin <= 7)
+        return launch_cin_small<float>(x, dy, dw, db, workspace, N, H, W, Cin, Cout, reinterpret_cast<hipStream_t>(stream),
+                                       "sq_conv2d_nhwc_wgrad_f32(small Cin)");
     return launch_dispatch(x, dy, dw, db, workspace, N, H, W, Cin, Cout, K, reinterpret_cast<hipStream_t>(stream));
 }
 
 // first-layer weight gradient with a bf16 dY (the bf16 training graph): same MFMA-over-taps kernel
-extern "C" int64_t sq_conv3x3_first_wgrad_workspace_bf16(int N, int H, int W, int Cout) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4) return -1;
-    return (int64_t)cin1_grid(N, H, W, nullptr) * 10 * Cout * 4;
+extern "C" int64_t sq_conv3x3_first_wgrad_workspace_bf16(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 1 || Cin > 7 || Cout <= 0 || Cout % 4) return -1;
+    return (int64_t)cin1_grid(N, H, W, nullptr) * (9 * Cin + 1) * Cout * 4;
 }
 
 extern "C" int sq_conv3x3_first_wgrad_bf16(const float *x, const void *dy, float *dw, float *db, float *workspace,
-                                           int N, int H, int W, int Cout, void *stream) {
-    SQ_REQUIRE(x && dy && dw && workspace && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 4 == 0,
-               "sq_conv3x3_first_wgrad_bf16: bad arguments (Cout %% 4 == 0)");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int tpb;
-    const int gx = cin1_grid(N, H, W, &tpb);
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    hipLaunchKernelGGL(conv_wgrad_cin1_f32_kernel<__bf16>, dim3(gx, (Cout + 15) / 16), dim3(256), 0, st, x,
-                       reinterpret_cast<const __bf16 *>(dy), workspace, N, H, W, Cout, tiles_x, tiles_y,
-                       tiles_x * tiles_y * N, tpb);
-    int rc = sq_check_launch("sq_conv3x3_first_wgrad_bf16");
-    if (rc) return rc;
-    const int G = sq_group_size(gx);
-    hipLaunchKernelGGL(conv_wgrad_cin1_finish_kernel, dim3((10 * Cout * G + 255) / 256), dim3(256), 0, st, workspace, dw, db,
-                       gx, Cout, G);
-    return sq_check_launch("sq_conv3x3_first_wgrad_bf16(finish)");
+                                           int N, int H, int W, int Cin, int Cout, void *stream) {
+    SQ_REQUIRE(x && dy && dw && workspace && N > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 7 && Cout > 0 && Cout % 4 == 0,
+               "sq_conv3x3_first_wgrad_bf16: bad arguments (Cin 1..7, Cout %% 4 == 0)");
+    return launch_cin_small<__bf16>(x, reinterpret_cast<const __bf16 *>(dy), dw, db, workspace, N, H, W, Cin, Cout,
+                                    reinterpret_cast<hipStream_t>(stream), "sq_conv3x3_first_wgrad_bf16");
 }

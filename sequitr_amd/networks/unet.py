@@ -312,7 +312,7 @@ class UNet2D(UNet):
     # -- input ---------------------------------------------------------------------------
     def reshape_input(self, features):
         if isinstance(features, np.ndarray):
-            features = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32))
+            features = torch.from_numpy(np.require(features, np.float32, ['C', 'W']))
         if not isinstance(features, torch.Tensor):
             raise TypeError('features must be a numpy array or a torch tensor')
         features = features.to(self.device, dtype=torch.float32, non_blocking=True)
@@ -532,7 +532,7 @@ class GraphedPredict(object):
         """features: array / tensor of the captured shape; returns (mask, logits) static device tensors
         (overwritten by the next call)."""
         if isinstance(features, np.ndarray):
-            features = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32))
+            features = torch.from_numpy(np.require(features, np.float32, ['C', 'W']))
         if tuple(features.shape) != tuple(self.x.shape):
             raise ValueError('captured for %s, got %s' % (tuple(self.x.shape), tuple(features.shape)))
         self.x.copy_(features, non_blocking=True)
@@ -550,8 +550,8 @@ class UNet2DBf16(UNet2D):
         UNet2D.__init__(self, dict(params, fuse=False), mode)
         self.fuse_block = bool(params.get('fuse_block', True))   # conv_block / decoder junction as single tape entries
         self._skip_boxes = {}
-        if self.n_inputs != 1:
-            raise ValueError('the bf16 graph takes a single-channel f32 image (num_inputs == 1)')
+        if not 1 <= self.n_inputs <= 7:
+            raise ValueError('the bf16 graph takes an f32 image of 1..7 channels (num_inputs)')
         if self.batch_norm:
             raise ValueError('batch_norm is an f32-graph option (the bf16 graph has no BN kernels yet)')
         if any(f % 16 for f in self.filters) or self.bridge_type == 'concat':

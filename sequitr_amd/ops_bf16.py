@@ -93,14 +93,16 @@ def conv2d_dgrad_relu(dy, wp_t, gate, K):
 
 
 def conv3x3_first(x, w, bias, act="relu"):
-    """f32 (N,H,W,1) image, f32 (3,3,1,Cout) filter -> bf16 activation."""
+    """f32 (N,H,W,Cin) image (Cin 1..7), f32 (3,3,Cin,Cout) filter -> bf16 activation."""
     _chk(x, "x", dtype=torch.float32, ndim=4), _chk(w, "w", dtype=torch.float32, ndim=4)
-    N, H, W, _ = x.shape
+    N, H, W, Cin = x.shape
     Cout = w.shape[3]
+    if tuple(w.shape[:3]) != (3, 3, Cin):
+        raise ValueError("conv3x3_first: filter %s does not match %d input channels" % (tuple(w.shape), Cin))
     y = torch.empty((N, H, W, Cout), dtype=BF16, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.sq_conv3x3_first_fwd_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), N, H, W, Cout, ACT[act], _stream()),
-               "sq_conv3x3_first_fwd_bf16")
+    _lib.check(lib.sq_conv3x3_first_fwd_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, ACT[act],
+                                             _stream()), "sq_conv3x3_first_fwd_bf16")
     return y
 
 
@@ -355,14 +357,14 @@ def head_bwd(x, w, dz, want_dx=True, dw_out=None, db_out=None):
 
 
 def conv3x3_first_wgrad(x, dy, dw_out=None, db_out=None):
-    """x f32 (N,H,W,1), dy bf16 (N,H,W,Cout) -> (dW (3,3,1,Cout) f32, db f32)."""
+    """x f32 (N,H,W,Cin), dy bf16 (N,H,W,Cout) -> (dW (3,3,Cin,Cout) f32, db f32)."""
     _chk(x, "x", dtype=torch.float32, ndim=4), _chk(dy, "dy", ndim=4)
-    N, H, W, _ = x.shape
+    N, H, W, Cin = x.shape
     Cout = dy.shape[3]
     lib = _lib.load()
-    ws = _workspace(lib.sq_conv3x3_first_wgrad_workspace_bf16(N, H, W, Cout), x.device)
-    dw = _grad_out(dw_out, (3, 3, 1, Cout), x.device)
+    ws = _workspace(lib.sq_conv3x3_first_wgrad_workspace_bf16(N, H, W, Cin, Cout), x.device)
+    dw = _grad_out(dw_out, (3, 3, Cin, Cout), x.device)
     db = _grad_out(db_out, (Cout,), x.device)
-    _lib.check(lib.sq_conv3x3_first_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cout, _stream()),
-               "sq_conv3x3_first_wgrad_bf16")
+    _lib.check(lib.sq_conv3x3_first_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout,
+                                               _stream()), "sq_conv3x3_first_wgrad_bf16")
     return dw, db

@@ -64,8 +64,9 @@ def test_dgrad_pack_equals_transposed_conv():
     check_bf16(got, xg.grad.permute(0, 2, 3, 1), "dgrad bf16")
 
 
-def test_first_conv_bf16():
-    x, w, b = tiles(6, 2, 40, 24, 1), rand_weights(7, (3, 3, 1, 16), 0.5), rand_weights(8, (16,), 0.1)
+@pytest.mark.parametrize("cin", [1, 2, 3, 7])
+def test_first_conv_bf16(cin):
+    x, w, b = tiles(6, 2, 40, 24, cin), rand_weights(7, (3, 3, cin, 16), 0.5), rand_weights(8, (16,), 0.1)
     ref = TF.relu(TF.conv2d(torch.as_tensor(x, dtype=torch.float64).permute(0, 3, 1, 2),
                             torch.as_tensor(w, dtype=torch.float64).permute(3, 2, 0, 1),
                             torch.as_tensor(b, dtype=torch.float64), padding=1)).permute(0, 2, 3, 1)
@@ -159,14 +160,15 @@ def test_head_and_first_wgrad_bf16():
     check_bf16(dx, (dzt @ torch.as_tensor(w, dtype=torch.float64).reshape(16, 2).T).reshape(2, 24, 24, 16), "head dx")
     assert np.allclose(dw.cpu().numpy().reshape(16, 2), (xb.reshape(-1, 16).T @ dzt).numpy(), rtol=1e-5, atol=1e-4)
     assert np.allclose(db.cpu().numpy(), dzt.sum(0).numpy(), rtol=1e-5, atol=1e-4)
-    # first-layer weight gradient: f32 image, bf16 dY
-    xi, dy = tiles(27, 2, 20, 28, 1), tiles(28, 2, 20, 28, 16)
-    wt = torch.zeros((16, 1, 3, 3), dtype=torch.float64, requires_grad=True)
-    bt = torch.zeros(16, dtype=torch.float64, requires_grad=True)
-    TF.conv2d(torch.as_tensor(xi, dtype=torch.float64).permute(0, 3, 1, 2), wt, bt, padding=1).backward(bf16_round(dy).permute(0, 3, 1, 2))
-    dw, db = ob.conv3x3_first_wgrad(dev(xi), dev(dy, torch.bfloat16))
-    assert np.allclose(dw.cpu().numpy(), wt.grad.permute(2, 3, 1, 0).numpy(), rtol=1e-5, atol=1e-4)
-    assert np.allclose(db.cpu().numpy(), bt.grad.numpy(), rtol=1e-5, atol=1e-4)
+    # first-layer weight gradient: f32 image (1..7 channels), bf16 dY
+    for cin, cout in ((1, 16), (2, 16), (3, 32), (7, 16)):
+        xi, dy = tiles(27, 2, 20, 28, cin), tiles(28, 2, 20, 28, cout)
+        wt = torch.zeros((cout, cin, 3, 3), dtype=torch.float64, requires_grad=True)
+        bt = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        TF.conv2d(torch.as_tensor(xi, dtype=torch.float64).permute(0, 3, 1, 2), wt, bt, padding=1).backward(bf16_round(dy).permute(0, 3, 1, 2))
+        dw, db = ob.conv3x3_first_wgrad(dev(xi), dev(dy, torch.bfloat16))
+        assert np.allclose(dw.cpu().numpy(), wt.grad.permute(2, 3, 1, 0).numpy(), rtol=1e-5, atol=1e-4), cin
+        assert np.allclose(db.cpu().numpy(), bt.grad.numpy(), rtol=1e-5, atol=1e-4), cin
 
 
 def _batch(seed, n, size):
@@ -280,7 +282,8 @@ def test_pack_plan_equals_the_single_packs():
 
 
 @pytest.mark.parametrize("cfg", [{"filters": (16, 32), "num_outputs": 3}, {"filters": (16, 32), "num_outputs": 5},
-                                 {"filters": (32, 64), "num_outputs": 2}, {"filters": (16, 32), "bridge": "eltwise_add"}])
+                                 {"filters": (32, 64), "num_outputs": 2}, {"filters": (16, 32), "bridge": "eltwise_add"},
+                                 {"filters": (16, 32), "num_inputs": 2}, {"filters": (32, 64), "num_inputs": 3}])
 def test_bf16_training_other_configurations_match_the_emulation(cfg):
     """class counts up to 5 and other schedules / bridges through the bf16 graph (fused tape entries on):
     loss close to the fp64 graph's and gradients aligned with it."""
@@ -289,7 +292,7 @@ def test_bf16_training_other_configurations_match_the_emulation(cfg):
     params = dict({"shape": (32, 32), "dropout": 0.0, "device": "cuda:0", "seed": 3, "dtype": "bf16"}, **cfg)
     nout = params.get("num_outputs", 2)
     rng = np.random.default_rng(5)
-    x = rng.standard_normal((2, 32, 32, 1)).astype(np.float32)
+    x = rng.standard_normal((2, 32, 32, params.get("num_inputs", 1))).astype(np.float32)
     lab = rng.integers(0, nout, (2, 32, 32))
     onehot = (lab[..., None] == np.arange(nout)).astype(np.uint8)
     wmap = (1 + rng.random((2, 32, 32, 1))).astype(np.float32)

@@ -41,6 +41,10 @@ CONV_CASES = [
     (37, 16, 16, 16, 16, 3, "relu"),     # more tiles than one persistent block run divides evenly
     (1, 1, 100, 16, 16, 3, "relu"),      # a single row
     (1, 100, 1, 16, 32, 3, None),        # a single column
+    (2, 21, 19, 2, 16, 3, "relu"),       # multi-channel tiles (num_inputs 2..7): direct kernel
+    (1, 32, 32, 3, 32, 3, "relu"),
+    (2, 16, 24, 4, 16, 3, "relu"),
+    (1, 20, 28, 7, 24, 3, None),
 ]
 
 

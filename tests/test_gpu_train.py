@@ -31,7 +31,8 @@ def close(got, ref, tol, what=""):
 
 WG_CASES = [(2, 32, 48, 16, 16, 3), (1, 32, 32, 16, 32, 3), (2, 16, 16, 64, 64, 3), (1, 16, 16, 128, 64, 3),
             (1, 21, 19, 32, 32, 3), (2, 32, 32, 1, 16, 3), (1, 16, 16, 64, 256, 1), (1, 16, 16, 8, 16, 3),
-            (1, 8, 8, 256, 256, 3), (2, 40, 24, 1, 16, 3)]
+            (1, 8, 8, 256, 256, 3), (2, 40, 24, 1, 16, 3), (2, 21, 19, 2, 16, 3), (1, 32, 32, 3, 32, 3),
+            (2, 16, 16, 4, 16, 3), (1, 20, 28, 7, 24, 3)]
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,K", WG_CASES)
@@ -268,14 +269,15 @@ def test_direct_gradient_sinks_equal_autograd_accumulation(dtype):
 
 @pytest.mark.parametrize("cfg", [{"filters": (8, 16), "num_outputs": 2}, {"filters": (48, 96), "num_outputs": 3},
                                  {"filters": (16, 32), "num_outputs": 5}, {"filters": (16, 32), "bridge": "concat"},
-                                 {"filters": (16, 32), "bridge": None}])
+                                 {"filters": (16, 32), "bridge": None}, {"filters": (16, 32), "num_inputs": 2},
+                                 {"filters": (16, 32), "num_inputs": 3}, {"filters": (32, 64), "num_inputs": 4}])
 def test_training_other_configurations_vs_fp64(cfg):
     """filter schedules, class counts (the reference allows up to 5, weightmap.py:60-61) and bridges other than
     the default: loss and gradients vs the fp64 graph."""
     params = dict({"shape": (32, 32), "dropout": 0.0, "device": "cuda:0", "seed": 2}, **cfg)
     nout = params.get("num_outputs", 2)
     rng = np.random.default_rng(11)
-    x = rng.standard_normal((2, 32, 32, 1)).astype(np.float32)
+    x = rng.standard_normal((2, 32, 32, params.get("num_inputs", 1))).astype(np.float32)
     lab = rng.integers(0, nout, (2, 32, 32))
     onehot = (lab[..., None] == np.arange(nout)).astype(np.uint8)
     wmap = (1 + rng.random((2, 32, 32, 1))).astype(np.float32)

@@ -269,3 +269,15 @@ def test_one_by_one_kernel_configuration_bit_exact():
     ref = unet_oracle.unet_forward(x, w, params)
     assert_bit_exact(net.logits().cpu().numpy(), ref, "logits")
     assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "mask")
+
+
+@pytest.mark.parametrize("cin,filters", [(2, (16, 32)), (3, (16, 32)), (4, (32, 64)), (7, (16, 32))])
+def test_multi_channel_input_bit_exact(cin, filters):
+    """`num_inputs` > 1 (multi-channel microscopy tiles): conv1 of level 0 runs the small-Cin kernels."""
+    params = {"shape": (32, 32), "filters": filters, "num_inputs": cin}
+    net, w = make(params, seed=cin)
+    x = tiles(cin, 3, 32, 32, c=cin)
+    mask = net.predict(x)
+    ref = unet_oracle.unet_forward(x, w, params)
+    assert_bit_exact(net.logits().cpu().numpy(), ref, "logits")
+    assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "mask")
