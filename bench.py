@@ -446,7 +446,7 @@ def main_gan(args):
     from sequitr_amd.networks.gan import GenerativeAdverserialNetwork
     nb, level = 32, 6
     g = GenerativeAdverserialNetwork({"num_levels": 7, "batch_size": nb, "repeat_batch": 1, "learning_rate": 1e-3,
-                                      "device": str(dev), "seed": 0}, mode=None)
+                                      "device": str(dev), "seed": 0, "dtype": args.dtype}, mode=None)
     g.build()
     g.set_level(level)
     rng = np.random.default_rng(3 + rank)
@@ -480,10 +480,12 @@ def main_gan(args):
                           "value": round(samples * 256 * 256 / dt / 1e6, 3), "unit": "Mpixels/s",
                           "samples_per_s": round(samples / dt, 2), "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                           "data": "synthetic",
                           "config": {"workload": "progressive WGAN-GP level 6 (256x256x2), filters "
-                                                 "[512,256,128,64,32,16,8], batch 32 per GPU, alpha 1; fp32",
+                                                 "[512,256,128,64,32,16,8], batch 32 per GPU, alpha 1; " +
+                                                 ("f32 tensors, bf16-multiply / f32-accumulate convolutions"
+                                                  if args.dtype == "bf16" else "fp32"),
                                      "d_loss": g.last_losses[0], "g_loss": g.last_losses[1]}}))
     if dist is not None:
         dist.destroy_process_group()
@@ -495,7 +497,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="training dtype (--mode train)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="--mode train / gan: compute dtype")
     ap.add_argument("--fuse-up", type=int, default=1, help="1 = convT+bridge of up0 inside its first conv (infer mode)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive rate (infer mode)")
     ap.add_argument("--graph", type=int, default=1, help="--mode train: replay the step as hipGraphs (1) or eager (0)")

@@ -306,8 +306,8 @@ int sq_convT_conv3x3_fwd_f32(const float *x_low, const float *wt, const float *b
  * ---------------------------------------------------------------------------------------- */
 
 /* Packed bf16 filter of the KxK conv Cin -> Cout: [Cin/KC][Cout][KP] with k = tap*KC + c, KC = 32 when
- * Cin % 32 == 0 else 16, KP = K*K*KC rounded up to 32.  sq_conv_packed_weights_elems_bf16 gives the
- * element count (-1: unsupported).  transform != 0 packs the dgrad filter of the forward conv
+ * Cin % 32 == 0, 16 when Cin % 16 == 0, else 8 (Cin % 8 == 0); KP = K*K*KC rounded up to 32.
+ * sq_conv_packed_weights_elems_bf16 gives the element count (-1: unsupported).  transform != 0 packs the dgrad filter of the forward conv
  * Cout -> Cin whose f32 HWIO weights (K,K,Cout,Cin) are passed in `w`. */
 int64_t sq_conv_packed_weights_elems_bf16(int K, int Cin, int Cout);
 int sq_conv_pack_weights_bf16(const float *w, void *wp, int K, int Cin, int Cout, float wscale, int transform,
@@ -323,6 +323,18 @@ int sq_conv_pack_weights_multi_bf16(const float *base, void *out, const int32_t 
 /* conv_layer / weighted_conv2d on bf16 activations: y = act(conv(x, wp) + bias), fp32 accumulate. */
 int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H, int W,
                             int Cin, int Cout, int K, int act, void *stream);
+
+/* "Mixed" convolution behind an f32 graph (the GAN of BASELINE config 5; weighted_conv2d, gan.py:61-99): f32
+ * activations in and out, both operands rounded to bf16 (RNE) on the way into LDS, f32 accumulation on
+ * v_mfma_f32_16x16x32_bf16.  wp = sq_conv_pack_weights_bf16(w, K, Cin, Cout, wscale, transform) (Cin % 8 == 0);
+ * Cout % 4 == 0.  The drop-in for sq_conv2d_nhwc_fwd_f32 where the bf16 matrix rate is wanted. */
+int sq_conv2d_nhwc_fwd_mixed_f32(const float *x, const void *wp, const float *bias, float *y, int N, int H, int W,
+                                 int Cin, int Cout, int K, int act, void *stream);
+/* its weight gradient: dW (K,K,Cin,Cout) f32, db (Cout) f32 or NULL from f32 X and f32 dY (rounded to bf16 in
+ * LDS); Cin % 16 == 0, Cout % 16 == 0. */
+int64_t sq_conv2d_nhwc_wgrad_workspace_mixed_f32(int N, int H, int W, int Cin, int Cout, int K);
+int sq_conv2d_nhwc_wgrad_mixed_f32(const float *x, const float *dy, float *dw, float *db, float *workspace, int N,
+                                   int H, int W, int Cin, int Cout, int K, void *stream);
 
 /* first conv of down0 in the bf16 graph: f32 (N,H,W,Cin) image, Cin 1..7 -> bf16 (N,H,W,Cout), 3x3, f32 HWIO
  * weights (`num_inputs`, unet.py:131). */

@@ -86,6 +86,9 @@ SIGNATURES = {
     "sq_conv_packed_weights_elems_bf16": (c_int64, [c_int] * 3),
     "sq_conv_pack_weights_bf16": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_float, c_int, c_void_p]),
     "sq_conv2d_nhwc_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
+    "sq_conv2d_nhwc_fwd_mixed_f32": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
+    "sq_conv2d_nhwc_wgrad_workspace_mixed_f32": (c_int64, [c_int] * 6),
+    "sq_conv2d_nhwc_wgrad_mixed_f32": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "sq_conv3x3_first_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "sq_conv2d_nhwc_wgrad_workspace_bf16": (c_int64, [c_int] * 6),
     "sq_conv2d_nhwc_wgrad_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),

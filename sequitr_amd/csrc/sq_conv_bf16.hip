@@ -10,8 +10,12 @@
 //   KC = 16 (otherwise)    : one MFMA step = two taps x 16 channels (the 10th half-step has zero weights).
 // Weights are pre-packed once per optimiser step into [chunk][cout][KP] bf16 (k contiguous per output
 // channel), optionally rotated/transposed for dgrad: sq_conv_pack_weights_bf16.
+//   KC = 8  (Cin % 16 == 8)  : one MFMA step = four taps x 8 channels (GAN 256x256 layers; taps 9..11 are zero).
 // At levels 0-1 these kernels are HBM-bound (the matrix pipe is 16x the f32 rate); halving the bytes
 // is the point of the bf16 path.
+// TIO = float ("mixed"): the activations stay f32 in HBM, are rounded to bf16 (RNE) while they are staged into
+// LDS, and the f32 accumulators are stored as f32 -- bf16 multiply / f32 accumulate behind an f32 graph (the GAN
+// of BASELINE config 5, whose double-backward graph is built from f32 ops).
 #include "sq_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -45,7 +49,7 @@ template <int BN, int KS, int KC>
 struct CfgB {
     static constexpr int HALO_W = TW + KS - 1;
     static constexpr int HP = HALO_W * (TH + KS - 1);
-    static constexpr int PSB = KC == 16 ? 32 : 96;             // pixel stride in BYTES (conflict-free b128 reads)
+    static constexpr int PSB = KC == 8 ? 16 : (KC == 16 ? 32 : 96);   // pixel stride in BYTES (conflict-free b128 reads)
     static constexpr int KP = kp_for(KS, KC);                 // padded k per chunk
     static constexpr int WROWB = KP * 2 + ((KP * 2 / 16) % 16 == 6 ? 0 : ((6 - (KP * 2 / 16) % 16 + 16) % 16) * 16);
     static constexpr int XS_BYTES = HP * PSB;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
             wp[j] = (__bf16)w[j];
             continue;
         }
-        const int KC = Cin % 32 == 0 ? 32 : 16, KP = kp_for(K, KC);
+        const int KC = Cin % 32 == 0 ? 32 : (Cin % 16 == 0 ? 16 : 8), KP = kp_for(K, KC);
         const int k = j % KP, co = (j / KP) % Cout, chunk = j / (KP * Cout);
         float v = 0.f;
         if (k < K * K * KC) {
@@ -130,13 +134,15 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
     }
 }
 
-template <int BN, int KS, int KC>
+template <int BN, int KS, int KC, typename TIO>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
-    const __bf16 *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
-    __bf16 *__restrict__ y, int N, int H, int W, int Cin, int Cout, int act, int tiles_x, int tiles_y,
+    const TIO *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+    TIO *__restrict__ y, int N, int H, int W, int Cin, int Cout, int act, int tiles_x, int tiles_y,
     int ntiles, int tiles_per_block, const __bf16 *__restrict__ gate, SqDropEpi drop) {
     using C = CfgB<BN, KS, KC>;
     constexpr int NR = BN / 16, PAD = KS / 2;
+    constexpr bool F32IO = sizeof(TIO) == 4;                    // f32 activations in HBM, bf16 in LDS
+    constexpr int ES = (int)sizeof(TIO), XV = F32IO ? 2 : 1;    // 16-byte loads per 8-channel LDS item
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *xs = smem;
     unsigned char *ws = smem + C::XS_BYTES;
@@ -153,17 +159,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const bool restage_w = nchunk > 1;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16 *>(x), 0, (int)((size_t)N * H * W * Cin * 2), 0x00020000);
+        const_cast<TIO *>(x), 0, (int)((size_t)N * H * W * Cin * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16 *>(wp), 0, (int)((size_t)nchunk * Cout * C::KP * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        y, 0, (int)((size_t)N * H * W * Cout * 2), 0x00020000);
+        y, 0, (int)((size_t)N * H * W * Cout * ES), 0x00020000);
     // dgrad fused with the upstream ReLU's backward: outputs pass only where gate (N,H,W,Cout) > 0
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16 *>(gate), 0, gate ? (int)((size_t)N * H * W * Cout * 2) : 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
-    uint4 xr[C::XSLOTS], wr[C::WSLOTS];
+    uint4 xr[C::XSLOTS][XV], wr[C::WSLOTS];
     int xrel[C::XSLOTS], xpy[C::XSLOTS], xpx[C::XSLOTS];
 #pragma unroll
     for (int sl = 0; sl < C::XSLOTS; ++sl) {
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         const int pix = idx / C::XQ, q = idx % C::XQ;
         xpy[sl] = pix / C::HALO_W;
         xpx[sl] = pix % C::HALO_W;
-        xrel[sl] = idx < C::XITEMS ? ((xpy[sl] * W + xpx[sl]) * Cin + q * 8) * 2 : (int)OOB;
+        xrel[sl] = idx < C::XITEMS ? ((xpy[sl] * W + xpx[sl]) * Cin + q * 8) * ES : (int)OOB;
     }
     int wrel[C::WSLOTS];
 #pragma unroll
@@ -184,13 +190,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     auto issue = [&](int tile, int chunk, bool want_w) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW - PAD, y0 = ty * TH - PAD;
-        const int base = (((n * H + y0) * W + x0) * Cin + chunk * KC) * 2;
+        const int base = (((n * H + y0) * W + x0) * Cin + chunk * KC) * ES;
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
             const bool inb = (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
                              xrel[sl] != (int)OOB;
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? (unsigned)(base + xrel[sl]) : OOB, 0, 0);
-            xr[sl] = *reinterpret_cast<const uint4 *>(&v);
+#pragma unroll
+            for (int h = 0; h < XV; ++h) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? (unsigned)(base + xrel[sl] + 16 * h) : OOB, 0, 0);
+                xr[sl][h] = *reinterpret_cast<const uint4 *>(&v);
+            }
         }
         if (want_w) {
             const int wbase = chunk * Cout * C::KP * 2;
@@ -206,8 +215,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
             const int idx = tid + sl * 256;
-            if (idx < C::XITEMS)
-                *reinterpret_cast<uint4 *>(xs + (idx / C::XQ) * C::PSB + (idx % C::XQ) * 16) = xr[sl];
+            if (idx < C::XITEMS) {
+                uint4 item;
+                if constexpr (F32IO) {                          // 8 f32 channels -> 8 bf16 (round to nearest even)
+                    const float4 lo = __builtin_bit_cast(float4, xr[sl][0]), hi = __builtin_bit_cast(float4, xr[sl][XV - 1]);
+                    bf16x8 h;
+                    h[0] = (__bf16)lo.x; h[1] = (__bf16)lo.y; h[2] = (__bf16)lo.z; h[3] = (__bf16)lo.w;
+                    h[4] = (__bf16)hi.x; h[5] = (__bf16)hi.y; h[6] = (__bf16)hi.z; h[7] = (__bf16)hi.w;
+                    item = __builtin_bit_cast(uint4, h);
+                } else {
+                    item = xr[sl][0];
+                }
+                *reinterpret_cast<uint4 *>(xs + (idx / C::XQ) * C::PSB + (idx % C::XQ) * 16) = item;
+            }
         }
         if (want_w) {
 #pragma unroll
@@ -222,12 +242,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     // per-lane fragment addressing
     //   KC = 32: step = tap, the lane's 8 channels are 8*kg .. 8*kg+7
     //   KC = 16: step s covers taps 2s (kg 0,1) and 2s+1 (kg 2,3), channels 8*(kg&1) ..
-    const unsigned char *xb = xs + ((4 * wv) * C::HALO_W + li) * C::PSB + (KC == 32 ? kg * 16 : (kg & 1) * 16);
+    //   KC = 8 : step s covers taps 4s + kg, all 8 channels
+    const unsigned char *xb = xs + ((4 * wv) * C::HALO_W + li) * C::PSB + (KC == 32 ? kg * 16 : (KC == 16 ? (kg & 1) * 16 : 0));
     const unsigned char *wa = ws + li * C::WROWB + kg * 16;
     int toff[C::NSTEP];
 #pragma unroll
     for (int s = 0; s < C::NSTEP; ++s) {
-        int tap = KC == 32 ? s : 2 * s + (kg >> 1);
+        int tap = KC == 32 ? s : (KC == 16 ? 2 * s + (kg >> 1) : 4 * s + kg);
         if (tap > KS * KS - 1) tap = KS * KS - 1;                  // zero-weight padding step: any valid address
         toff[s] = ((tap / KS) * C::HALO_W + tap % KS) * C::PSB;
     }
@@ -259,7 +280,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
             for (int r = 0; r < 4; ++r) {
                 const int gy = ty * TH + 4 * wv + r;
                 const bool ok = gy < H && gx < W && co < Cout;
-                offs[r] = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 2) : OOB;
+                offs[r] = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * ES) : OOB;
+            }
+            if constexpr (F32IO) {                              // f32 store of the f32 accumulators; no gate / dropout
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float4 o;
+                    o.x = actf(acc[r][nb][0] + bv.x);
+                    o.y = actf(acc[r][nb][1] + bv.y);
+                    o.z = actf(acc[r][nb][2] + bv.z);
+                    o.w = actf(acc[r][nb][3] + bv.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
+                        __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), yrsrc, offs[r], 0, 0);
+                    acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                continue;
             }
             if (gate) {
 #pragma unroll
@@ -353,7 +388,8 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
     float a[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) a[o] = 0.f;
-#pragma unroll
+    constexpr int TAP_UNROLL = CIN == 1 ? 9 : 1;                // multi-channel: rolled taps keep the filter out of registers
+#pragma unroll TAP_UNROLL
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
         for (int c = 0; c < CIN; ++c) {
@@ -379,13 +415,13 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
     }
 }
 
-template <int BN, int KS, int KC>
-int launch(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int N, int H, int W, int Cin, int Cout,
+template <int BN, int KS, int KC, typename TIO>
+int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int H, int W, int Cin, int Cout,
            int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
     using C = CfgB<BN, KS, KC>;
     static bool attr_set = false;
     static int occ = 2;                                         // resident blocks per CU (registers / LDS)
-    auto kern = conv_mfma_bf16_kernel<BN, KS, KC>;
+    auto kern = conv_mfma_bf16_kernel<BN, KS, KC, TIO>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
@@ -413,20 +449,36 @@ int launch(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int 
     return sq_check_launch("sq_conv2d_nhwc_fwd_bf16");
 }
 
-template <int KS, int KC>
-int dispatch_bn(const __bf16 *x, const __bf16 *wp, const float *bias, __bf16 *y, int N, int H, int W, int Cin,
+template <int KS, int KC, typename TIO>
+int dispatch_bn(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int H, int W, int Cin,
                 int Cout, int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
-    if (Cout >= 64) return launch<64, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
-    if (Cout > 16) return launch<32, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
-    return launch<16, KS, KC>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    if (Cout >= 64) return launch<64, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    if (Cout > 16) return launch<32, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    return launch<16, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
 }
 
-inline int kc_for(int Cin) { return Cin % 32 == 0 ? 32 : 16; }
+inline int kc_for(int Cin) { return Cin % 32 == 0 ? 32 : (Cin % 16 == 0 ? 16 : 8); }
+
+template <typename TIO>
+int dispatch_kc(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int H, int W, int Cin, int Cout, int K,
+                int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
+    switch (kc_for(Cin)) {
+    case 32:
+        return K == 3 ? dispatch_bn<3, 32, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop)
+                      : dispatch_bn<1, 32, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    case 16:
+        return K == 3 ? dispatch_bn<3, 16, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop)
+                      : dispatch_bn<1, 16, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    default:
+        return K == 3 ? dispatch_bn<3, 8, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop)
+                      : dispatch_bn<1, 8, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    }
+}
 
 }  // namespace
 
 extern "C" int64_t sq_conv_packed_weights_elems_bf16(int K, int Cin, int Cout) {
-    if ((K != 1 && K != 3) || Cin <= 0 || Cin % 16 || Cout <= 0) return -1;
+    if ((K != 1 && K != 3) || Cin <= 0 || Cin % 8 || Cout <= 0) return -1;
     const int KC = kc_for(Cin);
     return (int64_t)(Cin / KC) * Cout * kp_for(K, KC);
 }
@@ -438,7 +490,7 @@ extern "C" int sq_conv_pack_weights_bf16(const float *w, void *wp, int K, int Ci
                                          int transform, void *stream) {
     SQ_REQUIRE(w && wp, "sq_conv_pack_weights_bf16: null pointer");
     const int64_t n = sq_conv_packed_weights_elems_bf16(K, Cin, Cout);
-    SQ_REQUIRE(n > 0, "sq_conv_pack_weights_bf16: unsupported K=%d Cin=%d Cout=%d (Cin %% 16 == 0)", K, Cin, Cout);
+    SQ_REQUIRE(n > 0, "sq_conv_pack_weights_bf16: unsupported K=%d Cin=%d Cout=%d (Cin %% 8 == 0)", K, Cin, Cout);
     const int KC = kc_for(Cin);
     int64_t nb = (n + 255) / 256;
     if (nb > 2048) nb = 2048;
@@ -466,8 +518,8 @@ static int conv_fwd_bf16_impl(const void *x, const void *wp, const float *bias, 
                               const SqDropEpi &drop = SqDropEpi{0u, 1.f, 0u, nullptr}) {
     SQ_REQUIRE(x && wp && y, "sq_conv2d_nhwc_fwd_bf16: null tensor pointer");
     SQ_REQUIRE(N > 0 && H > 0 && W > 0 && (K == 1 || K == 3), "sq_conv2d_nhwc_fwd_bf16: bad shape / K");
-    SQ_REQUIRE(Cin % 16 == 0 && Cin > 0 && Cout % 4 == 0 && Cout > 0,
-               "sq_conv2d_nhwc_fwd_bf16: Cin=%d (multiple of 16), Cout=%d (multiple of 4)", Cin, Cout);
+    SQ_REQUIRE(Cin % 8 == 0 && Cin > 0 && Cout % 4 == 0 && Cout > 0,
+               "sq_conv2d_nhwc_fwd_bf16: Cin=%d (multiple of 8), Cout=%d (multiple of 4)", Cin, Cout);
     SQ_REQUIRE((size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 2 < ((size_t)1 << 31),
                "sq_conv2d_nhwc_fwd_bf16: tensors must be < 2 GiB");
     SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_conv2d_nhwc_fwd_bf16: bad activation %d", act);
@@ -478,11 +530,25 @@ static int conv_fwd_bf16_impl(const void *x, const void *wp, const float *bias, 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *wb = reinterpret_cast<const __bf16 *>(wp);
     __bf16 *yb = reinterpret_cast<__bf16 *>(y);
-    if (kc_for(Cin) == 32)
-        return K == 3 ? dispatch_bn<3, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb, drop)
-                      : dispatch_bn<1, 32>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb, drop);
-    return K == 3 ? dispatch_bn<3, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb, drop)
-                  : dispatch_bn<1, 16>(xb, wb, bias, yb, N, H, W, Cin, Cout, act, st, gb, drop);
+    return dispatch_kc<__bf16>(xb, wb, bias, yb, N, H, W, Cin, Cout, K, act, st, gb, drop);
+}
+
+// "mixed" convolution: f32 activations in and out, operands rounded to bf16 on the way into LDS, f32 accumulation
+// (v_mfma_f32_16x16x32_bf16).  wp from sq_conv_pack_weights_bf16 (which also folds the equalised-LR scale in).
+// The drop-in for sq_conv2d_nhwc_fwd_f32 behind an f32 graph that wants the bf16 matrix rate (GAN, config 5).
+extern "C" int sq_conv2d_nhwc_fwd_mixed_f32(const float *x, const void *wp, const float *bias, float *y, int N, int H,
+                                            int W, int Cin, int Cout, int K, int act, void *stream) {
+    SQ_REQUIRE(x && wp && y, "sq_conv2d_nhwc_fwd_mixed_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && (K == 1 || K == 3), "sq_conv2d_nhwc_fwd_mixed_f32: bad shape / K");
+    SQ_REQUIRE(Cin % 8 == 0 && Cin > 0 && Cout % 4 == 0 && Cout > 0,
+               "sq_conv2d_nhwc_fwd_mixed_f32: Cin=%d (multiple of 8), Cout=%d (multiple of 4)", Cin, Cout);
+    SQ_REQUIRE((size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31),
+               "sq_conv2d_nhwc_fwd_mixed_f32: tensors must be < 2 GiB");
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_conv2d_nhwc_fwd_mixed_f32: bad activation %d", act);
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(wp); SQ_REQUIRE_ALIGNED(y);
+    if (bias) SQ_REQUIRE_ALIGNED(bias);
+    return dispatch_kc<float>(x, reinterpret_cast<const __bf16 *>(wp), bias, y, N, H, W, Cin, Cout, K, act,
+                              reinterpret_cast<hipStream_t>(stream), nullptr, SqDropEpi{0u, 1.f, 0u, nullptr});
 }
 
 extern "C" int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H,

@@ -167,9 +167,12 @@ __global__ __launch_bounds__(256) void conv_direct_f32_kernel(
     float acc[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) acc[o] = 0.f;
-#pragma unroll
+    // more than 9 filter rows: keep the tap loops rolled, or the compiler hoists every (wave-uniform) weight read
+    // into registers and spills
+    constexpr int TAP_UNROLL = KS * KS * CIN <= 9 ? KS : 1;
+#pragma unroll TAP_UNROLL
     for (int ky = 0; ky < KS; ++ky)
-#pragma unroll
+#pragma unroll TAP_UNROLL
         for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {

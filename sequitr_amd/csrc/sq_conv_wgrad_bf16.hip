@@ -14,6 +14,8 @@
 //     row = r + (g >> 1),  x = 4*(g & 1) + 8*(e >> 2) + (e & 3)
 // chosen so the two groups of a 32-lane half read blocks 128 B apart (conflict-free).
 // Partials + fixed-order finish kernel as in sq_conv_wgrad_f32.hip (no float atomics).
+// TIO = float ("mixed"): X and dY are f32 tensors, rounded to bf16 (RNE) while they are staged into LDS --
+// the weight gradient of sq_conv2d_nhwc_fwd_mixed_f32 (f32 graph, bf16 multiply, f32 accumulate).
 #include "sq_common.h"
 #include <stdlib.h>
 
@@ -55,12 +57,21 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char *p0, const unsigne
 template <int KS, int NI, int NO>
 constexpr int wgrad_occ() { return KS * KS * NI * NO > 18 ? 1 : 2; }
 
-template <int KS, int NI, int NO, int PF>
+__device__ __forceinline__ uint4 f32x8_to_bf16x8(const uint4 &a, const uint4 &b) {
+    const float4 lo = __builtin_bit_cast(float4, a), hi = __builtin_bit_cast(float4, b);
+    bf16x8 h;
+    h[0] = (__bf16)lo.x; h[1] = (__bf16)lo.y; h[2] = (__bf16)lo.z; h[3] = (__bf16)lo.w;
+    h[4] = (__bf16)hi.x; h[5] = (__bf16)hi.y; h[6] = (__bf16)hi.z; h[7] = (__bf16)hi.w;
+    return __builtin_bit_cast(uint4, h);
+}
+
+template <int KS, int NI, int NO, int PF, typename TIO>
 __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf16_kernel(
-    const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy, float *__restrict__ partials, int N, int H,
+    const TIO *__restrict__ x, const TIO *__restrict__ dy, float *__restrict__ partials, int N, int H,
     int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block) {
     using C = WB<KS, NI, NO>;
     constexpr int PAD = KS / 2;
+    constexpr int ES = (int)sizeof(TIO), XV = ES == 4 ? 2 : 1;  // 16-byte loads per 8-channel LDS item
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *xs = smem, *ys = smem + C::XS_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -70,9 +81,9 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
     const int t_begin = blockIdx.x * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16 *>(x), 0, (int)((size_t)N * H * W * Cin * 2), 0x00020000);
+        const_cast<TIO *>(x), 0, (int)((size_t)N * H * W * Cin * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16 *>(dy), 0, (int)((size_t)N * H * W * Cout * 2), 0x00020000);
+        const_cast<TIO *>(dy), 0, (int)((size_t)N * H * W * Cout * ES), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
     // 16-byte items: item = (pixel, plane, half); a pixel's 32 NI bytes are contiguous in HBM.  The index
@@ -80,42 +91,52 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
     // need them.
     // PF register sets: the loads of tile t+PF are issued while tile t is computed, i.e. PF-1 whole
     // iterations before they are committed to LDS -- one iteration is far shorter than an HBM round trip
-    uint4 xr[PF][C::XSLOTS], yr[PF][C::YSLOTS];
-    auto issue = [&](int tile, uint4 (&xr)[C::XSLOTS], uint4 (&yr)[C::YSLOTS]) {
+    uint4 xr[PF][C::XSLOTS][XV], yr[PF][C::YSLOTS][XV];
+    auto issue = [&](int tile, uint4 (&xr)[C::XSLOTS][XV], uint4 (&yr)[C::YSLOTS][XV]) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW, y0 = ty * TH;
-        const int xbase = (((n * H + y0 - PAD) * W + x0 - PAD) * Cin + ci0) * 2;
-        const int ybase = (((n * H + y0) * W + x0) * Cout + co0) * 2;
+        const int xbase = (((n * H + y0 - PAD) * W + x0 - PAD) * Cin + ci0) * ES;
+        const int ybase = (((n * H + y0) * W + x0) * Cout + co0) * ES;
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
             const int idx = tid + sl * 256, pix = idx / (2 * NI), rem = idx % (2 * NI);
             const int py = pix / C::HALO_W, px = pix % C::HALO_W;
             const bool inb = idx < C::XITEMS && (unsigned)(y0 - PAD + py) < (unsigned)H &&
                              (unsigned)(x0 - PAD + px) < (unsigned)W;
-            const unsigned off = inb ? (unsigned)(xbase + ((py * W + px) * Cin + rem * 8) * 2) : OOB;
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
-            xr[sl] = *reinterpret_cast<const uint4 *>(&v);
+            const unsigned off = inb ? (unsigned)(xbase + ((py * W + px) * Cin + rem * 8) * ES) : OOB;
+#pragma unroll
+            for (int h = 0; h < XV; ++h) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? off + 16 * h : OOB, 0, 0);
+                xr[sl][h] = *reinterpret_cast<const uint4 *>(&v);
+            }
         }
 #pragma unroll
         for (int sl = 0; sl < C::YSLOTS; ++sl) {
             const int idx = tid + sl * 256, pix = idx / (2 * NO), rem = idx % (2 * NO);
             const int py = pix / TW, px = pix % TW;
             const bool inb = (y0 + py) < H && (x0 + px) < W;
-            const unsigned off = inb ? (unsigned)(ybase + ((py * W + px) * Cout + rem * 8) * 2) : OOB;
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, off, 0, 0);
-            yr[sl] = *reinterpret_cast<const uint4 *>(&v);
+            const unsigned off = inb ? (unsigned)(ybase + ((py * W + px) * Cout + rem * 8) * ES) : OOB;
+#pragma unroll
+            for (int h = 0; h < XV; ++h) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, inb ? off + 16 * h : OOB, 0, 0);
+                yr[sl][h] = *reinterpret_cast<const uint4 *>(&v);
+            }
         }
     };
-    auto commit = [&](const uint4 (&xr)[C::XSLOTS], const uint4 (&yr)[C::YSLOTS]) {
+    auto item = [&](const uint4 (&r)[XV]) {
+        if constexpr (XV == 2) return f32x8_to_bf16x8(r[0], r[XV - 1]);
+        else return r[0];
+    };
+    auto commit = [&](const uint4 (&xr)[C::XSLOTS][XV], const uint4 (&yr)[C::YSLOTS][XV]) {
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
             const int idx = tid + sl * 256, pix = idx / (2 * NI), rem = idx % (2 * NI);
-            if (idx < C::XITEMS) *reinterpret_cast<uint4 *>(xs + (rem >> 1) * C::XPLANE + pix * PSB + (rem & 1) * 16) = xr[sl];
+            if (idx < C::XITEMS) *reinterpret_cast<uint4 *>(xs + (rem >> 1) * C::XPLANE + pix * PSB + (rem & 1) * 16) = item(xr[sl]);
         }
 #pragma unroll
         for (int sl = 0; sl < C::YSLOTS; ++sl) {
             const int idx = tid + sl * 256, pix = idx / (2 * NO), rem = idx % (2 * NO);
-            *reinterpret_cast<uint4 *>(ys + (rem >> 1) * C::YPLANE + pix * PSB + (rem & 1) * 16) = yr[sl];
+            *reinterpret_cast<uint4 *>(ys + (rem >> 1) * C::YPLANE + pix * PSB + (rem & 1) * 16) = item(yr[sl]);
         }
     };
 
@@ -138,7 +159,7 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
     const unsigned char *xa = xs + ((4 * wv) * C::HALO_W + lane_hx) * PSB + p * 8;
 
     // an out-of-range tile index loads nothing (every lane's offset is out of bounds) and is never committed
-    auto issue_if = [&](int tile, uint4 (&xr_)[C::XSLOTS], uint4 (&yr_)[C::YSLOTS]) {
+    auto issue_if = [&](int tile, uint4 (&xr_)[C::XSLOTS][XV], uint4 (&yr_)[C::YSLOTS][XV]) {
         if (tile < t_end) issue(tile, xr_, yr_);
     };
 #pragma unroll
@@ -253,16 +274,16 @@ void plan(int N, int H, int W, int Cin, int Cout, int *gx, int *tpb, int64_t *ws
     *ws_floats = (int64_t)(*gx) * npairs * C::RED_FLOATS;
 }
 
-template <int KS, int NI, int NO>
-int launch(const __bf16 *x, const __bf16 *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin,
+template <int KS, int NI, int NO, typename TIO>
+int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin,
            int Cout, hipStream_t st) {
     using C = WB<KS, NI, NO>;
     static bool attr_set = false;
-    // prefetch depth: as deep as the accumulators leave registers for
-    constexpr int acc_regs = C::NTAP * NI * NO * 4, set_regs = (C::XSLOTS + C::YSLOTS) * 4;
+    // prefetch depth: as deep as the accumulators leave registers for (f32 tensors: twice the registers per set)
+    constexpr int acc_regs = C::NTAP * NI * NO * 4, set_regs = (C::XSLOTS + C::YSLOTS) * 4 * (int)(sizeof(TIO) / 2);
     constexpr int budget = (wgrad_occ<KS, NI, NO>() == 1 ? 300 : 200) - acc_regs - 40;
-    constexpr int PF = budget / set_regs >= 4 ? 4 : (budget / set_regs >= 3 ? 3 : 2);
-    auto kern = conv_wgrad_bf16_kernel<KS, NI, NO, PF>;
+    constexpr int PF = budget / set_regs >= 4 ? 4 : (budget / set_regs >= 3 ? 3 : (budget / set_regs >= 2 ? 2 : 1));
+    auto kern = conv_wgrad_bf16_kernel<KS, NI, NO, PF, TIO>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
@@ -352,14 +373,29 @@ int64_t plan_floats(int N, int H, int W, int Cin, int Cout, int K) {
 #undef SQ_PLAN_CALL
 }
 
-int launch_any(const __bf16 *x, const __bf16 *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin,
-               int Cout, int K, hipStream_t st) {
-    SQ_WGRAD_BF16_DISPATCH(launch, x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
+template <int KS, int NI, int NO>
+int launch_b(const __bf16 *x, const __bf16 *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin, int Cout,
+             hipStream_t st) {
+    return launch<KS, NI, NO, __bf16>(x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
+}
+template <int KS, int NI, int NO>
+int launch_f(const float *x, const float *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin, int Cout,
+             hipStream_t st) {
+    return launch<KS, NI, NO, float>(x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
 }
 
-bool ok_shape(int N, int H, int W, int Cin, int Cout, int K) {
+int launch_any(const __bf16 *x, const __bf16 *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin,
+               int Cout, int K, hipStream_t st) {
+    SQ_WGRAD_BF16_DISPATCH(launch_b, x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
+}
+int launch_any_mixed(const float *x, const float *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin,
+                     int Cout, int K, hipStream_t st) {
+    SQ_WGRAD_BF16_DISPATCH(launch_f, x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
+}
+
+bool ok_shape(int N, int H, int W, int Cin, int Cout, int K, int elem_bytes = 2) {
     return N > 0 && H > 0 && W > 0 && (K == 1 || K == 3) && Cin > 0 && Cin % 16 == 0 && Cout > 0 && Cout % 16 == 0 &&
-           (size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 2 < ((size_t)1 << 31);
+           (size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * elem_bytes < ((size_t)1 << 31);
 }
 
 }  // namespace
@@ -379,4 +415,21 @@ extern "C" int sq_conv2d_nhwc_wgrad_bf16(const void *x, const void *dy, float *d
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *yb = reinterpret_cast<const __bf16 *>(dy);
     return launch_any(xb, yb, dw, db, workspace, N, H, W, Cin, Cout, K, st);
+}
+
+// "mixed" weight gradient: f32 X and dY, rounded to bf16 on the way into LDS, f32 accumulation -- the wgrad of
+// sq_conv2d_nhwc_fwd_mixed_f32.  Same block shapes, workspace and fixed-order finish as the bf16 entry.
+extern "C" int64_t sq_conv2d_nhwc_wgrad_workspace_mixed_f32(int N, int H, int W, int Cin, int Cout, int K) {
+    if (!ok_shape(N, H, W, Cin, Cout, K, 4)) return -1;
+    return plan_floats(N, H, W, Cin, Cout, K) * 4;
+}
+
+extern "C" int sq_conv2d_nhwc_wgrad_mixed_f32(const float *x, const float *dy, float *dw, float *db, float *workspace,
+                                              int N, int H, int W, int Cin, int Cout, int K, void *stream) {
+    SQ_REQUIRE(x && dy && dw && workspace, "sq_conv2d_nhwc_wgrad_mixed_f32: null pointer");
+    SQ_REQUIRE(ok_shape(N, H, W, Cin, Cout, K, 4),
+               "sq_conv2d_nhwc_wgrad_mixed_f32: unsupported shape Cin=%d Cout=%d K=%d (both %% 16, K 1|3, < 2 GiB)", Cin,
+               Cout, K);
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(workspace);
+    return launch_any_mixed(x, dy, dw, db, workspace, N, H, W, Cin, Cout, K, reinterpret_cast<hipStream_t>(stream));
 }

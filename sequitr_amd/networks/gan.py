@@ -207,7 +207,8 @@ class GenerativeAdverserialNetwork(object):
 
     params: num_outputs, batch_size, repeat_batch, num_levels, num_epochs_per_level, start_size,
     training_data (``.npy`` (N,H,W,C) stack; None -> synthetic tiles), learning_rate; new keys:
-    device, seed, num_batches_per_epoch (when the data is synthetic)."""
+    device, seed, num_batches_per_epoch (when the data is synthetic), dtype ('f32' default: exact-f32 MFMA
+    convolutions; 'bf16': the f32 graph with bf16-multiply / f32-accumulate convolutions, BASELINE config 5)."""
 
     def __init__(self, params, mode=None, discriminator_fn=discriminator_network,
                  generator_fn=generator_network):
@@ -222,6 +223,9 @@ class GenerativeAdverserialNetwork(object):
         self.start_size = params.get('start_size', (4, 4))
         self.training_data_filename = params.get('training_data', None)
         self.learning_rate = params.get('learning_rate', 1e-3)
+        self.dtype = params.get('dtype', 'f32')
+        if self.dtype not in ('f32', 'bf16'):
+            raise ValueError("dtype must be 'f32' or 'bf16', got %r" % (self.dtype,))
         dev = params.get('device', None)
         self.device = torch.device(dev) if dev is not None else torch.device('cuda', torch.cuda.current_device())
         if self.device.type != 'cuda':
@@ -389,8 +393,21 @@ class GenerativeAdverserialNetwork(object):
             o += g.numel()
         return 1.0 / dist.get_world_size(self.group)
 
+    def precision(self):
+        """context for everything this network launches (forward AND backward): `with net.precision(): ...`"""
+        return ops.mixed_precision(self.dtype == 'bf16')
+
     def d_solver(self, X, Z, alpha, r=None):
         """d_opt.minimize(d_loss, var_list=d_vars) for the current level (gan.py:649)."""
+        with self.precision():
+            return self._d_solver(X, Z, alpha, r)
+
+    def g_solver(self, X, Z, alpha):
+        """g_opt.minimize(g_loss, var_list=g_vars, global_step) for the current level (gan.py:650-651)."""
+        with self.precision():
+            return self._g_solver(X, Z, alpha)
+
+    def _d_solver(self, X, Z, alpha, r=None):
         level = self.current_level
         d_vars, _ = self.get_training_variables(level)
         _, d_loss, g_loss = self._build_network(X, Z, alpha, r=r, need_g_graph=False)
@@ -400,8 +417,7 @@ class GenerativeAdverserialNetwork(object):
         self.last_losses = (float(d_loss.detach()), float(g_loss.detach()))
         return d_loss.detach()
 
-    def g_solver(self, X, Z, alpha):
-        """g_opt.minimize(g_loss, var_list=g_vars, global_step) for the current level (gan.py:650-651)."""
+    def _g_solver(self, X, Z, alpha):
         level = self.current_level
         _, g_vars = self.get_training_variables(level)
         d_filters, _, Gz, _ = self._prepare(X, Z, alpha, need_g_graph=True)
@@ -516,7 +532,7 @@ class GenerativeAdverserialNetwork(object):
             raise Exception('You must provide latent variables to the model.')
         level = self.num_levels - 1 if level is None else level
         z = torch.as_tensor(np.asarray(latent), dtype=torch.float32).to(self.device).reshape(-1, 1, 1, 512)
-        with torch.no_grad():
+        with torch.no_grad(), self.precision():
             _, out = self.generator(z, self.filters[:(level + 1)])
         return out
 

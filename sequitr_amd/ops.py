@@ -84,6 +84,42 @@ def mosaic_unpack(m, N, H, W, R, Cc):
 
 USE_DENSE = os.environ.get("SQ_DENSE", "1") != "0"        # A/B switch for the split-reduction dense kernel
 
+# "mixed" convolutions: f32 tensors, bf16 multiply, f32 accumulate (sq_conv2d_nhwc_{fwd,wgrad}_mixed_f32).  While the
+# flag is set, conv2d / conv2d_dgrad / conv2d_wgrad route every layer the mixed kernels take (Cin % 8, Cout % 4;
+# wgrad: both % 16) to them; image-side 1x1 convs (to_image / from_image / class heads) and dense stay f32.
+MIXED = False
+
+
+class mixed_precision:
+    """`with ops.mixed_precision():` -- bf16-multiply convolutions for everything launched inside, including a
+    backward pass run inside the block (the GAN's `dtype='bf16'`, BASELINE config 5)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global MIXED
+        self.prev, MIXED = MIXED, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global MIXED
+        MIXED = self.prev
+        return False
+
+
+def _conv2d_mixed(x, w, bias, act, wscale, y):
+    N, H, W, Cin = x.shape
+    K, Cout = w.shape[0], w.shape[3]
+    lib = _lib.load()
+    n = lib.sq_conv_packed_weights_elems_bf16(K, Cin, Cout)
+    wp = torch.empty((n,), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.sq_conv_pack_weights_bf16(_ptr(w), _ptr(wp), K, Cin, Cout, float(wscale), 0, _stream()),
+               "sq_conv_pack_weights_bf16")
+    _lib.check(lib.sq_conv2d_nhwc_fwd_mixed_f32(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, K, ACT[act],
+                                               _stream()), "sq_conv2d_nhwc_fwd_mixed_f32")
+    return y
+
 
 def dense(x, w, bias=None, act=None, wscale=1.0):
     """y (M,N) = act(x (M,K) @ w (K,N) * wscale + bias): few rows, long reduction (sq_dense_fwd_f32)."""
@@ -126,6 +162,8 @@ def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None):
             ym = conv2d(mosaic_pack(x, *plan), w, bias, act, wscale)
             return mosaic_unpack(ym, N, H, W, *plan)
     y = _out(out, (N, H, W, Cout), x)
+    if MIXED and Cin % 8 == 0 and Cout % 4 == 0:
+        return _conv2d_mixed(x, w, bias, act, wscale, y)
     lib = _lib.load()
     _lib.check(lib.sq_conv2d_nhwc_fwd_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, K,
                                          float(wscale), ACT[act], _stream()), "sq_conv2d_nhwc_fwd_f32")
@@ -304,12 +342,18 @@ def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None):
         if plan is not None:                                  # separator cells of dY are zero: they add nothing
             return conv2d_wgrad(mosaic_pack(x, *plan), mosaic_pack(dy, *plan), K, want_bias, dw_out, db_out)
     lib = _lib.load()
-    nbytes = lib.sq_conv2d_nhwc_wgrad_workspace_f32(N, H, W, Cin, Cout, K)
+    mixed = MIXED and lib.sq_conv2d_nhwc_wgrad_workspace_mixed_f32(N, H, W, Cin, Cout, K) >= 0
+    nbytes = (lib.sq_conv2d_nhwc_wgrad_workspace_mixed_f32 if mixed else lib.sq_conv2d_nhwc_wgrad_workspace_f32)(
+        N, H, W, Cin, Cout, K)
     if nbytes < 0:
         raise _lib.SequitrHipError("conv2d_wgrad: unsupported shape Cin=%d Cout=%d K=%d" % (Cin, Cout, K))
     ws = _workspace(nbytes, x.device)
     dw = _grad_out(dw_out, (K, K, Cin, Cout), x.device)
     db = _grad_out(db_out, (Cout,), x.device) if want_bias else None
+    if mixed:
+        _lib.check(lib.sq_conv2d_nhwc_wgrad_mixed_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin,
+                                                     Cout, K, _stream()), "sq_conv2d_nhwc_wgrad_mixed_f32")
+        return dw, db
     _lib.check(lib.sq_conv2d_nhwc_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout,
                                            K, _stream()), "sq_conv2d_nhwc_wgrad_f32")
     return dw, db

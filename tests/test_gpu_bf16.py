@@ -34,7 +34,9 @@ def check_bf16(got, ref64, what):
 
 CASES = [(2, 32, 48, 16, 16, 3, "relu"), (1, 32, 32, 16, 32, 3, "relu"), (1, 32, 32, 32, 32, 3, "relu"),
          (1, 16, 32, 64, 64, 3, "relu"), (1, 16, 16, 128, 256, 3, None), (2, 20, 27, 48, 16, 3, "leaky"),
-         (1, 16, 16, 64, 32, 1, None), (1, 24, 24, 16, 64, 1, "relu"), (1, 8, 8, 256, 256, 3, "relu")]
+         (1, 16, 16, 64, 32, 1, None), (1, 24, 24, 16, 64, 1, "relu"), (1, 8, 8, 256, 256, 3, "relu"),
+         (2, 20, 27, 8, 8, 3, "leaky"), (1, 32, 32, 8, 16, 3, None), (1, 16, 16, 24, 32, 3, "relu"),   # KC = 8
+         (1, 16, 16, 8, 32, 1, None)]
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,K,act", CASES)

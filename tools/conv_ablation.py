@@ -26,6 +26,12 @@ VARIANTS = {
     "noload": [("const unsigned off = inb ? (unsigned)(base + xrel[sl]) : OOB;", "const unsigned off = OOB; (void)inb; (void)base;")],
 }
 VARIANTS["noload_nostore"] = VARIANTS["nostore"] + VARIANTS["noload"]
+# convoy hypothesis: persistent blocks that share a CU start together and stay in phase (all staging, then all
+# MFMA); delay residency slot s by s * k * 64 clocks so their phases interleave
+for _k in (24, 48, 96):
+    VARIANTS["stagger%d" % _k] = [("    if (t_begin >= t_end) return;\n",
+                                   "    if (t_begin >= t_end) return;\n"
+                                   "    for (int s_ = (blockIdx.x >> 8) %% C::OCC; s_ > 0; --s_) __builtin_amdgcn_s_sleep(%d);\n" % _k)]
 
 
 def build():
@@ -102,7 +108,8 @@ if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
     elif sys.argv[1] == "run":
-        for v in ["prod"] + list(VARIANTS) + list(WGRAD_VARIANTS):   # one process per variant: the library is loaded once
+        names = sys.argv[2:] or (["prod"] + list(VARIANTS) + list(WGRAD_VARIANTS))
+        for v in names:   # one process per variant: the library is loaded once
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "one", v])
     else:
         run_one(sys.argv[2])
