@@ -105,17 +105,40 @@ class mixed_precision:
     def __exit__(self, *exc):
         global MIXED
         MIXED = self.prev
+        if not MIXED:
+            _PACKS.clear()
         return False
 
 
-def _conv2d_mixed(x, w, bias, act, wscale, y):
-    N, H, W, Cin = x.shape
-    K, Cout = w.shape[0], w.shape[3]
+# packed bf16 filters of PARAMETERS (leaf tensors that require grad), valid until the outermost mixed_precision
+# block ends: a solver step evaluates the discriminator three times and differentiates it twice with the same
+# weights, and the optimiser only writes them as the step's last act.  Entries hold the parameter itself, so its
+# storage cannot be recycled under the key.
+_PACKS = {}
+
+
+def _packed_filter(w, K, Cin, Cout, wscale, transform):
+    """bf16 pack of the conv Cin -> Cout; transform: `w` is the FORWARD filter (K,K,Cout,Cin) of which this conv
+    is the dgrad (taps rotated, channel roles swapped inside the pack kernel -- no separate transform pass)."""
+    cacheable = w.is_leaf and w.requires_grad
+    key = (w.data_ptr(), K, Cin, Cout, float(wscale), bool(transform))
+    if cacheable and key in _PACKS:
+        return _PACKS[key][1]
     lib = _lib.load()
     n = lib.sq_conv_packed_weights_elems_bf16(K, Cin, Cout)
-    wp = torch.empty((n,), dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.sq_conv_pack_weights_bf16(_ptr(w), _ptr(wp), K, Cin, Cout, float(wscale), 0, _stream()),
-               "sq_conv_pack_weights_bf16")
+    wp = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
+    _lib.check(lib.sq_conv_pack_weights_bf16(_ptr(w), _ptr(wp), K, Cin, Cout, float(wscale), 1 if transform else 0,
+                                            _stream()), "sq_conv_pack_weights_bf16")
+    if cacheable:
+        _PACKS[key] = (w, wp)
+    return wp
+
+
+def _conv2d_mixed(x, w, bias, act, wscale, y, transform):
+    N, H, W, Cin = x.shape
+    K, Cout = w.shape[0], (w.shape[2] if transform else w.shape[3])
+    lib = _lib.load()
+    wp = _packed_filter(w, K, Cin, Cout, wscale, transform)
     _lib.check(lib.sq_conv2d_nhwc_fwd_mixed_f32(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, K, ACT[act],
                                                _stream()), "sq_conv2d_nhwc_fwd_mixed_f32")
     return y
@@ -138,13 +161,20 @@ def dense(x, w, bias=None, act=None, wscale=1.0):
     return y
 
 
-def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None):
+def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None, _dgrad=False):
     """KxK SAME conv + bias + activation.  x (N,H,W,Cin), w (K,K,Cin,Cout) HWIO.
     Batches of small images (H, W <= 8) run as one mosaic image (3x3) or as a flat pixel strip (1x1):
-    same fmaf chain per output, far fewer and fuller 16x16 tiles."""
+    same fmaf chain per output, far fewer and fuller 16x16 tiles.
+    _dgrad (internal): `w` is the filter (K,K,Cout,Cin) of the forward conv whose input gradient this is."""
     _chk(x, "x", ndim=4), _chk(w, "w", ndim=4)
     N, H, W, Cin = x.shape
+    if _dgrad:
+        takes_dense = out is None and w.shape[0] == 1 and N * H * W <= 128 and Cin >= 1024 and Cin % 4 == 0 and USE_DENSE
+        if takes_dense or not (MIXED and Cin % 8 == 0 and w.shape[2] % 4 == 0):
+            w, _dgrad = conv_weight_transform(w), False        # the f32 kernels take the transformed filter
     K, K2, Ci, Cout = w.shape
+    if _dgrad:
+        Ci, Cout = Cout, Ci
     if K != K2 or Ci != Cin:
         raise ValueError("weight shape %s does not match input channels %d" % (tuple(w.shape), Cin))
     if bias is not None:
@@ -156,14 +186,14 @@ def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None):
     if out is None and USE_MOSAIC and W < 16 and N * H > 1:
         P = N * H * W
         if K == 1 and P % 16 == 0:                            # pixels are independent: a free view
-            return conv2d(x.view(1, P // 16, 16, Cin), w, bias, act, wscale).view(N, H, W, Cout)
+            return conv2d(x.view(1, P // 16, 16, Cin), w, bias, act, wscale, _dgrad=_dgrad).view(N, H, W, Cout)
         plan = _mosaic_plan(N, H, W) if (K == 3 and Cin % 4 == 0 and Cout % 4 == 0) else None
         if plan is not None:
-            ym = conv2d(mosaic_pack(x, *plan), w, bias, act, wscale)
+            ym = conv2d(mosaic_pack(x, *plan), w, bias, act, wscale, _dgrad=_dgrad)
             return mosaic_unpack(ym, N, H, W, *plan)
     y = _out(out, (N, H, W, Cout), x)
     if MIXED and Cin % 8 == 0 and Cout % 4 == 0:
-        return _conv2d_mixed(x, w, bias, act, wscale, y)
+        return _conv2d_mixed(x, w, bias, act, wscale, y, _dgrad)
     lib = _lib.load()
     _lib.check(lib.sq_conv2d_nhwc_fwd_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, K,
                                          float(wscale), ACT[act], _stream()), "sq_conv2d_nhwc_fwd_f32")
@@ -313,7 +343,7 @@ def conv_weight_transform(w):
 
 def conv2d_dgrad(dy, w, wscale=1.0):
     """dX of conv2d: a forward convolution of dY with the transformed filter."""
-    return conv2d(dy, conv_weight_transform(w), None, act=None, wscale=wscale)
+    return conv2d(dy, w, None, act=None, wscale=wscale, _dgrad=True)
 
 
 def _grad_out(buf, shape, device):
@@ -605,7 +635,7 @@ def conv_dgrad_raw(dy, w, wscale=1.0):
     K, _, Cin, Cout = w.shape
     if Cin % 4 != 0 and not (K == 1 and Cin <= 4):
         raise _lib.SequitrHipError("conv dgrad to %d channels with K=%d is not supported" % (Cin, K))
-    return conv2d(dy, conv_weight_transform(w), None, act=None, wscale=wscale)
+    return conv2d(dy, w, None, act=None, wscale=wscale, _dgrad=True)
 
 
 def conv_wgrad_raw(x, dy, K, want_bias=False, dw_out=None, db_out=None):
