@@ -23,6 +23,13 @@
 //     tensor (537 MB per 32-tile batch) is never written or re-read and the HBM-bound convT launch disappears.
 #include "sq_common.h"
 
+#ifndef SQ_TILE_INTERLEAVE
+#define SQ_TILE_INTERLEAVE 0    // 1: block b takes tiles b, b+G, b+2G, ... (A/B switch: no measurable difference)
+#endif
+#ifndef SQ_STORE_PERMUTE
+#define SQ_STORE_PERMUTE 0      // 1: lane-contiguous stores through ds_bpermute (A/B switch: no measurable difference)
+#endif
+
 struct SqConvEpi {
     float *pooled;          // (N,H/2,W/2,Cout) or NULL
     const float *head_w;    // (Cout, head_c) 1x1 head or NULL (needs Cout == 16)
@@ -96,11 +103,23 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
     const int li = lane & 15, kk = lane >> 4;
     const int n0 = blockIdx.y * BN;
     const int vb = (int)sq_xcd_remap(blockIdx.x, gridDim.x);
+#if SQ_TILE_INTERLEAVE
+    // block b takes tiles b, b + G, b + 2G, ...: the G tiles in flight at any moment are a contiguous run of the
+    // image (whole rows of DRAM pages, shared halos resident in the same L2) instead of G scattered tile rows.
+    // Measured: no difference at any level.
+    const int tstride = (int)gridDim.x;
+    const int t_begin = vb;
+    if (t_begin >= ntiles) return;
+    const int t_count = (ntiles - vb + tstride - 1) / tstride;
+#else
+    const int tstride = 1;
     const int t_begin = vb * tiles_per_block;
     const int t_end = min(t_begin + tiles_per_block, ntiles);
     if (t_begin >= t_end) return;
+    const int t_count = t_end - t_begin;
+#endif
     const int nchunk = FIRST ? 1 : Cin / KC;
-    const int nitems = (t_end - t_begin) * nchunk;
+    const int nitems = t_count * nchunk;
     const bool restage_w = nchunk > 1;
 
     float4 xr[C::XSLOTS];
@@ -144,7 +163,9 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
     }
 
     // ---- issue the global loads of one work item (tile, chunk) into registers -------------
-    auto issue = [&](int tile, int cc, bool want_w) {
+    // live == false: every lane's offset is out of range, nothing is fetched (the item past the last one -- issue()
+    // and commit() run unconditionally every iteration, see the main loop)
+    auto issue = [&](int tile, int cc, bool want_w, bool live) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         if constexpr (FIRST) {
             // 20x20 single-channel patch around the tile (halo of the halo)
@@ -153,7 +174,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
             for (int sl = 0; sl < 2; ++sl) {
                 const int idx = tid + sl * 256;
                 const int py = idx / C::IN_W, px = idx % C::IN_W;
-                const bool inb = idx < C::IN_FLOATS && (unsigned)(y0 + py) < (unsigned)H &&
+                const bool inb = live && idx < C::IN_FLOATS && (unsigned)(y0 + py) < (unsigned)H &&
                                  (unsigned)(x0 + px) < (unsigned)W;
                 const unsigned off = inb ? (unsigned)((((n * H + y0 + py) * W) + x0 + px) * 4) : OOB;
                 inr[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, 0, 0));
@@ -163,7 +184,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
             const int base = (((n * H + y0) * W + x0) * Cin + cc) * 4;     // may be "negative": wraps back
 #pragma unroll
             for (int sl = 0; sl < C::XSLOTS; ++sl) {
-                const bool inb = (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
+                const bool inb = live && (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
                                  xrel[sl] != (int)OOB;
                 const unsigned off = inb ? (unsigned)(base + xrel[sl]) : OOB;
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
             for (int sl = 0; sl < 4; ++sl) {
                 const int idx = tid + sl * 256, lp = idx >> 3, q = idx & 7;
                 const int ly = lp / C::UP_W, lx = lp % C::UP_W;
-                const bool inb = idx < C::UP_W * C::UP_W * 8 && (unsigned)(ly0 + ly) < (unsigned)Hl &&
+                const bool inb = live && idx < C::UP_W * C::UP_W * 8 && (unsigned)(ly0 + ly) < (unsigned)Hl &&
                                  (unsigned)(lx0 + lx) < (unsigned)Wl;
                 const unsigned off = inb ? (unsigned)((((n * Hl + ly0 + ly) * Wl + lx0 + lx) * C::UP_CIN + q * 4) * 4) : OOB;
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, off, 0, 0);
@@ -188,7 +209,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
             const int wbase = cc * Cout * 4;
 #pragma unroll
             for (int sl = 0; sl < C::WSLOTS; ++sl) {
-                const unsigned off = wrel[sl] != (int)OOB ? (unsigned)(wbase + wrel[sl]) : OOB;
+                const unsigned off = (live && wrel[sl] != (int)OOB) ? (unsigned)(wbase + wrel[sl]) : OOB;
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0);
                 wr[sl] = *reinterpret_cast<const float4 *>(&v);
             }
@@ -361,14 +382,28 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         }
     }
 
+    // SQ_STORE_PERMUTE: lane-contiguous output stores.  The MFMA leaves lane 16*q + p with the channel quad q of pixel
+    // p, so a b128 store in that order touches four different 64-byte segments per 4 consecutive lanes (16 bytes of
+    // each).  ds_bpermute (cross-lane, no LDS memory) can hand lane 4*p + q that quad instead: every 4 lanes = one
+    // contiguous 64-byte segment.  Measured: no difference at any level -- the TA coalesces the instruction's 1 KiB either way.
+#if SQ_STORE_PERMUTE
+    const int st_src = (((lane & 3) << 4) | (lane >> 2)) << 2;   // byte address of the source lane for ds_bpermute
+    const int st_px = lane >> 2, st_q = lane & 3;
+#endif
+    // the lane's bias quads, fetched once: a load inside the epilogue costs every tile an L2 round trip
+    float4 bvr[NR];
+#pragma unroll
+    for (int nb = 0; nb < NR; ++nb) {
+        const int co = n0 + nb * 16 + 4 * kk;
+        bvr[nb] = (bias && co < Cout) ? *reinterpret_cast<const float4 *>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     auto epilogue = [&](int tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int gx = tx * TW + li;
 #pragma unroll
         for (int nb = 0; nb < NR; ++nb) {
             const int co = n0 + nb * 16 + 4 * kk;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bias && co < Cout) bv = *reinterpret_cast<const float4 *>(bias + co);
+            const float4 bv = bvr[nb];
             f32x4 o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -378,11 +413,25 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
                 o[r][2] = actf(bias ? acc[r][nb][2] + bv.z : acc[r][nb][2]);
                 o[r][3] = actf(bias ? acc[r][nb][3] + bv.w : acc[r][nb][3]);
                 if (epi.store_y) {
+#if SQ_STORE_PERMUTE
+                    const float t0 = __int_as_float(__builtin_amdgcn_ds_bpermute(st_src, __float_as_int(o[r][0])));
+                    const float t1 = __int_as_float(__builtin_amdgcn_ds_bpermute(st_src, __float_as_int(o[r][1])));
+                    const float t2 = __int_as_float(__builtin_amdgcn_ds_bpermute(st_src, __float_as_int(o[r][2])));
+                    const float t3 = __int_as_float(__builtin_amdgcn_ds_bpermute(st_src, __float_as_int(o[r][3])));
+                    f32x4 t = (f32x4){t0, t1, t2, t3};
+                    const int sgx = tx * TW + st_px, sco = n0 + nb * 16 + 4 * st_q;
+                    const bool ok = gy < H && sgx < W && sco < Cout;
+                    const unsigned off = ok ? (unsigned)((((n * H + gy) * W + sgx) * Cout + sco) * 4) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        *reinterpret_cast<__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned *>(&t),
+                        yrsrc, off, 0, 0);
+#else
                     const bool ok = gy < H && gx < W && co < Cout;
                     const unsigned off = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 4) : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(
                         *reinterpret_cast<__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned *>(&o[r]),
                         yrsrc, off, 0, 0);
+#endif
                 }
                 acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};      // ready for the next tile
             }
@@ -442,7 +491,8 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         }
     };
 
-    issue(t_begin, 0, true);
+    issue(t_begin, 0, true, true);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), stated outside commit()'s branches (see the main loop)
     commit(true);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -462,9 +512,9 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
     for (int it = 0; it < nitems; ++it) {
         // next work item
         int ntile = tile, nchk = chunk + 1;
-        if (nchk == nchunk) { nchk = 0; ntile = tile + 1; }
+        if (nchk == nchunk) { nchk = 0; ntile = tile + tstride; }
         const bool has_next = it + 1 < nitems;
-        if (has_next) issue(ntile, nchk * KC, restage_w);
+        if (has_next) issue(ntile, nchk * KC, restage_w, true);
 
         // ---- MFMA phase: NSTEP steps; the ds_reads of step s+1 are issued BEFORE the MFMAs
         // of step s (sched_barrier fences stop hipcc sinking them back to just-in-time) ----------
@@ -500,6 +550,12 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         }
         // ---- stage the next item, THEN store this tile: the stores drain under the next MFMA
         // phase instead of being waited for together with the prefetch (vmcnt is in-order) -------
+        // The prefetch has landed -- stated OUTSIDE the `has_next` branch.  The compiler does not correlate the two
+        // `if (has_next)` tests, so it also walks "issued but never committed", keeps the prefetch registers marked as
+        // pending loads round the back edge and guards the next issue()'s register writes with s_waitcnt vmcnt(5..0);
+        // at run time those wait for the epilogue's STORES (one counter for loads and stores on gfx9): a store round
+        // trip per tile, seen as "issue 32 % / epilogue 34 % / MFMA 28 %" in tools/conv_ablation.py timeline.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0); expcnt / lgkmcnt untouched
         if (has_next) {
             __syncthreads();            // every wave is done reading this item's LDS image
             commit(restage_w);

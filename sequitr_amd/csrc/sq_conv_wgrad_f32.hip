@@ -65,25 +65,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
         const_cast<float *>(dy), 0, (int)((size_t)N * H * W * Cout * 4), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
-    int xrel[C::XSLOTS], xpy[C::XSLOTS], xpx[C::XSLOTS];
-#pragma unroll
-    for (int sl = 0; sl < C::XSLOTS; ++sl) {
-        const int idx = tid + sl * 256;
-        const int pix = idx / C::QPP, q = idx % C::QPP;
-        xpy[sl] = pix / C::HALO_W;
-        xpx[sl] = pix % C::HALO_W;
-        xrel[sl] = idx < C::XITEMS ? ((xpy[sl] * W + xpx[sl]) * Cin + ci0 + q * 4) * 4 : (int)OOB;
-    }
-    int yrel[C::YSLOTS], ypy[C::YSLOTS], ypx[C::YSLOTS];
-#pragma unroll
-    for (int sl = 0; sl < C::YSLOTS; ++sl) {
-        const int idx = tid + sl * 256;
-        const int pix = idx / (BN / 4), q = idx % (BN / 4);
-        ypy[sl] = pix / TW;
-        ypx[sl] = pix % TW;
-        yrel[sl] = (co0 + q * 4 < Cout) ? ((ypy[sl] * W + ypx[sl]) * Cout + co0 + q * 4) * 4 : (int)OOB;
-    }
-
+    // the per-slot index decode is redone per tile (a few integer ops against 288+ MFMAs) instead of living in
+    // ~40 registers next to the accumulators: the <32,3,16> instance spilled 59 VGPRs with the tables
     float4 xr[C::XSLOTS], yr[C::YSLOTS];
     auto issue = [&](int tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
@@ -92,15 +75,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
         const int ybase = (((n * H + y0) * W + x0) * Cout) * 4;
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
-            const bool inb = (unsigned)(y0 - PAD + xpy[sl]) < (unsigned)H &&
-                             (unsigned)(x0 - PAD + xpx[sl]) < (unsigned)W && xrel[sl] != (int)OOB;
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? (unsigned)(xbase + xrel[sl]) : OOB, 0, 0);
+            const int idx = tid + sl * 256;
+            const int pix = idx / C::QPP, q = idx % C::QPP;
+            const int py = pix / C::HALO_W, px = pix % C::HALO_W;
+            const bool inb = idx < C::XITEMS && (unsigned)(y0 - PAD + py) < (unsigned)H &&
+                             (unsigned)(x0 - PAD + px) < (unsigned)W;
+            const unsigned off = inb ? (unsigned)(xbase + ((py * W + px) * Cin + ci0 + q * 4) * 4) : OOB;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
             xr[sl] = *reinterpret_cast<const float4 *>(&v);
         }
 #pragma unroll
         for (int sl = 0; sl < C::YSLOTS; ++sl) {
-            const bool inb = (y0 + ypy[sl]) < H && (x0 + ypx[sl]) < W && yrel[sl] != (int)OOB;
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, inb ? (unsigned)(ybase + yrel[sl]) : OOB, 0, 0);
+            const int idx = tid + sl * 256;
+            const int pix = idx / (BN / 4), q = idx % (BN / 4);
+            const int py = pix / TW, px = pix % TW;
+            const bool inb = (y0 + py) < H && (x0 + px) < W && co0 + q * 4 < Cout;
+            const unsigned off = inb ? (unsigned)(ybase + ((py * W + px) * Cout + co0 + q * 4) * 4) : OOB;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, off, 0, 0);
             yr[sl] = *reinterpret_cast<const float4 *>(&v);
         }
     };
