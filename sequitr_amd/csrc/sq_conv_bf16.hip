@@ -266,6 +266,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         const float neg = is_relu ? 0.0f : v * slope;
         return v > 0.0f ? v : neg;
     };
+    // the lane's bias quads, fetched once per block where the registers allow (BN <= 32): a load inside the epilogue
+    // costs every tile an L2 round trip
+    constexpr bool HOIST_BIAS = NR <= 2;
+    float4 bvr[HOIST_BIAS ? NR : 1];
+    if constexpr (HOIST_BIAS) {
+#pragma unroll
+        for (int nb = 0; nb < NR; ++nb) {
+            const int co = n0 + nb * 16 + 4 * kg;
+            bvr[nb] = (bias && co < Cout) ? *reinterpret_cast<const float4 *>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     auto epilogue = [&](int tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int gx = tx * TW + li;
@@ -273,7 +284,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         for (int nb = 0; nb < NR; ++nb) {
             const int co = n0 + nb * 16 + 4 * kg;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bias && co < Cout) bv = *reinterpret_cast<const float4 *>(bias + co);
+            if constexpr (HOIST_BIAS) bv = bvr[nb];
+            else if (bias && co < Cout) bv = *reinterpret_cast<const float4 *>(bias + co);
             unsigned offs[4];
             bf16x4 gv[4];
 #pragma unroll
@@ -300,6 +312,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     gv[r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(grsrc, offs[r], 0, 0));
+                // waited for inside the same branch: otherwise "loaded but never consumed" is a path to the compiler
+                // and the main loop's prefetch gets guarded by waits that drain the stores
+                __builtin_amdgcn_s_waitcnt(0x0F70);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -327,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     };
 
     issue(t_begin, 0, true);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), stated outside commit()'s branches (see the main loop)
     commit(true);
     __syncthreads();
     int tile = t_begin, chunk = 0;
@@ -352,6 +368,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                     acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nb], b[r], acc[r][nb], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(3);
+        // the prefetch has landed -- stated OUTSIDE the `has_next` branch: hipcc does not correlate the two tests, keeps the
+        // prefetch registers marked as pending loads round the back edge and otherwise guards the next issue() with
+        // s_waitcnt vmcnt(n), which at run time waits for the epilogue's stores (sq_conv_f32_v2.hip)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0); expcnt / lgkmcnt untouched
         if (has_next) {
             __syncthreads();
             commit(restage_w);
