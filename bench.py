@@ -446,7 +446,8 @@ def main_gan(args):
     from sequitr_amd.networks.gan import GenerativeAdverserialNetwork
     nb, level = 32, 6
     g = GenerativeAdverserialNetwork({"num_levels": 7, "batch_size": nb, "repeat_batch": 1, "learning_rate": 1e-3,
-                                      "device": str(dev), "seed": 0, "dtype": args.dtype}, mode=None)
+                                      "device": str(dev), "seed": 0, "dtype": args.dtype,
+                                      "graph": bool(args.graph)}, mode=None)
     g.build()
     g.set_level(level)
     rng = np.random.default_rng(3 + rank)
@@ -485,7 +486,8 @@ def main_gan(args):
                           "config": {"workload": "progressive WGAN-GP level 6 (256x256x2), filters "
                                                  "[512,256,128,64,32,16,8], batch 32 per GPU, alpha 1; " +
                                                  ("f32 tensors, bf16-multiply / f32-accumulate convolutions"
-                                                  if args.dtype == "bf16" else "fp32"),
+                                                  if args.dtype == "bf16" else "fp32") +
+                                                 ("; hipGraph replay" if args.graph else "; eager launches"),
                                      "d_loss": g.last_losses[0], "g_loss": g.last_losses[1]}}))
     if dist is not None:
         dist.destroy_process_group()
@@ -500,7 +502,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="--mode train / gan: compute dtype")
     ap.add_argument("--fuse-up", type=int, default=1, help="1 = convT+bridge of up0 inside its first conv (infer mode)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive rate (infer mode)")
-    ap.add_argument("--graph", type=int, default=1, help="--mode train: replay the step as hipGraphs (1) or eager (0)")
+    ap.add_argument("--graph", type=int, default=1, help="--mode train / gan: replay the step as hipGraphs (1) or eager (0)")
     ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
     ap.add_argument("--mode", choices=["infer", "train", "gan", "centroids", "weightmap", "frontend"], default="infer",
                     help="infer = the headline metric (BASELINE configs[1]); train = configs[2]/[3] "

@@ -179,6 +179,11 @@ int sq_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, fl
  * the counter on the device, so a captured step replays with the right bias correction. */
 int sq_adam_step_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
                          float beta2, float eps, int32_t *state, float grad_scale, void *stream);
+/* its two halves, for optimisers with per-variable slots (the GAN's two AdamOptimizers, gan.py:736-751): one advance
+ * of {step, lr_t} per minimize(), then one apply per tensor reading it. */
+int sq_adam_advance_dev(int32_t *state, float lr, float beta1, float beta2, void *stream);
+int sq_adam_apply_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float beta1, float beta2,
+                          float eps, const int32_t *state, float grad_scale, void *stream);
 
 /* conv_transpose_layer with a 3x3 kernel (SURVEY.md A.1 `up_kernel` = (3,3); hook at
  * sequitr/networks/unet.py:336-338): TF's conv2d_transpose(k=3, s=2, SAME) equals a SAME 3x3

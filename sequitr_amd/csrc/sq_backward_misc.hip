@@ -493,6 +493,22 @@ extern "C" int sq_adam_step_f32(float *p, const float *g, float *m, float *v, in
     return sq_check_launch("sq_adam_step_f32");
 }
 
+// the two halves of sq_adam_step_dev_f32 for optimisers that update many tensors per step (the GAN's per-variable
+// slots): ONE advance per minimize(), then one apply per tensor
+extern "C" int sq_adam_advance_dev(int32_t *state, float lr, float beta1, float beta2, void *stream) {
+    SQ_REQUIRE(state, "sq_adam_advance_dev: null state");
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, SQ_ST(stream), state, lr, beta1, beta2);
+    return sq_check_launch("sq_adam_advance_dev");
+}
+
+extern "C" int sq_adam_apply_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float beta1, float beta2,
+                                     float eps, const int32_t *state, float grad_scale, void *stream) {
+    SQ_REQUIRE(p && g && m && v && state && n > 0, "sq_adam_apply_dev_f32: bad arguments");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), p, g, m, v, n, 0.f, state, beta1,
+                       beta2, eps, grad_scale);
+    return sq_check_launch("sq_adam_apply_dev_f32");
+}
+
 extern "C" int sq_adam_step_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
                                     float beta2, float eps, int32_t *state, float grad_scale, void *stream) {
     SQ_REQUIRE(p && g && m && v && state && n > 0, "sq_adam_step_dev_f32: bad arguments");

@@ -187,19 +187,24 @@ class _Adam(object):
 
     def __init__(self, lr, beta1=0.0, beta2=0.99, eps=1e-8):
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
-        self.t = 0
+        self.t = 0                  # host mirror of the device counter
+        self.state = None           # int32[2] {step, lr_t bits} on the device: a captured step replays correctly
         self.slots = {}
 
     def apply(self, named_vars, grads, grad_scale=1.0):
+        live = [(name, v, g) for (name, v), g in zip(named_vars, grads) if g is not None]
+        if not live:
+            return
         self.t += 1
-        for (name, v), g in zip(named_vars, grads):
-            if g is None:
-                continue
+        if self.state is None:
+            self.state = torch.zeros(2, dtype=torch.int32, device=live[0][1].device)
+        ops.adam_advance_dev(self.state, self.lr, self.b1, self.b2)       # ONE shared beta-power step per minimize()
+        for name, v, g in live:
             if name not in self.slots:
                 self.slots[name] = (torch.zeros_like(v), torch.zeros_like(v))
             m, s = self.slots[name]
-            ops.adam_step(v.detach().view(-1), g.contiguous().view(-1), m.view(-1), s.view(-1), self.lr, self.b1,
-                          self.b2, self.eps, self.t, grad_scale=grad_scale)
+            ops.adam_apply_dev(v.detach().view(-1), g.contiguous().view(-1), m.view(-1), s.view(-1), self.b1, self.b2,
+                               self.eps, self.state, grad_scale=grad_scale)
 
 
 class GenerativeAdverserialNetwork(object):
@@ -208,7 +213,8 @@ class GenerativeAdverserialNetwork(object):
     params: num_outputs, batch_size, repeat_batch, num_levels, num_epochs_per_level, start_size,
     training_data (``.npy`` (N,H,W,C) stack; None -> synthetic tiles), learning_rate; new keys:
     device, seed, num_batches_per_epoch (when the data is synthetic), dtype ('f32' default: exact-f32 MFMA
-    convolutions; 'bf16': the f32 graph with bf16-multiply / f32-accumulate convolutions, BASELINE config 5)."""
+    convolutions; 'bf16': the f32 graph with bf16-multiply / f32-accumulate convolutions, BASELINE config 5),
+    graph (default False: True replays the solver steps of the alpha == 1 phases as hipGraphs)."""
 
     def __init__(self, params, mode=None, discriminator_fn=discriminator_network,
                  generator_fn=generator_network):
@@ -223,6 +229,9 @@ class GenerativeAdverserialNetwork(object):
         self.start_size = params.get('start_size', (4, 4))
         self.training_data_filename = params.get('training_data', None)
         self.learning_rate = params.get('learning_rate', 1e-3)
+        self.use_graph = bool(params.get('graph', False))    # replay solver steps at alpha == 1 as hipGraphs
+        self._graphs = {}
+        self._capture_stream = None
         self.dtype = params.get('dtype', 'f32')
         if self.dtype not in ('f32', 'bf16'):
             raise ValueError("dtype must be 'f32' or 'bf16', got %r" % (self.dtype,))
@@ -255,7 +264,7 @@ class GenerativeAdverserialNetwork(object):
         self.filters = utils.filter_doubling(start_filters=8, num_layers=self.num_levels,
                                              max_filters=512, reverse=True)
         self.d_opt = self.g_opt = None
-        self.last_losses = None
+        self._last_losses = None
 
     # -- properties / helpers, gan.py:542-568 ---------------------------------------------------------
     @property
@@ -397,37 +406,104 @@ class GenerativeAdverserialNetwork(object):
         """context for everything this network launches (forward AND backward): `with net.precision(): ...`"""
         return ops.mixed_precision(self.dtype == 'bf16')
 
+    @property
+    def last_losses(self):
+        """(d_loss, g_loss) of the last discriminator step as floats; read lazily so a step never waits for the GPU"""
+        if self._last_losses is None:
+            return None
+        return tuple(float(t) for t in self._last_losses)
+
     def d_solver(self, X, Z, alpha, r=None):
         """d_opt.minimize(d_loss, var_list=d_vars) for the current level (gan.py:649)."""
         with self.precision():
+            if self._graphable(alpha) and r is None:
+                return self._solver_graphed('d', X, Z, alpha)
             return self._d_solver(X, Z, alpha, r)
 
     def g_solver(self, X, Z, alpha):
         """g_opt.minimize(g_loss, var_list=g_vars, global_step) for the current level (gan.py:650-651)."""
         with self.precision():
+            if self._graphable(alpha):
+                return self._solver_graphed('g', X, Z, alpha)
             return self._g_solver(X, Z, alpha)
 
-    def _d_solver(self, X, Z, alpha, r=None):
-        level = self.current_level
-        d_vars, _ = self.get_training_variables(level)
+    # the two halves of a solver step: (losses + gradients) and (Adam); the all-reduce sits between them
+    def _d_grads(self, X, Z, alpha, r):
+        d_vars, _ = self.get_training_variables(self.current_level)
         _, d_loss, g_loss = self._build_network(X, Z, alpha, r=r, need_g_graph=False)
         grads = torch.autograd.grad(d_loss, [v for _, v in d_vars], allow_unused=True)
-        scale = self._allreduce(grads)
-        self.d_opt.apply(d_vars, grads, grad_scale=scale)
-        self.last_losses = (float(d_loss.detach()), float(g_loss.detach()))
-        return d_loss.detach()
+        return d_vars, grads, (d_loss.detach(), g_loss.detach())
 
-    def _g_solver(self, X, Z, alpha):
-        level = self.current_level
-        _, g_vars = self.get_training_variables(level)
+    def _g_grads(self, X, Z, alpha):
+        _, g_vars = self.get_training_variables(self.current_level)
         d_filters, _, Gz, _ = self._prepare(X, Z, alpha, need_g_graph=True)
         _, Dz = self.discriminator(Gz, d_filters)
         g_loss = torch.mean(-Dz)
         grads = torch.autograd.grad(g_loss, [v for _, v in g_vars], allow_unused=True)
+        return g_vars, grads, (g_loss.detach(),)
+
+    def _d_solver(self, X, Z, alpha, r=None):
+        d_vars, grads, losses = self._d_grads(X, Z, alpha, r)
+        scale = self._allreduce(grads)
+        self.d_opt.apply(d_vars, grads, grad_scale=scale)
+        self._last_losses = losses
+        return losses[0]
+
+    def _g_solver(self, X, Z, alpha):
+        g_vars, grads, losses = self._g_grads(X, Z, alpha)
         scale = self._allreduce(grads)
         self.g_opt.apply(g_vars, grads, grad_scale=scale)
         self.global_step += 1
-        return g_loss.detach()
+        return losses[0]
+
+    # -- hipGraph replay of the solver steps (a step is ~700 short launches: host-bound from Python) ----------------
+    def _graphable(self, alpha):
+        return self.use_graph and float(alpha) == 1.0           # alpha is baked into the launches: stabilisation phases only
+
+    def _solver_graphed(self, kind, X, Z, alpha):
+        """call 1 for a (solver, level, batch shape): the ordinary eager step (it also warms every kernel up);
+        call 2: capture (gradients) and (Adam) as two hipGraphs and replay them; later calls: copy the inputs into the
+        static buffers and replay.  The mixing tensor r is drawn eagerly before each replay; the gradient all-reduce
+        stays between the two graphs, outside any capture, so the RCCL call is an ordinary stream operation."""
+        key = (kind, self.current_level, tuple(X.shape), tuple(Z.shape))
+        entry = self._graphs.get(key)
+        if entry is None:
+            self._graphs[key] = 'warm'
+            return self._d_solver(X, Z, alpha) if kind == 'd' else self._g_solver(X, Z, alpha)
+        opt = self.d_opt if kind == 'd' else self.g_opt
+        if entry == 'warm':
+            sx, sz = X.clone(), Z.clone()
+            sr = torch.empty((X.shape[0],), dtype=torch.float32, device=self.device) if kind == 'd' else None
+            if self._capture_stream is None:
+                self._capture_stream = torch.cuda.Stream(device=self.device)
+            torch.cuda.synchronize(self.device)
+            g_grad, g_adam = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_grad, stream=self._capture_stream):
+                named, grads, losses = self._d_grads(sx, sz, alpha, sr) if kind == 'd' else self._g_grads(sx, sz, alpha)
+            t_host = opt.t
+            with torch.cuda.graph(g_adam, stream=self._capture_stream):
+                opt.apply(named, grads, grad_scale=1.0 / self._world())
+            opt.t = t_host                                      # the capture executed nothing
+            entry = self._graphs[key] = (g_grad, g_adam, sx, sz, sr, grads, losses)
+        g_grad, g_adam, sx, sz, sr, grads, losses = entry
+        sx.copy_(X), sz.copy_(Z)
+        if sr is not None:
+            sr.copy_(self._mixing_r(X.shape[0]))
+        g_grad.replay()
+        self._allreduce(grads)
+        g_adam.replay()
+        opt.t += 1
+        if kind == 'd':
+            self._last_losses = losses
+        else:
+            self.global_step += 1
+        return losses[0]
+
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
 
     # -- data -----------------------------------------------------------------------------------------
     def build_latent(self):

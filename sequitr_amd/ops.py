@@ -739,6 +739,23 @@ def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, state, grad_scale=1.0):
                "sq_adam_step_dev_f32")
 
 
+def adam_advance_dev(state, lr, beta1, beta2):
+    """one minimize(): step += 1 and lr_t on the device (`state` int32[2]); hipGraph-safe."""
+    _chk(state, "state", dtype=torch.int32)
+    _lib.check(_lib.load().sq_adam_advance_dev(_ptr(state), float(lr), float(beta1), float(beta2), _stream()),
+               "sq_adam_advance_dev")
+
+
+def adam_apply_dev(p, g, m, v, beta1, beta2, eps, state, grad_scale=1.0):
+    """Adam update of one tensor with the {step, lr_t} of the last adam_advance_dev."""
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, n)
+    _chk(state, "state", dtype=torch.int32)
+    _lib.check(_lib.load().sq_adam_apply_dev_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(beta1), float(beta2),
+                                                float(eps), _ptr(state), float(grad_scale), _stream()),
+               "sq_adam_apply_dev_f32")
+
+
 # ----------------------------------------------------------------------------------------------
 # batch normalisation (include/sequitr_hip.h "Batch normalisation"; SURVEY.md A.1 `batch_norm`)
 # ----------------------------------------------------------------------------------------------
