@@ -1,0 +1,60 @@
+"""The driver's contract with bench.py (task statement "Maintain bench.py", tier section 4): flags, ONE JSON line,
+the metric / roofline / cpu_baseline objects and the algorithmic-work figure of SURVEY 8(d)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_flags_and_work_figures_cpu():
+    import bench
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], stdout=subprocess.PIPE, text=True).stdout
+    for flag in ("--gpus", "--steps", "--warmup", "--mode", "--dtype"):
+        assert flag in out, flag
+    # 19,285,409,792 FLOP per 512x512 tile for filters 16..256, 2 classes, eltwise bridge
+    f, t = bench.FILTERS, bench.TILE
+    flops, cin = 0.0, 1
+    for i, c in enumerate(f):                                               # encoder: conv1, conv2 per level
+        h = t >> i
+        flops += bench.mfma_conv_flops(1, h, h, cin, c, 3) + bench.mfma_conv_flops(1, h, h, c, c, 3)
+        cin = c
+    for i in reversed(range(len(f) - 1)):                                   # decoder: convT 2x2, conv1, conv2
+        h = t >> i
+        flops += 2.0 * (h // 2) * (h // 2) * 4 * f[i + 1] * f[i] + 2 * bench.mfma_conv_flops(1, h, h, f[i], f[i], 3)
+    flops += bench.mfma_conv_flops(1, t, t, f[0], 2, 1)
+    assert flops == 19285409792.0
+    assert bench.PEAK_F32_MFMA_TFLOPS == 157.3
+    a = np.array([[0, 1], [1, 1]])
+    assert bench.iou_per_class(a, a) == [1.0, 1.0] and bench.iou_per_class(a, 1 - a) == [0.0, 0.0]
+    # the committed PMC summary the line's roofline.traffic comes from
+    assert bench.pmc_traffic_per_launch() is None or bench.pmc_traffic_per_launch() > 1e8
+
+
+@pytest.mark.gpu
+def test_default_line_has_every_contract_field():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                            # exactly ONE JSON line on stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["unit"] == "Mpixels/s" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 32 * 512 * 512 / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["value"]
+    rl = d["roofline"]
+    assert rl["bound"] == "mfma" and rl["unit"] == "TFLOP/s" and rl["peak"] == 157.3
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3 and 0.3 < rl["frac"] < 1.0
+    assert rl["traffic"] is None or rl["traffic"] > 1e8
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert min(cb["iou_gpu_vs_cpu_per_class"]) >= 0.9999                     # oneDNN sums in another order: near-ties may flip
