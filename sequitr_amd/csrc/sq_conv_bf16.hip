@@ -17,6 +17,7 @@
 // LDS, and the f32 accumulators are stored as f32 -- bf16 multiply / f32 accumulate behind an f32 graph (the GAN
 // of BASELINE config 5, whose double-backward graph is built from f32 ops).
 #include "sq_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -472,8 +473,14 @@ int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int
 template <int KS, int KC, typename TIO>
 int dispatch_bn(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int H, int W, int Cin,
                 int Cout, int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
-    if (Cout >= 64) return launch<64, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
-    if (Cout > 16) return launch<32, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    // narrow the channel block until the launch has ~2 blocks per CU (as sq_conv_f32_v2.hip): the GAN's 4x4 .. 32x32
+    // levels are a handful of mosaic tiles x 512 .. 64 channels, and 64-channel blocks leave most of the chip idle
+    const int64_t ntiles = (int64_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH) * N;
+    int bn = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16);
+    static const int narrow = [] { const char *e = getenv("SQ_CONV_BF16_NARROW"); return e ? atoi(e) : 1; }();
+    while (narrow && bn > 16 && ntiles * ((Cout + bn - 1) / bn) < 2 * 256) bn >>= 1;
+    if (bn == 64) return launch<64, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    if (bn == 32) return launch<32, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
     return launch<16, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
 }
 
