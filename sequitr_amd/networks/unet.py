@@ -506,6 +506,75 @@ class UNet2D(UNet):
         return self._mask
 
 
+class UNet_LEGACY(UNet2D):
+    """The reference's older wiring (unet.py:445-729): identical arithmetic, but no variable scopes -- the layer
+    names ``L{i}d`` / ``L{i}u`` are passed to down_layer / up_layer and never used (unet.py:626-639, 655, 678), so
+    under TF-1.x the variables carry ``tf.layers``' automatic names: ``conv2d``, ``conv2d_1`` ... in creation order
+    (the 1x1 head is the last ``conv2d_<n>``) and ``conv2d_transpose``, ``conv2d_transpose_1`` ...  ``state_dict()``
+    has exactly those keys, so a legacy checkpoint exported to ``.npz`` loads by name.  The hook it calls for pooling
+    is ``max_pool_layer`` (unet.py:727).  Runs the per-layer path (the fused kernels key on the scoped names)."""
+
+    def __init__(self, params, mode=PREDICT):
+        UNet2D.__init__(self, dict(params, fuse=False), mode)
+        self._auto = {}
+
+    def _auto_scope(self, kind):
+        n = self._auto.get(kind, 0)
+        self._auto[kind] = n + 1
+        return self.variable_scope(kind if n == 0 else '{0:s}_{1:d}'.format(kind, n))
+
+    def build(self, features):                                 # unet.py:613-647
+        logger.info('Building UNet ({0:s})...'.format(self.__class__.__name__))
+        self._auto = {}
+        input_layer = self.reshape_input(features)
+        self._net = [self.down_layer(input_layer, self.filters[0], name='L0d')]
+        for i, f in enumerate(self.filters[1:]):
+            prev_layer = self.max_pool_layer(self._net[-1])
+            self._net.append(self.down_layer(prev_layer, f, name='L{0:d}d'.format(i + 1)))
+        for i, f in reversed(list(enumerate(self.filters[:-1]))):
+            self._net.append(self.up_layer(self._net[-1], f, self._net[i], name='L{0:d}u'.format(i)))
+        logits = self.conv_layer_1x1(self._net[-1], self.n_outputs)
+        self._net.append(logits)
+        logger.info('Output layer -> shape {0:s}'.format(str(tuple(logits.shape))))
+        return logits
+
+    def down_layer(self, x, filters, name=None):               # unet.py:655-675: the name is not used
+        return self.dropout_layer(self.conv_layer(self.conv_layer(x, filters), filters))
+
+    def up_layer(self, x, filters, bridge, name=None):         # unet.py:678-705
+        merged = self.bridge(self.conv_transpose_layer(x, filters), bridge)
+        return self.dropout_layer(self.conv_layer(self.conv_layer(merged, filters), filters))
+
+    def conv_layer(self, x, filters):
+        with self._auto_scope('conv2d'):
+            return UNet2D.conv_layer(self, x, filters)
+
+    def conv_layer_1x1(self, x, filters):
+        with self._auto_scope('conv2d'):
+            return UNet2D.conv_layer_1x1(self, x, filters)
+
+    def conv_transpose_layer(self, x, filters):
+        with self._auto_scope('conv2d_transpose'):
+            return UNet2D.conv_transpose_layer(self, x, filters)
+
+
+def legacy_state_dict(weights, params):
+    """Scoped U-Net weights (``UNet/down0/conv1/kernel`` ...) under UNet_LEGACY's automatic names, in creation
+    order -- and the inverse mapping, for moving checkpoints between the two wirings."""
+    out, back, nc, nt = {}, {}, 0, 0
+    for key, _shape in unet_variable_shapes(params):
+        scope, var = key.rsplit('/', 1)
+        if scope not in back:
+            if scope.endswith('/upscale'):
+                back[scope] = 'conv2d_transpose' if nt == 0 else 'conv2d_transpose_%d' % nt
+                nt += 1
+            else:
+                back[scope] = 'conv2d' if nc == 0 else 'conv2d_%d' % nc
+                nc += 1
+        out[back[scope] + '/' + var] = weights[key]
+    return out, {v: k for k, v in back.items()}
+
+
 class GraphedPredict(object):
     """UNet2D.predict captured as one hipGraph for a fixed batch shape (inference is GPU-bound, but one graph
     launch per batch instead of ~25 kernel launches makes the host side immune to scheduling jitter: a

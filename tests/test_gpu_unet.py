@@ -281,3 +281,32 @@ def test_multi_channel_input_bit_exact(cin, filters):
     ref = unet_oracle.unet_forward(x, w, params)
     assert_bit_exact(net.logits().cpu().numpy(), ref, "logits")
     assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "mask")
+
+
+def test_legacy_wiring_same_bits_flat_variable_names():
+    """UNet_LEGACY (unet.py:445-729): identical arithmetic, tf.layers' automatic variable names, max_pool_layer hook."""
+    from sequitr_amd.networks.unet import UNet_LEGACY, legacy_state_dict
+    params = {"shape": (32, 32), "filters": (16, 32, 64)}
+    w = init_unet_weights(params, 4)
+    flat, back = legacy_state_dict(w, params)
+    assert "conv2d/kernel" in flat and "conv2d_10/kernel" in flat and "conv2d_transpose_1/bias" in flat
+    assert back["conv2d_10"] == "UNet/to_image" and back["conv2d_transpose"] == "UNet/up1/upscale"
+    calls = []
+
+    class Net(UNet_LEGACY):
+        def max_pool_layer(self, x):
+            calls.append(tuple(x.shape))
+            return UNet_LEGACY.max_pool_layer(self, x)
+
+    net = Net(dict(params, device="cuda:0"), "infer")
+    net.load_state_dict(flat)
+    x = tiles(5, 2, 32, 32)
+    mask = net.predict(x)
+    ref = unet_oracle.unet_forward(x, w, params)
+    assert_bit_exact(net.logits().cpu().numpy(), ref, "legacy logits")
+    assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref), "legacy mask")
+    assert sorted(net.state_dict()) == sorted(flat) and len(calls) == 2
+    # a fresh legacy net creates the same names on its own
+    fresh = UNet_LEGACY(dict(params, device="cuda:0"), "infer")
+    fresh.predict(x)
+    assert sorted(fresh.state_dict()) == sorted(flat)

@@ -160,3 +160,16 @@ def test_logging_setup_validation(tmp_path):
     with pytest.raises(ValueError):
         serverlogs.setup_logging(str(tmp_path), "other")
     assert serverlogs.generate_log_filename().startswith("LOG_(")
+
+
+def test_legacy_variable_names_mapping_is_a_bijection_in_creation_order():
+    from sequitr_amd.networks.unet import init_unet_weights, legacy_state_dict, unet_variable_shapes
+    params = {"filters": (16, 32, 64, 128, 256)}
+    w = init_unet_weights(params, 0)
+    flat, back = legacy_state_dict(w, params)
+    assert len(flat) == len(w) == 2 * 23 and len(back) == 23          # 18 convs + 4 transposes + the head
+    assert back["conv2d"] == "UNet/down0/conv1" and back["conv2d_18"] == "UNet/to_image"
+    assert back["conv2d_10"] == "UNet/up3/conv1" and back["conv2d_transpose_3"] == "UNet/up0/upscale"
+    for k, scoped in back.items():
+        assert flat[k + "/kernel"] is w[scoped + "/kernel"]
+    assert [k for k, _ in unet_variable_shapes(params)][0] == "UNet/down0/conv1/kernel"
