@@ -465,6 +465,44 @@ def main_frontend(args):
     print(json.dumps(res))
 
 
+def main_infer_bf16(args):
+    """Secondary line: the inference batch of config 2 through the bf16 graph (bf16 activations and multiplies, f32
+    accumulation), with the IoU of its masks against the fp32 path's -- what BASELINE's metric asks beside the rate.
+    Not the headline (config 2 is fp32); op by op, none of the fp32 path's fusions."""
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from sequitr_amd.networks.unet import UNet2D, UNet2DBf16, init_unet_weights
+    params = {"shape": (TILE, TILE), "num_inputs": 1, "num_outputs": 2, "filters": FILTERS, "bridge": "eltwise_mul",
+              "device": str(dev)}
+    weights = init_unet_weights(params, seed=0)
+    x = torch.from_numpy(np.random.default_rng(1).standard_normal((BATCH, TILE, TILE, 1)).astype(np.float32)).to(dev)
+    ref = UNet2D(params, "infer")
+    ref.load_state_dict(weights)
+    mref = ref.predict(x).cpu().numpy()
+    lref = ref.logits().float().cpu()
+    net = UNet2DBf16(params, "infer")
+    net.load_state_dict(weights)
+    for _ in range(max(args.warmup, 2)):
+        net.predict(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m = net.predict(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    iou = iou_per_class(m.cpu().numpy(), mref)
+    ldiff = float((net.logits().float().cpu() - lref).abs().max())
+    print(json.dumps({"metric": "segmented Mpixels/sec on 512x512 tiles; IoU vs reference", "value": round(BATCH * TILE * TILE / dt / 1e6, 3),
+                      "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "bf16", "data": "synthetic",
+                      "config": {"workload": "U-Net 2-class inference, batch=32 512x512x1 tiles, bf16 activations / f32 "
+                                             "accumulation, per-layer launches (secondary line: config 2 is fp32)",
+                                 "iou_vs_fp32_masks_per_class": [round(v, 6) for v in iou],
+                                 "logits_max_abs_diff_vs_fp32": float("%.3e" % ldiff),
+                                 "logits_max_abs_fp32": float("%.3e" % float(lref.abs().max()))}}))
+
+
 def main_gan(args):
     """BASELINE configs[4]: progressive WGAN-GP at level 6 (256x256x2), batch 32 per GPU, alpha = 1;
     one iteration = one d_solver + one g_solver (sequitr/networks/gan.py:850-851)."""
@@ -541,12 +579,14 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive rate (infer mode)")
     ap.add_argument("--graph", type=int, default=1, help="--mode train / gan: replay the step as hipGraphs (1) or eager (0)")
     ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
-    ap.add_argument("--mode", choices=["infer", "train", "gan", "centroids", "weightmap", "frontend"], default="infer",
+    ap.add_argument("--mode", choices=["infer", "infer-bf16", "train", "gan", "centroids", "weightmap", "frontend"], default="infer",
                     help="infer = the headline metric (BASELINE configs[1]); train = configs[2]/[3] "
                          "(U-Net training step, batch 16 per GPU) for DESIGN.md, not the driver's line")
     args = ap.parse_args()
     if args.mode == "train":
         return main_train(args)
+    if args.mode == "infer-bf16":
+        return main_infer_bf16(args)
     if args.mode == "gan":
         return main_gan(args)
     if args.mode == "centroids":
