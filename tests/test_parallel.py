@@ -79,3 +79,34 @@ def test_allreduce_equals_global_batch_gradient():
 def test_allreduce_is_noop_without_process_group():
     t = torch.ones(8)
     assert allreduce_sum_(t) == 1 and torch.all(t == 1)
+
+
+def _gan_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from sequitr_amd.networks.gan import GenerativeAdverserialNetwork as GAN
+        g = torch.Generator().manual_seed(rank)
+        grads = [torch.randn(3, 3, 4, 8, generator=g), None, torch.randn(8, generator=g), torch.randn(1, 1, 8, 2, generator=g)]
+        mine = [None if t is None else t.clone() for t in grads]
+        scale = GAN._allreduce(SimpleNamespace(group=None), grads)          # the solver's ONE collective per step
+        others = []
+        for r in range(world):
+            gr = torch.Generator().manual_seed(r)
+            others.append([torch.randn(3, 3, 4, 8, generator=gr), None, torch.randn(8, generator=gr), torch.randn(1, 1, 8, 2, generator=gr)])
+        ok = scale == 1.0 / world and grads[1] is None
+        for i in (0, 2, 3):
+            want = sum(o[i] for o in others)
+            ok = ok and torch.allclose(grads[i], want, rtol=0, atol=1e-6) and grads[i].shape == mine[i].shape
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gan_solver_allreduce_sums_every_live_gradient_in_one_collective():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gan_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
