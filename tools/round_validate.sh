@@ -15,7 +15,7 @@ timeout -k 10 200 python bench.py --mode train --dtype f32 --steps 20 --warmup 3
 timeout -k 10 300 python bench.py --mode gan --dtype f32 --steps 5 --warmup 2 > $O/bench_gan.json 2>/dev/null
 timeout -k 10 300 python bench.py --mode gan --dtype bf16 --steps 5 --warmup 2 > $O/bench_gan_bf16.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_infer -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_infer.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_infer -- python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-end-to-end > $O/prof_infer.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gan_bf16 -- python $R/bench.py --mode gan --dtype bf16 --steps 5 --warmup 2 > $O/prof_gan_bf16.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/pmc_write.log 2>&1
