@@ -214,7 +214,7 @@ class GenerativeAdverserialNetwork(object):
     training_data (``.npy`` (N,H,W,C) stack; None -> synthetic tiles), learning_rate; new keys:
     device, seed, num_batches_per_epoch (when the data is synthetic), dtype ('f32' default: exact-f32 MFMA
     convolutions; 'bf16': the f32 graph with bf16-multiply / f32-accumulate convolutions, BASELINE config 5),
-    graph (default False: True replays the solver steps of the alpha == 1 phases as hipGraphs)."""
+    graph (default False: True replays the solver steps as hipGraphs)."""
 
     def __init__(self, params, mode=None, discriminator_fn=discriminator_network,
                  generator_fn=generator_network):
@@ -229,7 +229,7 @@ class GenerativeAdverserialNetwork(object):
         self.start_size = params.get('start_size', (4, 4))
         self.training_data_filename = params.get('training_data', None)
         self.learning_rate = params.get('learning_rate', 1e-3)
-        self.use_graph = bool(params.get('graph', False))    # replay solver steps at alpha == 1 as hipGraphs
+        self.use_graph = bool(params.get('graph', False))    # replay the solver steps as hipGraphs
         self._graphs = {}
         self._capture_stream = None
         self.dtype = params.get('dtype', 'f32')
@@ -458,13 +458,15 @@ class GenerativeAdverserialNetwork(object):
 
     # -- hipGraph replay of the solver steps (a step is ~700 short launches: host-bound from Python) ----------------
     def _graphable(self, alpha):
-        return self.use_graph and float(alpha) == 1.0           # alpha is baked into the launches: stabilisation phases only
+        return self.use_graph                                   # alpha rides in a device tensor: fade phases replay too
 
     def _solver_graphed(self, kind, X, Z, alpha):
         """call 1 for a (solver, level, batch shape): the ordinary eager step (it also warms every kernel up);
         call 2: capture (gradients) and (Adam) as two hipGraphs and replay them; later calls: copy the inputs into the
-        static buffers and replay.  The mixing tensor r is drawn eagerly before each replay; the gradient all-reduce
-        stays between the two graphs, outside any capture, so the RCCL call is an ordinary stream operation."""
+        static buffers and replay.  The fade-in alpha is a per-sample device tensor (the form F.lerp / ops.lerp take
+        anyway), refilled before each replay, so one pair of graphs serves the fade and the stabilisation phase; the
+        mixing tensor r is drawn eagerly before each replay; the gradient all-reduce stays between the two graphs,
+        outside any capture, so the RCCL call is an ordinary stream operation."""
         key = (kind, self.current_level, tuple(X.shape), tuple(Z.shape))
         entry = self._graphs.get(key)
         if entry is None:
@@ -473,20 +475,21 @@ class GenerativeAdverserialNetwork(object):
         opt = self.d_opt if kind == 'd' else self.g_opt
         if entry == 'warm':
             sx, sz = X.clone(), Z.clone()
+            sa = torch.full((X.shape[0],), float(alpha), dtype=torch.float32, device=self.device)
             sr = torch.empty((X.shape[0],), dtype=torch.float32, device=self.device) if kind == 'd' else None
             if self._capture_stream is None:
                 self._capture_stream = torch.cuda.Stream(device=self.device)
             torch.cuda.synchronize(self.device)
             g_grad, g_adam = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_grad, stream=self._capture_stream):
-                named, grads, losses = self._d_grads(sx, sz, alpha, sr) if kind == 'd' else self._g_grads(sx, sz, alpha)
+                named, grads, losses = self._d_grads(sx, sz, sa, sr) if kind == 'd' else self._g_grads(sx, sz, sa)
             t_host = opt.t
             with torch.cuda.graph(g_adam, stream=self._capture_stream):
                 opt.apply(named, grads, grad_scale=1.0 / self._world())
             opt.t = t_host                                      # the capture executed nothing
-            entry = self._graphs[key] = (g_grad, g_adam, sx, sz, sr, grads, losses)
-        g_grad, g_adam, sx, sz, sr, grads, losses = entry
-        sx.copy_(X), sz.copy_(Z)
+            entry = self._graphs[key] = (g_grad, g_adam, sx, sz, sa, sr, grads, losses)
+        g_grad, g_adam, sx, sz, sa, sr, grads, losses = entry
+        sx.copy_(X), sz.copy_(Z), sa.fill_(float(alpha))
         if sr is not None:
             sr.copy_(self._mixing_r(X.shape[0]))
         g_grad.replay()

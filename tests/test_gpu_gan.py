@@ -272,18 +272,19 @@ def test_cli_train_then_predict_exports_tiffs(tmp_path):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_graphed_solver_steps_equal_eager_steps(dtype):
-    """params['graph']: the alpha == 1 solver steps replayed as hipGraphs (gradients | all-reduce | Adam) leave
-    bit-identical weights to the eager steps (same kernels, same mixing draws, device-side Adam counter)."""
+    """params['graph']: the solver steps replayed as hipGraphs (gradients | all-reduce | Adam) leave bit-identical
+    weights to the eager steps (same kernels, same mixing draws, device-side Adam counter); the fade-in alpha is a
+    device tensor, so one pair of graphs serves every alpha."""
     def run(graph):
         g = make_gan(graph=graph, dtype=dtype)
         g.set_level(1)
         rng = np.random.default_rng(12)
-        for it in range(4):
+        for it, alpha in enumerate((0.25, 0.5, 1.0, 1.0)):
             z = dev(rng.standard_normal((4, 1, 1, 512)).astype(np.float32))
             x = dev(rng.standard_normal((4, 8, 8, 2)).astype(np.float32))
-            g.d_solver(x, z, 1.0)
-            g.g_solver(x, z, 1.0)
-        g.d_solver(x, z, 0.5)                                   # a fade step in between runs eagerly either way
+            g.d_solver(x, z, alpha)
+            g.g_solver(x, z, alpha)
+        g.d_solver(x, z, 0.5)
         g.d_solver(x, z, 1.0)
         return g
     a, b = run(False), run(True)
