@@ -571,8 +571,8 @@ def main_gan(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)       # >= 20 warm-up + >= 100 timed iterations
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="--mode train / gan: compute dtype")
     ap.add_argument("--fuse-up", type=int, default=1, help="1 = convT+bridge of up0 inside its first conv (infer mode)")

@@ -10,10 +10,10 @@ cd $R
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?"
 timeout -k 10 300 python bench.py > $O/bench_infer.json 2> $O/bench_infer.err; echo "bench rc=$?"
-timeout -k 10 200 python bench.py --mode train --dtype bf16 --steps 20 --warmup 3 > $O/bench_train_bf16.json 2>/dev/null
-timeout -k 10 200 python bench.py --mode train --dtype f32 --steps 20 --warmup 3 > $O/bench_train_f32.json 2>/dev/null
-timeout -k 10 300 python bench.py --mode gan --dtype f32 --steps 5 --warmup 2 > $O/bench_gan.json 2>/dev/null
-timeout -k 10 300 python bench.py --mode gan --dtype bf16 --steps 5 --warmup 2 > $O/bench_gan_bf16.json 2>/dev/null
+timeout -k 10 200 python bench.py --mode train --dtype bf16 > $O/bench_train_bf16.json 2>/dev/null
+timeout -k 10 200 python bench.py --mode train --dtype f32 > $O/bench_train_f32.json 2>/dev/null
+timeout -k 10 300 python bench.py --mode gan --dtype f32 --steps 20 --warmup 5 > $O/bench_gan.json 2>/dev/null
+timeout -k 10 300 python bench.py --mode gan --dtype bf16 --steps 20 --warmup 5 > $O/bench_gan_bf16.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_infer -- python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-end-to-end > $O/prof_infer.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gan_bf16 -- python $R/bench.py --mode gan --dtype bf16 --steps 5 --warmup 2 > $O/prof_gan_bf16.log 2>&1
