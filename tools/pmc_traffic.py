@@ -47,7 +47,7 @@ def main():
     a = ap.parse_args()
     fe, wr = load(a.fetch_csv, "FETCH_SIZE"), load(a.write_csv, "WRITE_SIZE")
     out = {}
-    tot_b, tot_l = 0.0, 0
+    tot_b, tot_l, tot_raw = 0.0, 0, 0.0
     for k in sorted(set(fe) | set(wr)):
         nf, f = fe.get(k, (0, 0.0))
         nw, w = wr.get(k, (0, 0.0))
@@ -60,6 +60,7 @@ def main():
         if re.search(a.kernel_regex, k):
             tot_b += b * n
             tot_l += n
+            tot_raw += (fk + wk) * 1024.0 * n
     out["_summary"] = {
         "command": a.command,
         "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts half of a wide "
@@ -69,6 +70,11 @@ def main():
         "conv_mfma_hbm_bytes_per_step": tot_b / float(a.steps),
         "conv_mfma_hbm_bytes_per_launch_avg": tot_b / max(1, tot_l),
         "conv_mfma_algorithmic_bytes_per_step": a.algorithmic_bytes_per_step,
+        "conv_mfma_hbm_bytes_per_step_uncorrected": tot_raw / float(a.steps),
+        "note": "the x2 rule holds for 128-byte requests (the level-0 kernels: 64-byte pixels in contiguous rows); the "
+                "16-channel chunk loads of the C >= 32 layers are 64-byte pieces at a 128+ byte stride, which FETCH_SIZE "
+                "tallies exactly -- for those launches the corrected figure is an upper bound and the uncorrected one is "
+                "the better estimate (DESIGN 4a)",
     }
     json.dump(out, sys.stdout, indent=1)
 
