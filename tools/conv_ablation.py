@@ -27,7 +27,7 @@ VARIANTS = {
 }
 VARIANTS["noload_nostore"] = VARIANTS["nostore"] + VARIANTS["noload"]
 VARIANTS["store_lane_order"] = [("#define SQ_STORE_PERMUTE 0", "#define SQ_STORE_PERMUTE 1")]
-VARIANTS["tiles_interleaved"] = [("#define SQ_TILE_INTERLEAVE 0", "#define SQ_TILE_INTERLEAVE 1")]
+VARIANTS["tiles_contiguous"] = [("#define SQ_TILE_INTERLEAVE 1", "#define SQ_TILE_INTERLEAVE 0")]
 # convoy hypothesis: persistent blocks that share a CU start together and stay in phase (all staging, then all
 # MFMA); delay residency slot s by s * k * 64 clocks so their phases interleave
 for _k in (24, 48, 96):
