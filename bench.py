@@ -522,7 +522,8 @@ def main_gan(args):
     nb, level = 32, 6
     g = GenerativeAdverserialNetwork({"num_levels": 7, "batch_size": nb, "repeat_batch": 1, "learning_rate": 1e-3,
                                       "device": str(dev), "seed": 0, "dtype": args.dtype,
-                                      "graph": bool(args.graph)}, mode=None)
+                                      "graph": bool(args.graph),
+                                      "batch_d": os.environ.get("SQ_GAN_BATCH_D", "1") != "0"}, mode=None)
     g.build()
     g.set_level(level)
     rng = np.random.default_rng(3 + rank)

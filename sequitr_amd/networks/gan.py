@@ -104,16 +104,21 @@ def dense(inputs, units, activation=None, name='dense'):
     return y.reshape(tuple(lead) + (units,))
 
 
-def minibatch_stdev(x):
+def minibatch_stdev(x, groups=1):
     """gan.py:204-212: sqrt(mean over (h,w,c) of the population variance over the batch), as a
-    constant feature map (N,4,4,1).  0.26 M elements: torch tensor ops (differentiable twice)."""
-    var = x.var(dim=0, unbiased=False).mean()
-    stdev = torch.sqrt(var)
-    return torch.ones((x.shape[0], 4, 4, 1), dtype=torch.float32, device=x.device) * stdev
+    constant feature map (N,4,4,1).  0.26 M elements: torch tensor ops (differentiable twice).
+    groups > 1: x is `groups` minibatches stacked along the batch axis, each gets its own statistic
+    (the reference evaluates the discriminator once per minibatch; see _build_network)."""
+    n = x.shape[0] // groups
+    xg = x.reshape((groups, n) + tuple(x.shape[1:]))
+    var = xg.var(dim=1, unbiased=False).reshape(groups, -1).mean(dim=1)
+    stdev = torch.sqrt(var).reshape(groups, 1, 1, 1, 1)
+    return (torch.ones((groups, n, 4, 4, 1), dtype=torch.float32, device=x.device) * stdev).reshape(x.shape[0], 4, 4, 1)
 
 
-def discriminator_network(x, filters):
-    """gan.py:149-240.  Returns (conv_layers, logits (N,))."""
+def discriminator_network(x, filters, groups=1):
+    """gan.py:149-240.  Returns (conv_layers, logits (N,)).  groups: number of minibatches stacked in x (every
+    layer but the minibatch statistic is per sample)."""
     num_layers = len(filters)
     with variable_scope("from_image"):
         x = from_image(x, filters=filters[0], n=num_layers - 1)
@@ -127,7 +132,7 @@ def discriminator_network(x, filters):
             conv_layers.append(F.avgpool2x2(conv2))
     x = conv_layers[-1]
     with variable_scope('output'):
-        mbstd = minibatch_stdev(x)
+        mbstd = minibatch_stdev(x, groups)
         conv = weighted_conv2d(inputs=x, filters=filters[-1], kernel_size=[3, 3],
                                activation=k_leaky_relu_alpha, name='conv', norm=False)
         conv = torch.cat([conv, mbstd], dim=-1)
@@ -214,7 +219,8 @@ class GenerativeAdverserialNetwork(object):
     training_data (``.npy`` (N,H,W,C) stack; None -> synthetic tiles), learning_rate; new keys:
     device, seed, num_batches_per_epoch (when the data is synthetic), dtype ('f32' default: exact-f32 MFMA
     convolutions; 'bf16': the f32 graph with bf16-multiply / f32-accumulate convolutions, BASELINE config 5),
-    graph (default False: True replays the solver steps as hipGraphs)."""
+    graph (default False: True replays the solver steps as hipGraphs), batch_d (default True: the discriminator sees
+    the generated and the real minibatch as one stacked batch, each with its own minibatch statistic)."""
 
     def __init__(self, params, mode=None, discriminator_fn=discriminator_network,
                  generator_fn=generator_network):
@@ -229,6 +235,8 @@ class GenerativeAdverserialNetwork(object):
         self.start_size = params.get('start_size', (4, 4))
         self.training_data_filename = params.get('training_data', None)
         self.learning_rate = params.get('learning_rate', 1e-3)
+        self.batch_d = bool(params.get('batch_d', True))     # D(Gz) and D(X) in one stacked pass (default discriminator only)
+        self._default_d = discriminator_fn is discriminator_network
         self.use_graph = bool(params.get('graph', False))    # replay the solver steps as hipGraphs
         self._graphs = {}
         self._capture_stream = None
@@ -374,8 +382,15 @@ class GenerativeAdverserialNetwork(object):
         autograd graph attached (d_loss w.r.t. the discriminator, g_loss w.r.t. the generator
         unless need_g_graph is False -- the discriminator step never needs it)."""
         d_filters, Gz_raw, Gz, X_resized = self._prepare(X, Z, alpha, need_g_graph=need_g_graph)
-        _, Dz = self.discriminator(Gz, d_filters)
-        _, Dx = self.discriminator(X_resized, d_filters)
+        if self.batch_d and self._default_d:
+            # D(Gz) and D(X) as ONE pass over the stacked minibatches (own minibatch statistic each): the same
+            # per-sample arithmetic, a third fewer launches of the small deep layers in forward and backward
+            n = Gz.shape[0]
+            _, Dzx = self.discriminator(torch.cat([Gz, X_resized], 0), d_filters, groups=2)
+            Dz, Dx = Dzx[:n], Dzx[n:]
+        else:
+            _, Dz = self.discriminator(Gz, d_filters)
+            _, Dx = self.discriminator(X_resized, d_filters)
         if r is None:
             r = self._mixing_r(X.shape[0])
         mix = F.lerp(X_resized, Gz.detach(), r).detach().requires_grad_(True)

@@ -309,3 +309,31 @@ def test_training_loop_with_graph_replay_across_levels(tmp_path):
     assert sorted(os.listdir(str(tmp_path / "o"))) == ["model_(16x16).npz", "model_(4x4).npz", "model_(8x8).npz"]
     w = g.store.state_dict()
     assert all(np.isfinite(v).all() for v in w.values())
+
+
+@pytest.mark.parametrize("level,alpha", [(0, 1.0), (2, 0.6)])
+def test_stacked_discriminator_pass_equals_separate_passes(level, alpha):
+    """params['batch_d']: D(Gz) and D(X) as one pass over the stacked minibatches, each with its own minibatch
+    statistic: the same per-sample arithmetic (losses to f32 rounding), gradients equal up to summation order."""
+    res = {}
+    for bd in (True, False):
+        g = make_gan(batch_d=bd)
+        g.set_level(level)
+        rng = np.random.default_rng(2)
+        z = rng.standard_normal((4, 1, 1, 512)).astype(np.float32)
+        x = rng.standard_normal((4,) + g.get_size(level) + (2,)).astype(np.float32)
+        r = rng.random(4).astype(np.float32)
+        _, d_loss, g_loss = g._build_network(dev(x), dev(z), alpha, r=dev(r))
+        d_vars, g_vars = g.get_training_variables(level)
+        dg = torch.autograd.grad(d_loss, [v for _, v in d_vars], retain_graph=True, allow_unused=True)
+        gg = torch.autograd.grad(g_loss, [v for _, v in g_vars], allow_unused=True)
+        res[bd] = (d_loss.item(), g_loss.item(), [t.cpu().numpy() for t in dg], [t.cpu().numpy() for t in gg])
+    a, b = res[True], res[False]
+    assert abs(a[0] - b[0]) <= 1e-5 * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 1e-5 * max(1.0, abs(b[1]))
+    for u, v in zip(a[2] + a[3], b[2] + b[3]):
+        close(u, v, 5e-4, "gradient, stacked vs separate")     # f32 sums in another order (vs fp64: 2e-3 for either)
+    # the minibatch statistic is per group, not over the stacked batch
+    feat = torch.randn(8, 4, 4, 16, device="cuda:0")
+    m = gan.minibatch_stdev(feat, groups=2)
+    assert torch.allclose(m[:4], gan.minibatch_stdev(feat[:4])) and torch.allclose(m[4:], gan.minibatch_stdev(feat[4:]))
+    assert not torch.allclose(m[:4], gan.minibatch_stdev(feat)[:4])
