@@ -395,6 +395,10 @@ int sq_dropout_bwd_bf16(const void *dy, const uint8_t *mask, void *dx, int64_t n
  * Cin % 32 == 0, Cout % 16 == 0.  The up-scaled value is rounded to bf16 before the bridge. */
 int sq_convT2x2s2_nhwc_fwd_bf16(const void *x, const void *w, const float *bias, const void *skip, void *y,
                                 int N, int H, int W, int Cin, int Cout, int bridge, void *stream);
+/* training form of the decoder junction (unet.py:312-319): one pass writes the up-scaled tensor `up` (kept for the
+ * bridge backward) AND merged = bridge(up, skip); same bits as sq_convT2x2s2_nhwc_fwd_bf16 + sq_bridge_fwd_bf16. */
+int sq_convT2x2s2_bridge_both_fwd_bf16(const void *x, const void *w, const float *bias, const void *skip, void *up,
+                                       void *merged, int N, int H, int W, int Cin, int Cout, int bridge, void *stream);
 
 /* to_image head on a bf16 activation: f32 (Cin,Cout<=4) weights, f32 logits + uint8 mask (may be NULL);
  * backward: dz f32 -> dx bf16 (may be NULL), dw (Cin,Cout) f32, db f32; Cin in {16,32}, Cout <= 2. */

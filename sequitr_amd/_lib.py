@@ -111,6 +111,7 @@ SIGNATURES = {
     "sq_dropout_fwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_float, ctypes.c_uint32, c_int, c_void_p, c_void_p]),
     "sq_dropout_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_float, c_void_p]),
     "sq_convT2x2s2_nhwc_fwd_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "sq_convT2x2s2_bridge_both_fwd_bf16": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     "sq_conv1x1_head_fwd_bf16": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
     "sq_conv1x1_head_bwd_workspace_bf16": (c_int64, [c_int64, c_int, c_int]),
     "sq_conv1x1_head_bwd_bf16": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]),

@@ -304,7 +304,7 @@ constexpr int CT_ROWB = 96;                                   // 64 B of data + 
 __global__ __launch_bounds__(256) void convT_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
                                                           const float *__restrict__ bias, const __bf16 *__restrict__ skip,
                                                           __bf16 *__restrict__ y, int64_t P, int H, int W, int Cin, int Cout,
-                                                          int bridge) {
+                                                          int bridge, __bf16 *__restrict__ up_out) {
     __shared__ __attribute__((aligned(16))) unsigned char as[64 * CT_ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char xs[64 * CT_ROWB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -345,6 +345,8 @@ __global__ __launch_bounds__(256) void convT_bf16_kernel(const __bf16 *__restric
         const int64_t n = t / H;
         const size_t off = ((size_t)(n * 2 * H + 2 * i + a2) * (2 * W) + 2 * j + b2) * Cout + o;
         float v[4] = {acc[cb][0] + bv.x, acc[cb][1] + bv.y, acc[cb][2] + bv.z, acc[cb][3] + bv.w};
+        if (up_out)                                               // training keeps the up-scaled tensor for the bridge backward
+            *reinterpret_cast<bf16x4 *>(up_out + off) = (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
         if (bridge != SQ_BRIDGE_NONE) {
             const bf16x4 k = *reinterpret_cast<const bf16x4 *>(skip + off);
 #pragma unroll
@@ -604,8 +606,25 @@ extern "C" int sq_convT2x2s2_nhwc_fwd_bf16(const void *x, const void *w, const f
     const int64_t P = (int64_t)N * H * W;
     dim3 grid((unsigned)((P + 63) / 64), (unsigned)(4 * Cout / 64));
     hipLaunchKernelGGL(convT_bf16_kernel, grid, dim3(256), 0, SQ_ST(stream), BF(x), BF(w), bias, BF(skip), BFM(y), P, H, W,
-                       Cin, Cout, bridge);
+                       Cin, Cout, bridge, (__bf16 *)nullptr);
     return sq_check_launch("sq_convT2x2s2_nhwc_fwd_bf16");
+}
+
+// the training form: writes BOTH the up-scaled tensor (needed by the bridge backward) and bridge(up, skip) from one
+// pass -- the separate bridge kernel's re-read of `up` and its launch disappear; same bits as the two kernels
+extern "C" int sq_convT2x2s2_bridge_both_fwd_bf16(const void *x, const void *w, const float *bias, const void *skip,
+                                                  void *up, void *merged, int N, int H, int W, int Cin, int Cout,
+                                                  int bridge, void *stream) {
+    SQ_REQUIRE(x && w && skip && up && merged, "sq_convT2x2s2_bridge_both_fwd_bf16: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cin > 0 && Cout % 16 == 0 && Cout > 0,
+               "sq_convT2x2s2_bridge_both_fwd_bf16: Cin=%d (multiple of 32), Cout=%d (multiple of 16)", Cin, Cout);
+    SQ_REQUIRE(bridge > SQ_BRIDGE_NONE && bridge <= SQ_BRIDGE_SUB, "sq_convT2x2s2_bridge_both_fwd_bf16: bad bridge %d", bridge);
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(w); SQ_REQUIRE_ALIGNED(up); SQ_REQUIRE_ALIGNED(merged); SQ_REQUIRE_ALIGNED(skip);
+    const int64_t P = (int64_t)N * H * W;
+    dim3 grid((unsigned)((P + 63) / 64), (unsigned)(4 * Cout / 64));
+    hipLaunchKernelGGL(convT_bf16_kernel, grid, dim3(256), 0, SQ_ST(stream), BF(x), BF(w), bias, BF(skip), BFM(merged), P, H,
+                       W, Cin, Cout, bridge, BFM(up));
+    return sq_check_launch("sq_convT2x2s2_bridge_both_fwd_bf16");
 }
 
 extern "C" int sq_conv1x1_head_fwd_bf16(const void *x, const float *w, const float *bias, float *logits, uint8_t *mask,

@@ -148,6 +148,9 @@ def maxpool2x2(x, box=None):
     return _MaxPool.apply(x, box)
 
 
+_UPJ_BOTH = __import__("os").environ.get("SQ_UPJ_BOTH", "1") != "0"   # A/B: dual-output convT+bridge kernel
+
+
 class _UpJunction(torch.autograd.Function):
     """conv_transpose_layer + bridge of a decoder level (unet.py:312-319) as one tape entry: the forward is
     the two kernels as before; the backward produces d_up directly in the space-to-depth layout the
@@ -156,8 +159,13 @@ class _UpJunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, skip, kind, box):
-        up = ob.convT2x2s2(x, ob.to_bf16(w), bias)
-        merged = ob.bridge(up, skip, kind)
+        if kind == 'eltwise_mul' and _UPJ_BOTH:                 # `up` is needed by the backward: both from one pass
+            up, merged = ob.convT2x2s2_bridge_both(x, ob.to_bf16(w), bias, skip, kind)
+        elif kind == 'eltwise_mul':
+            up = ob.convT2x2s2(x, ob.to_bf16(w), bias)
+            merged = ob.bridge(up, skip, kind)
+        else:                                                   # add / sub: the up-scaled tensor is not kept at all
+            up, merged = None, ob.convT2x2s2(x, ob.to_bf16(w), bias, skip, kind)
         keep = kind == 'eltwise_mul'
         ctx.save_for_backward(x, w, up if keep else None, skip if keep else None)
         ctx.kind, ctx.box, ctx.has_bias = kind, box, bias is not None

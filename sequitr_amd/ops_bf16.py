@@ -295,6 +295,22 @@ def convT2x2s2(x, w_bf16, bias, skip=None, bridge_kind=None):
     return y
 
 
+def convT2x2s2_bridge_both(x, w_bf16, bias, skip, bridge_kind):
+    """(up, merged = bridge(up, skip)) of a decoder junction from one pass; same bits as convT2x2s2 + bridge."""
+    _chk(x, "x", ndim=4), _chk(w_bf16, "w", ndim=4), _chk(skip, "skip", ndim=4)
+    N, H, W, Cin = x.shape
+    Cout = w_bf16.shape[2]
+    if tuple(skip.shape) != (N, 2 * H, 2 * W, Cout):
+        raise ValueError("skip has shape %s, expected %s" % (tuple(skip.shape), (N, 2 * H, 2 * W, Cout)))
+    up = torch.empty((N, 2 * H, 2 * W, Cout), dtype=BF16, device=x.device)
+    merged = torch.empty_like(up)
+    lib = _lib.load()
+    _lib.check(lib.sq_convT2x2s2_bridge_both_fwd_bf16(_ptr(x), _ptr(w_bf16), _ptr(bias), _ptr(skip), _ptr(up), _ptr(merged),
+                                                     N, H, W, Cin, Cout, BRIDGE[bridge_kind], _stream()),
+               "sq_convT2x2s2_bridge_both_fwd_bf16")
+    return up, merged
+
+
 def bridge_bwd_s2d(dy, up, skip, kind):
     """(g (N,H,W,4C) = d_up in space-to-depth layout, dskip) of merged = bridge(up, skip); dy (N,2H,2W,C)."""
     _chk(dy, "dy", ndim=4)

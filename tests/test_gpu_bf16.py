@@ -308,3 +308,16 @@ def test_bf16_training_other_configurations_match_the_emulation(cfg):
     num = sum(float((g[k].astype(np.float64) * rgrads[k]).sum()) for k in rgrads)
     den = np.sqrt(sum(float((g[k].astype(np.float64) ** 2).sum()) for k in rgrads) * sum(float((rgrads[k] ** 2).sum()) for k in rgrads))
     assert num / den > 0.97, num / den
+
+
+@pytest.mark.parametrize("kind", ["eltwise_mul", "eltwise_add", "eltwise_sub"])
+def test_convT_bridge_dual_output_equals_the_two_kernels(kind):
+    """sq_convT2x2s2_bridge_both_fwd_bf16 (training form of the decoder junction): up and merged from one pass,
+    bit-identical to convT followed by the bridge kernel."""
+    x, skip = tiles(31, 2, 12, 20, 64), tiles(32, 2, 24, 40, 32)
+    w, b = rand_weights(33, (2, 2, 32, 64), 0.2), rand_weights(34, (32,), 0.1)
+    wb = dev(w).to(torch.bfloat16)
+    up_ref = ob.convT2x2s2(dev(x, torch.bfloat16), wb, dev(b))
+    merged_ref = ob.bridge(up_ref, dev(skip, torch.bfloat16), kind)
+    up, merged = ob.convT2x2s2_bridge_both(dev(x, torch.bfloat16), wb, dev(b), dev(skip, torch.bfloat16), kind)
+    assert torch.equal(up, up_ref) and torch.equal(merged, merged_ref)
