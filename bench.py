@@ -32,6 +32,19 @@ BATCH = 32
 FILTERS = (16, 32, 64, 128, 256)
 
 
+def init_ranks(dist, local_rank):
+    """one process per GPU over RCCL (torch's "nccl" backend).  SQ_BENCH_BACKEND=gloo is the rehearsal mode for a
+    one-GPU box: every rank uses GPU 0 and gloo carries the (tiny) collectives of the harness -- it exercises the
+    N > 1 control flow (barriers, max-over-ranks time, rank-0 line), not the interconnect."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("SQ_BENCH_BACKEND", "nccl") == "gloo":
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+
 def mfma_conv_flops(n, h, w, cin, cout, k):
     return 2.0 * n * h * w * cin * cout * k * k
 
@@ -250,9 +263,7 @@ def main_train(args):
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        init_ranks(dist, local_rank)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -512,9 +523,7 @@ def main_gan(args):
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        init_ranks(dist, local_rank)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -603,9 +612,7 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        init_ranks(dist, local_rank)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
