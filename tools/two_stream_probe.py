@@ -56,3 +56,44 @@ for parts in (2, 4):
     assert torch.equal(torch.cat(outs), ref)
     print("%d streams, %d tiles each: %.3f ms" % (parts, 32 // parts, timed(run)), flush=True)
     print("%d sequential parts on one stream: %.3f ms" % (parts, timed(lambda: [n.predict(c) for n, c in zip(nets, chunks)])), flush=True)
+
+# free-running: each stream loops over its own part without a join per step (as two processes on one GPU do)
+for parts in (2, 4):
+    nets = [make() for _ in range(parts)]
+    streams = [torch.cuda.Stream() for _ in range(parts)]
+    chunks = [c.contiguous() for c in torch.chunk(x, parts)]
+
+    def run_free(reps):
+        main = torch.cuda.current_stream()
+        for s in streams:
+            s.wait_stream(main)
+        for _ in range(reps):
+            for n, s, c in zip(nets, streams, chunks):
+                with torch.cuda.stream(s):
+                    n.predict(c)
+        for s in streams:
+            main.wait_stream(s)
+    run_free(10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_free(40)
+    torch.cuda.synchronize()
+    print("%d free-running streams, %d tiles each: %.3f ms per 32 tiles" % (parts, 32 // parts, (time.perf_counter() - t0) / 40 * 1e3), flush=True)
+# two full batches in flight (the same batch size per launch as the headline, twice the tiles in flight)
+nets = [make() for _ in range(2)]
+streams = [torch.cuda.Stream() for _ in range(2)]
+main = torch.cuda.current_stream()
+for k in (10, 40):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in streams:
+        s.wait_stream(main)
+    for _ in range(k):
+        for n, s in zip(nets, streams):
+            with torch.cuda.stream(s):
+                n.predict(x)
+    for s in streams:
+        main.wait_stream(s)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (2 * k) * 1e3
+print("2 free-running streams, 32 tiles each: %.3f ms per 32 tiles" % dt, flush=True)
