@@ -17,6 +17,10 @@
 // LDS, and the f32 accumulators are stored as f32 -- bf16 multiply / f32 accumulate behind an f32 graph (the GAN
 // of BASELINE config 5, whose double-backward graph is built from f32 ops).
 #include "sq_common.h"
+
+#ifndef SQ_FIRST_UNROLL
+#define SQ_FIRST_UNROLL 0      // 1: the single-channel first conv keeps its 144 weights in registers (155 VGPRs, occupancy 3)
+#endif
 #include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
     float a[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) a[o] = 0.f;
-    constexpr int TAP_UNROLL = CIN == 1 ? 9 : 1;                // multi-channel: rolled taps keep the filter out of registers
+    constexpr int TAP_UNROLL = (CIN == 1 && SQ_FIRST_UNROLL) ? 9 : 1;   // rolled taps keep the filter out of registers
 #pragma unroll TAP_UNROLL
     for (int t = 0; t < 9; ++t) {
 #pragma unroll

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_direct_f32_kernel(
     for (int o = 0; o < 16; ++o) acc[o] = 0.f;
     // more than 9 filter rows: keep the tap loops rolled, or the compiler hoists every (wave-uniform) weight read
     // into registers and spills
-    constexpr int TAP_UNROLL = KS * KS * CIN <= 9 ? KS : 1;
+    constexpr int TAP_UNROLL = KS * KS * CIN <= 4 ? KS : 1;      // (the 9-row single-channel filter too: 155 -> 38 VGPRs)
 #pragma unroll TAP_UNROLL
     for (int ky = 0; ky < KS; ++ky)
 #pragma unroll TAP_UNROLL
