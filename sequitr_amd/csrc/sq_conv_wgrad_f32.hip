@@ -13,6 +13,7 @@
 // by a second kernel that adds the block partials IN A FIXED ORDER: no float atomics, results
 // are run-to-run reproducible (MI355X_MICROARCH.md "Global float atomics").
 #include "sq_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -389,7 +390,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_cin1_finish_kernel(const float
 
 int cin1_grid(int N, int H, int W, int *tpb_out) {
     const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * N;
-    int tpb = (ntiles + 1023) / 1024;
+    // the kernel is single-buffered (load, barrier, 16 MFMAs, barrier): it hides latency only through resident blocks,
+    // so the grid fills the block slots of every CU (2048 blocks: -0.5 % on the bf16 step vs 1024, within noise of 4096)
+    static const int target = [] { const char *e = getenv("SQ_CIN1_BLOCKS"); return e ? atoi(e) : 2048; }();
+    int tpb = (ntiles + target - 1) / target;
     if (tpb < 1) tpb = 1;
     if (tpb_out) *tpb_out = tpb;
     return (ntiles + tpb - 1) / tpb;
