@@ -157,6 +157,21 @@ def pmc_traffic_per_launch():
         return None
 
 
+def pmc_mfma_busy():
+    """MFMA-pipe busy fraction per conv kernel from the committed SQ counter passes (tools/pmc_sq.sh +
+    tools/pmc_sq_summary.py: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)); None if absent.  It counts
+    every MFMA issued, including the recomputed halos of the fused forms, so it sits above `frac`."""
+    import glob
+    try:
+        fn = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_summary.json")))[-1]
+        with open(fn) as f:
+            d = json.load(f)
+        return {k.replace("conv_mfma_f32_v2_kernel", "v2"): v["mfma_busy_frac"] for k, v in d.items()
+                if "mfma_busy_frac" in v and k.startswith("conv_mfma_f32_v2")}
+    except Exception:
+        return None
+
+
 def iou_per_class(a, b, nclass=2):
     out = []
     for c in range(nclass):
@@ -680,6 +695,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": pmc_traffic_per_launch(),
+                "mfma_busy_pmc": pmc_mfma_busy(),
                 "launches_per_step": nlaunch // max(1, args.steps),
                 "kernel_ms_per_step": round(conv_ms / max(1, args.steps), 4),
                 "flops_per_step": conv_flops / max(1, args.steps),
