@@ -21,3 +21,6 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/pmc_write.log 2>&1
 find $O -name "*kernel_trace.csv" -delete
 ls $O
+# SQ counters (MFMA-pipe busy per kernel): four more --pmc passes, summarised by tools/pmc_sq_summary.py
+cd $R && bash tools/pmc_sq.sh ${TAG}_sq --no-end-to-end > $O/pmc_sq.log 2>&1 && python tools/pmc_sq_summary.py $R/gpurun_out/${TAG}_sq > $O/pmc_sq_summary.json
+ls $O
