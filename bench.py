@@ -45,6 +45,74 @@ def init_ranks(dist, local_rank):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
 
+def rank_setup():
+    """(world, rank, dist-or-None, device) from the RANK / LOCAL_RANK / WORLD_SIZE the launcher (torch.distributed.run or
+    launch_ranks below) put in the environment; initialises the process group when world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        init_ranks(dist, local_rank)
+    else:
+        torch.cuda.set_device(0)
+    return world, rank, dist, torch.device("cuda", torch.cuda.current_device())
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, and relay rank 0's single JSON line.  The parent never touches the
+    GPU (no torch.cuda call has run: `import torch` does not initialise HIP) and never re-execs itself; any failed
+    child makes the exit code non-zero and ends the others (by PID)."""
+    import socket
+    import subprocess
+    gloo = os.environ.get("SQ_BENCH_BACKEND", "nccl") == "gloo"
+    have = torch.cuda.device_count()                    # counts devices without initialising the runtime
+    if not gloo and have < n:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (SQ_BENCH_BACKEND=gloo rehearses the N-rank "
+                         "control flow on one card)\n" % (n, have))
+        return 2
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()                                      # drain rank 0's pipe while polling every child
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in procs:                         # one rank died: the others would wait in a barrier for ever
+                    if q.poll() is None:
+                        q.terminate()
+        time.sleep(0.05)
+    reader.join(10)
+    out0 = buf[0] if buf else ""
+    lines = [l for l in (out0 or "").splitlines() if l.strip()]
+    if rc == 0 and lines:
+        print(lines[-1])
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: rank 0 printed no line\n")
+        rc = 1
+    return rc
+
+
 def mfma_conv_flops(n, h, w, cin, cout, k):
     return 2.0 * n * h * w * cin * cout * k * k
 
@@ -238,60 +306,189 @@ def end_to_end_rate(net, x_dev, iters=5):
                     "predict / download on three streams, double-buffered; serial: the same on one stream"}
 
 
-def cpu_baseline(weights, params, budget_s=20.0, gpu_net=None):
-    """Bounded CPU sample: time the torch-CPU (oneDNN, fp32, channels_last) restatement on a
-    few tiles of the same workload; never the thing shipped, only the reported baseline."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def timed_passes(fn, warm=3, timed=10, budget_s=12.0):
+    """>= `warm` warm-up and `timed` timed passes; the timed count shrinks only when one pass
+    is so slow that `timed` of them would exceed the budget.  Returns (times, n_warm)."""
+    for _ in range(warm):
+        t0 = time.perf_counter()
+        fn()
+        one = time.perf_counter() - t0
+    n = int(max(3, min(timed, budget_s / max(one, 1e-4))))
+    times = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    return times, warm
+
+
+def cpu_baseline(weights, params, gpu_net=None):
+    """Bounded CPU sample as BASELINE.md section 3 prescribes: the torch-CPU (oneDNN, fp32, channels_last) restatement
+    of the same net on tiles of the same workload, batch 1 and batch 8, 3 warm-up + 10 timed passes each, median /
+    min / max, CPU model and thread count stated.  Never the thing shipped, only the reported baseline."""
     from oracle.torch_ref import TorchCpuUNet
     # a 1-GPU box owns a 16-core share of the host (more threads only thrash the cgroup)
     threads = int(os.environ.get("SQ_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     net = TorchCpuUNet(weights, params, threads=threads)
-    x1 = np.random.default_rng(1).standard_normal((1, TILE, TILE, 1)).astype(np.float32)
-    net(x1)                                            # warm-up (oneDNN primitive creation)
-    t0 = time.perf_counter()
-    net(x1)
-    t1 = time.perf_counter() - t0
-    nt = int(max(1, min(8, budget_s / max(t1, 1e-3) / 3)))
-    xb = np.random.default_rng(1).standard_normal((nt, TILE, TILE, 1)).astype(np.float32)
-    times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        net(xb)
-        times.append(time.perf_counter() - t0)
-    best = min(times)
-    iou = None
+    xb = np.random.default_rng(1).standard_normal((8, TILE, TILE, 1)).astype(np.float32)
+    rows = {}
+    for nb in (1, 8):
+        xin = xb[:nb]
+        times, warm = timed_passes(lambda: net(xin))
+        rate = [nb * TILE * TILE / t / 1e6 for t in times]
+        rows["batch_%d" % nb] = {"median": round(float(np.median(rate)), 3), "min": round(min(rate), 3),
+                                 "max": round(max(rate), 3), "warmup": warm, "timed": len(times)}
+    iou = near = None
     if gpu_net is not None:                       # matched-IoU check of the timed GPU net against this CPU run
-        cpu_mask = np.argmax(net(xb), axis=-1).astype(np.uint8)
+        cpu_logits = net(xb)
+        cpu_mask = np.argmax(cpu_logits, axis=-1).astype(np.uint8)
         gpu_mask = gpu_net.predict(torch.from_numpy(xb).to(gpu_net.device)).cpu().numpy()
         iou = [round(v, 6) for v in iou_per_class(gpu_mask, cpu_mask, gpu_net.n_outputs)]
-    return {"value": round(nt * TILE * TILE / best / 1e6, 3), "unit": "Mpixels/s", "cores": net.threads,
-            "kind": "port", "iou_gpu_vs_cpu_per_class": iou,
-            "sample": "torch-CPU oneDNN fp32 restatement of the same U-Net (oracle/torch_ref.py), "
-                      "%d x 512x512 tiles per pass, best of 3 passes, %d threads; stands in for the "
-                      "reference TF-CPU path (TensorFlow not installable)" % (nt, net.threads)}
+        near = int((gpu_mask != cpu_mask).sum())
+    best = rows["batch_8"]
+    return {"value": best["median"], "unit": "Mpixels/s", "cores": net.threads, "kind": "port",
+            "cpu_model": cpu_model_name(), "os_cpu_count": os.cpu_count(), "passes": rows,
+            "iou_gpu_vs_cpu_per_class": iou, "pixels_differing_gpu_vs_cpu": near,
+            "sample": "CPU restatement (torch-oneDNN fp32 channels_last, oracle/torch_ref.py) of the same U-Net, standing "
+                      "in for the reference TF-CPU path (TensorFlow not installable); value = median over %d timed "
+                      "passes of 8 x 512x512 tiles after 3 warm-up passes, %d threads; batch 1 beside it"
+                      % (best["timed"], net.threads)}
+
+
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+PEAK_HBM_GBS = 8000.0             # HBM3E spec, MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def unet_work_per_tile(filters=FILTERS, tile=TILE, nout=2):
+    """SURVEY A.6 per 512x512 tile: (forward FLOPs, forward layer-by-layer activation elements read + written,
+    first-layer MACs).  Training FLOPs = 3 x forward - the first layer's dgrad (its input needs no gradient)."""
+    flops, elems, cin = 0.0, 0, 1
+    first = None
+    for i, c in enumerate(filters):                                         # encoder
+        h = tile >> i
+        if i > 0:
+            elems += (2 * h) * (2 * h) * cin + h * h * cin                  # pool: read + write
+        for ci in (cin, c):
+            f = mfma_conv_flops(1, h, h, ci, c, 3)
+            first = f if first is None else first
+            flops += f
+            elems += h * h * (ci + c)
+        cin = c
+    for i in reversed(range(len(filters) - 1)):                             # decoder
+        h, c, c2 = tile >> i, filters[i], filters[i + 1]
+        flops += 2.0 * (h // 2) * (h // 2) * 4 * c2 * c
+        elems += (h // 2) * (h // 2) * c2 + h * h * c                       # transpose conv
+        elems += 3 * h * h * c                                              # bridge: two reads + write
+        flops += 2 * mfma_conv_flops(1, h, h, c, c, 3)
+        elems += 2 * h * h * 2 * c
+    flops += mfma_conv_flops(1, tile, tile, filters[0], nout, 1)
+    elems += tile * tile * (filters[0] + nout)
+    return flops, elems, first
+
+
+def disk_labels(rng, n, tile=TILE, disks=60):
+    """config 3's label definition: the union of 60 random disks of radius 6-15 px per tile"""
+    yy, xx = np.mgrid[0:tile, 0:tile]
+    lab = np.zeros((n, tile, tile), np.bool_)
+    for i in range(n):
+        for _ in range(disks):
+            cy, cx, r = rng.integers(0, tile), rng.integers(0, tile), rng.integers(6, 16)
+            lab[i] |= (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+    return lab
+
+
+def config3_inputs(dev, seed=2, nb=16, tile=TILE):
+    """BASELINE config 3's tensors on the device: tiles default_rng(seed).standard_normal, labels = 60 random disks
+    per tile as one-hot uint8 (N,H,W,2), weights = ImageWeightMap(w0=10, sigma=5) of the label (sequitr/pipeline.py:
+    455-479) computed on the GPU by sq_weightmap_edt_f32 and left there, float32 (N,H,W,1), range [1, ~11]."""
+    from sequitr_amd.weightmap import device_weightmaps
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal((nb, tile, tile, 1)).astype(np.float32)).to(dev)
+    lab = disk_labels(rng, nb, tile)
+    onehot = torch.from_numpy(np.stack([~lab, lab], -1).astype(np.uint8)).to(dev)
+    wmap = device_weightmaps(lab.astype(np.float32), 10., 5., device=dev)
+    return x, onehot, wmap
+
+
+def pmc_step_traffic(tag):
+    """HBM bytes per step from the committed rocprofv3 PMC passes of this mode (profiles/r*_pmc_<tag>_traffic.json:
+    FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of the step; separate passes), with its source file; or None."""
+    import glob
+    try:
+        fn = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_traffic.json" % tag)))[-1]
+        with open(fn) as f:
+            return round(json.load(f)["_summary"]["hbm_bytes_per_step"], 1), os.path.relpath(fn, ROOT)
+    except Exception:
+        return None, None
+
+
+def cpu_baseline_train(params, x, onehot, wmap):
+    """CPU leg of the training line: fp32 torch-CPU autograd of the same graph (oracle/torch_ref.py
+    unet_loss_and_grads: forward + weighted softmax-CE + backward) + a numpy Adam update, on 2 of the 16 tiles."""
+    from oracle import torch_ref
+    from sequitr_amd.networks.unet import init_unet_weights
+    threads = int(os.environ.get("SQ_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+    torch.set_num_threads(threads)
+    w = init_unet_weights(params, seed=0)
+    m = {k: np.zeros_like(v) for k, v in w.items()}
+    v2 = {k: np.zeros_like(v) for k, v in w.items()}
+    nt = 2
+    xs, os_, ws = x[:nt].cpu().numpy(), onehot[:nt].cpu().numpy(), wmap[:nt].cpu().numpy()
+    state = {"t": 0}
+
+    def one():
+        _, g, _ = torch_ref.unet_loss_and_grads(xs, os_, ws, w, params, dtype=torch.float32)
+        state["t"] += 1
+        t = state["t"]
+        lr_t = 0.01 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        for k in w:
+            m[k] = 0.9 * m[k] + 0.1 * g[k]
+            v2[k] = 0.999 * v2[k] + 0.001 * g[k] * g[k]
+            w[k] = (w[k] - lr_t * m[k] / (np.sqrt(v2[k]) + 1e-8)).astype(np.float32)
+    times, warm = timed_passes(one, warm=1, timed=5, budget_s=20.0)
+    rate = [nt * TILE * TILE / t / 1e6 for t in times]
+    return {"value": round(float(np.median(rate)), 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model_name(), "min": round(min(rate), 3), "max": round(max(rate), 3),
+            "sample": "fp32 torch-CPU autograd restatement of the same training step (forward + weighted softmax-CE + "
+                      "backward + Adam, oracle/torch_ref.py) on 2 of the 16 tiles, %d warm-up + %d timed passes, %d "
+                      "threads; stands in for the reference's TF-CPU training (TensorFlow not installable)"
+                      % (warm, len(times), threads)}
 
 
 def main_train(args):
-    """U-Net training step (fwd + weighted CE + bwd + flat all-reduce + Adam), 16 tiles per GPU."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        init_ranks(dist, local_rank)
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
+    """BASELINE configs[2] / [3]: U-Net training step (fwd + weighted CE + bwd + flat all-reduce + Adam).
+    weak: 16 tiles per GPU per step (config 3 per rank, seeds 2 + rank).  strong: config 4's global batch of 128 tiles
+    sharded over the ranks; a rank with more than 16 tiles runs them as micro-batches of 16 with gradient accumulation
+    (UNetTrainer.step_accumulate) -- still one all-reduce and one Adam launch per step."""
+    world, rank, dist, dev = rank_setup()
     from sequitr_amd.train import UNetTrainer
+    from sequitr_amd.parallel import shard_range
     nb = 16
     params = {"shape": (TILE, TILE), "num_inputs": 1, "num_outputs": 2, "filters": FILTERS,
               "bridge": "eltwise_mul", "dropout": 0.4, "device": str(dev), "seed": 0, "dtype": args.dtype}
     tr = UNetTrainer(params, learning_rate=0.01)
-    rng = np.random.default_rng(2 + rank)
-    x = torch.from_numpy(rng.standard_normal((nb, TILE, TILE, 1)).astype(np.float32)).to(dev)
-    lab = rng.random((nb, TILE, TILE)) < 0.3
-    onehot = torch.from_numpy(np.stack([~lab, lab], -1).astype(np.uint8)).to(dev)
-    wmap = torch.from_numpy((1 + 9 * rng.random((nb, TILE, TILE, 1))).astype(np.float32)).to(dev)
+    if args.scaling == "strong":
+        g_tiles = args.global_tiles or 128
+        lo, hi = shard_range(g_tiles // nb, rank, world)             # whole micro-batches of 16 per rank
+        micro = [config3_inputs(dev, seed=2 + mb, nb=nb) for mb in range(lo, hi)]
+        total_tiles = (g_tiles // nb) * nb
+        if not micro:
+            raise SystemExit("bench.py --mode train --scaling strong: %d ranks but only %d micro-batches of 16" % (world, g_tiles // nb))
+    else:
+        micro = [config3_inputs(dev, seed=2 + rank, nb=nb)]
+        total_tiles = world * nb
+    x, onehot, wmap = micro[0]
 
     def barrier():
         if dist is not None:
@@ -300,12 +497,19 @@ def main_train(args):
 
     if args.graph:                     # hipGraph replay; step() still copies the batch into the static buffers
         tr.capture(x, onehot, wmap, warmup=2)
+
+    def step():
+        return tr.step_accumulate(micro)
+
     for _ in range(args.warmup):
-        tr.step(x, onehot, wmap)
+        step()
     barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step(x, onehot, wmap)
+    for i in range(args.steps):
+        ev[i][0].record()              # HIP events on the launch stream round the whole step (graph replays + all-reduce + Adam)
+        step()
+        ev[i][1].record()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -313,16 +517,48 @@ def main_train(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
-        pix = float(world) * nb * TILE * TILE * args.steps
-        print(json.dumps({"metric": "trained Mpixels/sec on 512x512 tiles (fwd+loss+bwd+allreduce+Adam)",
-                          "value": round(pix / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-                          "data": "synthetic",
-                          "config": {"workload": "U-Net training, weighted softmax-CE, batch=16 512x512x1 tiles per "
-                                                 "GPU, dropout 0.4, Adam (fp32 master weights); activations " + args.dtype
-                                                 + ("; hipGraph replay" if args.graph else "; eager launches"),
-                                     "loss": float(tr.last_loss.item())}}))
+        pix = float(total_tiles) * TILE * TILE * args.steps
+        dev_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+        f_fwd, e_fwd, f_first = unet_work_per_tile()
+        esz = 2 if args.dtype == "bf16" else 4
+        tiles_rank = len(micro) * nb
+        flops = (3.0 * f_fwd - f_first) * tiles_rank                 # fwd + dgrad + wgrad, no dgrad into the input image
+        alg_bytes = 3.0 * e_fwd * esz * tiles_rank                   # layer-by-layer traffic, x3 with backward
+        peak_tf = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        traffic, src = pmc_step_traffic("train_" + args.dtype)
+        out = {"metric": "trained Mpixels/sec on 512x512 tiles (fwd+loss+bwd+allreduce+Adam)",
+               "value": round(pix / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype,
+               "data": "synthetic",
+               "config": {"workload": "U-Net training, weightmap-weighted softmax-CE (disk labels, ImageWeightMap(10,5) "
+                                      "weights: BASELINE configs[2]), launches of 16 512x512x1 tiles, dropout 0.4, Adam "
+                                      "(fp32 master weights); activations " + args.dtype
+                                      + ("; hipGraph replay" if args.graph else "; eager launches")
+                                      + ("; strong scaling: global batch %d tiles per optimiser step (configs[3]), "
+                                         "micro-batches of 16 accumulated per rank" % total_tiles
+                                         if args.scaling == "strong" else "; one 16-tile batch per GPU per step"),
+                          "tiles_per_step": int(total_tiles), "tiles_this_rank": int(tiles_rank),
+                          "loss": float(tr.last_loss.item())},
+               "roofline": {"bound": "hbm",
+                            "kernel": "the whole captured step (forward + loss + backward + Adam: ~130 launches per "
+                                      "16-tile micro-batch); achieved = algorithmic bytes of the layer-by-layer schedule "
+                                      "(SURVEY 8d / A.6: activation elements read + written by every layer, x3 for "
+                                      "forward + dgrad + wgrad) / HIP-event time of the step",
+                            "achieved": round(alg_bytes / (dev_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(alg_bytes / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                            "traffic": traffic, "traffic_source": src,
+                            "algorithmic_bytes_per_step": alg_bytes, "device_ms_per_step": round(dev_ms, 4),
+                            "flops_per_step": flops,
+                            "mfma": {"achieved": round(flops / (dev_ms * 1e-3) / 1e12, 2), "peak": peak_tf,
+                                     "unit": "TFLOP/s", "frac": round(flops / (dev_ms * 1e-3) / 1e12 / peak_tf, 4)}}}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline_train(params, x, onehot, wmap)
+            except Exception as e:                              # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -529,19 +765,112 @@ def main_infer_bf16(args):
                                  "logits_max_abs_fp32": float("%.3e" % float(lref.abs().max()))}}))
 
 
+class WorkCounter(object):
+    """Counts the ALGORITHMIC work of everything launched through sequitr_amd.ops while active: FLOPs of the conv
+    family (2 x pixels x filter elements for conv2d / dgrad / wgrad, 2 x M x K x N for dense) and bytes of every op
+    (tensor arguments + tensor results).  Only the outermost ops call counts (conv2d re-enters itself for its mosaic
+    / dense dispatch), so small-image layers count their real shape, not the padded mosaic.  Used on ONE eager
+    iteration outside the timed region."""
+
+    def __init__(self, ops_mod):
+        self.ops, self.flops, self.bytes, self.calls, self.depth, self.orig = ops_mod, 0.0, 0.0, 0, 0, {}
+
+    @staticmethod
+    def _tbytes(obj):
+        if isinstance(obj, torch.Tensor):
+            return obj.numel() * obj.element_size()
+        if isinstance(obj, (tuple, list)):
+            return sum(WorkCounter._tbytes(o) for o in obj)
+        return 0
+
+    def _conv_flops(self, name, a, kw):
+        if name in ("conv2d", "conv_dgrad_raw", "conv2d_dgrad"):
+            x, w = a[0], a[1]
+            return 2.0 * (x.numel() // x.shape[-1]) * w.numel()
+        if name in ("conv_wgrad_raw", "conv2d_wgrad"):
+            x, dy, K = a[0], a[1], a[2]
+            return 2.0 * (x.numel() // x.shape[-1]) * K * K * x.shape[-1] * dy.shape[-1]
+        if name == "dense":
+            return 2.0 * a[0].shape[0] * a[1].numel()
+        return 0.0
+
+    def __enter__(self):
+        import types
+        for name, fn in list(vars(self.ops).items()):
+            if name.startswith("_") or not isinstance(fn, types.FunctionType) or fn.__module__ != self.ops.__name__:
+                continue
+            if name in ("invalidate_packs",):
+                continue
+            self.orig[name] = fn
+
+            def make(name, fn):
+                def counted(*a, **kw):
+                    top = self.depth == 0
+                    self.depth += 1
+                    try:
+                        out = fn(*a, **kw)
+                    finally:
+                        self.depth -= 1
+                    if top:
+                        self.calls += 1
+                        self.flops += self._conv_flops(name, a, kw)
+                        self.bytes += self._tbytes(a) + self._tbytes(list(kw.values())) + self._tbytes(out)
+                    return out
+                return counted
+            setattr(self.ops, name, make(name, fn))
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.orig.items():
+            setattr(self.ops, name, fn)
+
+
+def cpu_baseline_gan(level=6, nb=2):
+    """CPU leg of the GAN line: fp32 torch-CPU autograd restatement (oracle/torch_gan_ref.py, its dtype switched to
+    float32) of one d_loss gradient + one g_loss gradient evaluation at level 6 on `nb` samples."""
+    from oracle import torch_gan_ref as ref
+    from sequitr_amd.networks.gan import GenerativeAdverserialNetwork
+    threads = int(os.environ.get("SQ_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+    torch.set_num_threads(threads)
+    g = GenerativeAdverserialNetwork({"num_levels": 7, "batch_size": nb, "device": "cuda:0", "seed": 0}, mode=None)
+    g.build()
+    sd = g.store.state_dict()
+    filters = list(g.filters)
+    d_names = [n for n, _ in g.get_training_variables(level)[0]]
+    g_names = [n for n, _ in g.get_training_variables(level)[1]]
+    del g
+    old = ref.DT
+    ref.DT = torch.float32
+    try:
+        W = ref.to_torch(sd)
+        rng = np.random.default_rng(3)
+        X = torch.as_tensor(rng.standard_normal((nb, 256, 256, 2)), dtype=torch.float32)
+        Z = torch.as_tensor(rng.standard_normal((nb, 1, 1, 512)), dtype=torch.float32)
+        r = torch.as_tensor(rng.random(nb), dtype=torch.float32)
+
+        def one():
+            _, d_loss, _ = ref.losses(X, Z, 1.0, r, W, filters, level)
+            torch.autograd.grad(d_loss, [W[n] for n in d_names], allow_unused=True)
+            _, _, g_loss = ref.losses(X, Z, 1.0, r, W, filters, level)
+            torch.autograd.grad(g_loss, [W[n] for n in g_names], allow_unused=True)
+        times, warm = timed_passes(one, warm=1, timed=5, budget_s=20.0)
+    finally:
+        ref.DT = old
+    rate = [nb * 256 * 256 / t / 1e6 for t in times]
+    return {"value": round(float(np.median(rate)), 4), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model_name(), "min": round(min(rate), 4), "max": round(max(rate), 4),
+            "sample": "fp32 torch-CPU autograd restatement of the WGAN-GP level-6 losses and both solvers' gradients "
+                      "(oracle/torch_gan_ref.py; penalty by create_graph double backward, the discriminator evaluated as "
+                      "the reference does) on %d samples, %d warm-up + %d timed passes, %d threads; Adam excluded"
+                      % (nb, warm, len(times), threads)}
+
+
 def main_gan(args):
     """BASELINE configs[4]: progressive WGAN-GP at level 6 (256x256x2), batch 32 per GPU, alpha = 1;
-    one iteration = one d_solver + one g_solver (sequitr/networks/gan.py:850-851)."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        init_ranks(dist, local_rank)
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
+    one iteration = one d_solver + one g_solver (sequitr/networks/gan.py:850-851).  Always weak scaling: the
+    reference's batch_size (32, gan.py:431) is per replica, and the minibatch-stdev statistic is per replica."""
+    world, rank, dist, dev = rank_setup()
+    from sequitr_amd import ops as sq_ops
     from sequitr_amd.networks.gan import GenerativeAdverserialNetwork
     nb, level = 32, 6
     g = GenerativeAdverserialNetwork({"num_levels": 7, "batch_size": nb, "repeat_batch": 1, "learning_rate": 1e-3,
@@ -563,12 +892,17 @@ def main_gan(args):
         g.d_solver(X, Z, 1.0)
         g.g_solver(X, Z, 1.0)
 
-    for _ in range(args.warmup):
+    with WorkCounter(sq_ops) as wc:    # the first iteration is eager in every mode (it warms the graphs up): count it
+        it()
+    for _ in range(max(args.warmup - 1, 2 if args.graph else 0)):
         it()
     barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ev[i][0].record()
         it()
+        ev[i][1].record()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -577,18 +911,43 @@ def main_gan(args):
         dt = float(t.item())
     if rank == 0:
         samples = float(world) * nb * args.steps
-        print(json.dumps({"metric": "GAN training Mpixels/sec (256x256 samples; one D step + one G step)",
-                          "value": round(samples * 256 * 256 / dt / 1e6, 3), "unit": "Mpixels/s",
-                          "samples_per_s": round(samples / dt, 2), "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-                          "data": "synthetic",
-                          "config": {"workload": "progressive WGAN-GP level 6 (256x256x2), filters "
-                                                 "[512,256,128,64,32,16,8], batch 32 per GPU, alpha 1; " +
-                                                 ("f32 tensors, bf16-multiply / f32-accumulate convolutions"
-                                                  if args.dtype == "bf16" else "fp32") +
-                                                 ("; hipGraph replay" if args.graph else "; eager launches"),
-                                     "d_loss": g.last_losses[0], "g_loss": g.last_losses[1]}}))
+        dev_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+        peak_tf = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        f_mfma = wc.flops / (dev_ms * 1e-3) / 1e12 / peak_tf
+        f_hbm = wc.bytes / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+        traffic, src = pmc_step_traffic("gan_" + args.dtype)
+        hbm = {"achieved": round(wc.bytes / (dev_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "frac": round(f_hbm, 4)}
+        mfma = {"achieved": round(wc.flops / (dev_ms * 1e-3) / 1e12, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                "frac": round(f_mfma, 4)}
+        rl = dict(hbm if f_hbm >= f_mfma else mfma)
+        rl.update({"bound": "hbm" if f_hbm >= f_mfma else "mfma",
+                   "kernel": "the whole iteration (d_solver + g_solver, two pairs of replayed hipGraphs); algorithmic "
+                             "work counted op by op on one eager iteration: conv-family FLOPs (forward, dgrad, wgrad, "
+                             "double-backward convs, dense) and the bytes of every operator's tensor arguments + results",
+                   "traffic": traffic, "traffic_source": src, "device_ms_per_step": round(dev_ms, 4),
+                   "flops_per_step": wc.flops, "algorithmic_bytes_per_step": wc.bytes, "ops_per_step": wc.calls,
+                   "gflop_per_sample": round(wc.flops / nb / 1e9, 3), "hbm": hbm, "mfma": mfma})
+        out = {"metric": "GAN training Mpixels/sec (256x256 samples; one D step + one G step)",
+               "value": round(samples * 256 * 256 / dt / 1e6, 3), "unit": "Mpixels/s",
+               "samples_per_s": round(samples / dt, 2), "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+               "data": "synthetic",
+               "config": {"workload": "progressive WGAN-GP level 6 (256x256x2), filters "
+                                      "[512,256,128,64,32,16,8], batch 32 per GPU, alpha 1; " +
+                                      ("f32 tensors, bf16-multiply / f32-accumulate convolutions"
+                                       if args.dtype == "bf16" else "fp32") +
+                                      ("; hipGraph replay" if args.graph else "; eager launches"),
+                          "d_loss": g.last_losses[0], "g_loss": g.last_losses[1]},
+               "roofline": rl}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline_gan()
+            except Exception as e:                              # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -607,7 +966,18 @@ def main():
     ap.add_argument("--mode", choices=["infer", "infer-bf16", "train", "gan", "centroids", "weightmap", "frontend"], default="infer",
                     help="infer = the headline metric (BASELINE configs[1]); train = configs[2]/[3] "
                          "(U-Net training step, batch 16 per GPU) for DESIGN.md, not the driver's line")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="strong (default for --gpus > 1): a FIXED global batch (--global-tiles; train: 128 tiles = "
+                         "config 4) is sharded over the ranks; weak (default for one GPU): every rank its own "
+                         "config-sized batch (32 tiles; train: 16)")
+    ap.add_argument("--global-tiles", type=int, default=0, help="global batch of the strong mode (default 256; train 128)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.mode not in ("infer", "train", "gan"):
+            ap.error("--gpus > 1 is for --mode infer | train | gan")
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.scaling is None:
+        args.scaling = "strong" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "weak"
     if args.mode == "train":
         return main_train(args)
     if args.mode == "infer-bf16":
@@ -621,16 +991,7 @@ def main():
     if args.mode == "frontend":
         return main_frontend(args)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        init_ranks(dist, local_rank)
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
+    world, rank, dist, dev = rank_setup()
 
     from sequitr_amd import ops
     from sequitr_amd.networks.unet import UNet2D, init_unet_weights
@@ -640,22 +1001,43 @@ def main():
     weights = init_unet_weights(params, seed=0)
     net = UNet2D(params, "infer")
     net.load_state_dict(weights)
-    # synthetic tiles, already resident in HBM (seed 1 + rank: every rank its own batch)
-    x = torch.from_numpy(np.random.default_rng(1 + rank).standard_normal(
-        (BATCH, TILE, TILE, 1)).astype(np.float32)).to(dev)
+    # synthetic tiles, already resident in HBM.  weak: every rank its own 32-tile batch (seed 1 + rank).  strong: one
+    # FIXED global batch (default 256 tiles = 8 blocks of 32; block b is default_rng(1000 + b)) sharded contiguously
+    # over the ranks with parallel.shard_range; a rank walks its shard in launches of <= 32 tiles.  No data-path
+    # collective either way: tiles are independent units.
+    from sequitr_amd.parallel import shard_range
+    if args.scaling == "strong":
+        g_tiles = args.global_tiles or 8 * BATCH
+        lo, hi = shard_range(g_tiles, rank, world)
+        blocks = []
+        for blk in range(lo // BATCH, (max(hi, lo + 1) - 1) // BATCH + 1):
+            xb = np.random.default_rng(1000 + blk).standard_normal((BATCH, TILE, TILE, 1)).astype(np.float32)
+            blocks.append(xb[max(lo - blk * BATCH, 0):min(hi - blk * BATCH, BATCH)])
+        xs = np.concatenate(blocks) if blocks else np.zeros((0, TILE, TILE, 1), np.float32)
+        total_tiles = g_tiles
+    else:
+        xs = np.random.default_rng(1 + rank).standard_normal((BATCH, TILE, TILE, 1)).astype(np.float32)
+        total_tiles = world * BATCH
+    x_all = torch.from_numpy(xs).to(dev)
+    chunks = [x_all[i:i + BATCH] for i in range(0, x_all.shape[0], BATCH)]
+    x = chunks[0]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        for c in chunks:
+            net.predict(c)
+
     for _ in range(args.warmup):
-        net.predict(x)
+        step()
     barrier()
-    with ConvTimer(ops, expected_groups=8 * args.steps + 8) as ct:
+    with ConvTimer(ops, expected_groups=(8 * args.steps + 8) * len(chunks)) as ct:
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            net.predict(x)
+            step()
         ct.close()
         barrier()
         dt = time.perf_counter() - t0
@@ -665,7 +1047,7 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        pix = float(world) * BATCH * TILE * TILE * args.steps
+        pix = float(total_tiles) * TILE * TILE * args.steps
         conv_ms, conv_flops, nlaunch = ct.summary()
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         out = {
@@ -677,14 +1059,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "U-Net 2-class inference, batch=32 512x512x1 tiles per GPU, fp32 "
+            "config": {"workload": "U-Net 2-class inference, launches of 32 512x512x1 tiles, fp32 "
                                    "(BASELINE.json configs[1]: filters 16-32-64-128-256, eltwise_mul bridge); "
-                                   "logits + uint8 argmax mask",
-                       "tiles_per_gpu": BATCH,
+                                   "logits + uint8 argmax mask; " +
+                                   ("strong scaling: a fixed global batch of %d tiles per step, sharded over the ranks"
+                                    % total_tiles if args.scaling == "strong" else
+                                    "one 32-tile batch per GPU per step"),
+                       "tiles_per_step": int(total_tiles), "tiles_this_rank": int(x_all.shape[0]),
                        "parity": "logits and masks bit-exact vs oracle/sq_oracle.c (tests/test_gpu_unet.py)"},
             "roofline": {
                 "bound": "mfma",

@@ -175,6 +175,9 @@ int sq_dropout_bwd_f32(const float *dy, const uint8_t *mask, float *dx, int64_t 
  * g is first multiplied by grad_scale (1/world for data-parallel averaging); step counts from 1. */
 int sq_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
                      float beta2, float eps, int step, float grad_scale, void *stream);
+/* y += alpha * x (flat fp32): accumulates the gradient bucket over the micro-batches of one optimiser step when a
+ * rank's share of the global batch is larger than one launch batch (BASELINE config 4 on fewer than 8 GPUs). */
+int sq_axpy_f32(float *y, const float *x, float alpha, int64_t n, void *stream);
 /* hipGraph-safe form: state = 2 x int32 in device memory {step counter, lr_t bits}; the call increments
  * the counter on the device, so a captured step replays with the right bias correction. */
 int sq_adam_step_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,

@@ -41,6 +41,7 @@ SIGNATURES = {
     "sq_dropout_fwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_float, ctypes.c_uint32, c_int, c_void_p, c_void_p]),
     "sq_dropout_bwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_float, c_void_p]),
     "sq_adam_step_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 4 + [c_int, c_float, c_void_p]),
+    "sq_axpy_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "sq_mask_centroids_workspace": (c_int64, [c_int, c_int, c_int]),
     "sq_mask_centroids_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p]),

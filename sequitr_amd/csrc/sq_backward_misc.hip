@@ -493,6 +493,27 @@ extern "C" int sq_adam_step_f32(float *p, const float *g, float *m, float *v, in
     return sq_check_launch("sq_adam_step_f32");
 }
 
+// y += alpha * x over a flat buffer: gradient accumulation over the micro-batches of one optimiser step
+// (UNetTrainer.step_accumulate); float4 body + scalar tail, no alignment demand beyond 4 bytes.
+__global__ __launch_bounds__(256) void axpy_kernel(float *__restrict__ y, const float *__restrict__ x, float alpha,
+                                                   int64_t n) {
+    const int64_t n4 = ((((uintptr_t)y | (uintptr_t)x) & 15u) == 0) ? n / 4 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 a = ((float4 *)y)[i];
+        const float4 b = ((const float4 *)x)[i];
+        a.x = fmaf(alpha, b.x, a.x), a.y = fmaf(alpha, b.y, a.y), a.z = fmaf(alpha, b.z, a.z), a.w = fmaf(alpha, b.w, a.w);
+        ((float4 *)y)[i] = a;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = fmaf(alpha, x[i], y[i]);
+}
+
+extern "C" int sq_axpy_f32(float *y, const float *x, float alpha, int64_t n, void *stream) {
+    SQ_REQUIRE(y && x && n > 0, "sq_axpy_f32: bad arguments");
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, SQ_ST(stream), y, x, alpha, n);
+    return sq_check_launch("sq_axpy_f32");
+}
+
 // the two halves of sq_adam_step_dev_f32 for optimisers that update many tensors per step (the GAN's per-variable
 // slots): ONE advance per minimize(), then one apply per tensor
 extern "C" int sq_adam_advance_dev(int32_t *state, float lr, float beta1, float beta2, void *stream) {

@@ -237,7 +237,7 @@ def SERVER_train(params, options):
     """
     import torch
     from . import utils
-    from .parallel import shard_range
+    from .parallel import epoch_schedule
     from .weightmap import device_weightmaps
     from .train import UNetTrainer
 
@@ -272,15 +272,17 @@ def SERVER_train(params, options):
             trainer.load_state_dict(utils.load_model_weights(latest))
             logger.info('Warm start from {0:s}'.format(latest))
 
-    lo, hi = shard_range(x.shape[0], rank, world)
+    # Every rank must issue the SAME number of optimiser steps (each one is a gradient all-reduce), so the step count
+    # comes from rank-independent quantities only and every step is a full batch: one seeded permutation of the whole
+    # stack per epoch, cut into world x steps_per_epoch x batch indices; the remainder of the epoch is dropped.
     batch = int(params.get('batch_size', 16))
-    steps_per_epoch = max(1, (hi - lo) // batch)
+    order_fn, steps_per_epoch = epoch_schedule(x.shape[0], batch, world)
     epochs = int(params.get('num_epochs', config.num_epochs))
     max_steps = options.get('max_steps')
     losses = []
     t0 = time.time()
     for epoch in range(epochs):
-        order = np.random.default_rng(epoch).permutation(hi - lo)[:steps_per_epoch * batch] + lo
+        order = order_fn(epoch, rank)
         for s in range(steps_per_epoch):
             idx = np.sort(order[s * batch:(s + 1) * batch])
             xb = torch.from_numpy(np.ascontiguousarray(x[idx], dtype=np.float32)).to(device)

@@ -430,17 +430,23 @@ class GenerativeAdverserialNetwork(object):
 
     def d_solver(self, X, Z, alpha, r=None):
         """d_opt.minimize(d_loss, var_list=d_vars) for the current level (gan.py:649)."""
-        with self.precision():
-            if self._graphable(alpha) and r is None:
-                return self._solver_graphed('d', X, Z, alpha)
-            return self._d_solver(X, Z, alpha, r)
+        try:
+            with self.precision():
+                if self._graphable(alpha) and r is None:
+                    return self._solver_graphed('d', X, Z, alpha)
+                return self._d_solver(X, Z, alpha, r)
+        finally:
+            ops.invalidate_packs()      # the step ends with a weight update, also under an outer precision() block
 
     def g_solver(self, X, Z, alpha):
         """g_opt.minimize(g_loss, var_list=g_vars, global_step) for the current level (gan.py:650-651)."""
-        with self.precision():
-            if self._graphable(alpha):
-                return self._solver_graphed('g', X, Z, alpha)
-            return self._g_solver(X, Z, alpha)
+        try:
+            with self.precision():
+                if self._graphable(alpha):
+                    return self._solver_graphed('g', X, Z, alpha)
+                return self._g_solver(X, Z, alpha)
+        finally:
+            ops.invalidate_packs()
 
     # the two halves of a solver step: (losses + gradients) and (Adam); the all-reduce sits between them
     def _d_grads(self, X, Z, alpha, r):

@@ -266,6 +266,7 @@ class UNet2D(UNet):
         self._seed = params.get('seed', 0)
         self._rng = np.random.default_rng(self._seed)
         self._vars = {}                                        # scope/name -> device tensor
+        self._loaded, self._creatable = False, set()           # set by a strict load_state_dict
         self._dropout_calls = 0                               # dropout layer index within one build()
         self._builds = 0                                      # host-side step salt when no device counter is set
         self.dropout_masks = None
@@ -285,6 +286,10 @@ class UNet2D(UNet):
         key = self.scope + '/' + name
         v = self._vars.get(key)
         if v is None:
+            if self._loaded and key not in self._creatable:
+                # a model was loaded: build() must find every variable in it, never fill gaps with fresh random draws
+                raise KeyError('variable %s is not in the loaded model (load_state_dict(strict=False) to allow '
+                               'missing variables to be initialised)' % key)
             v = torch.from_numpy(init(shape)).to(self.device)
             self._vars[key] = v
         elif tuple(v.shape) != tuple(shape):
@@ -300,14 +305,46 @@ class UNet2D(UNet):
     def state_dict(self):
         return {k: v.detach().cpu().numpy() for k, v in self._vars.items()}
 
-    def load_state_dict(self, weights):
+    def expected_variables(self):
+        """({key: shape} build() will ask for, {key: shape} of optional non-trainable state): the trainable set is
+        unet_variable_shapes(params); with batch_norm the moving statistics of every conv are optional on load
+        (absent -> tf.layers' initial values 0 / 1)."""
+        req = dict(unet_variable_shapes(self._params))
+        opt = {}
+        if self.batch_norm:
+            for k, shp in list(req.items()):
+                if k.endswith('/gamma'):
+                    sc = k.rsplit('/', 1)[0]
+                    opt[sc + '/moving_mean'] = opt[sc + '/moving_variance'] = shp
+        return req, opt
+
+    def load_state_dict(self, weights, strict=True):
+        """Copy a model into the net.  strict (default): the keys must be exactly the variables this configuration
+        builds (plus optional BN moving statistics) with the right shapes -- a UNet_LEGACY checkpoint, another depth or
+        filter schedule, or a BN checkpoint in a non-BN net raise here instead of segmenting with partly random weights;
+        afterwards build() refuses to create variables the model did not hold.  strict=False: deliberate partial load,
+        missing variables are initialised by build() as in a fresh net."""
+        req, opt = self.expected_variables()
+        if strict:
+            missing = [k for k in req if k not in weights]
+            unexpected = [k for k in weights if k not in req and k not in opt]
+            bad = [(k, tuple(np.shape(weights[k])), tuple(s)) for k, s in list(req.items()) + list(opt.items())
+                   if k in weights and tuple(np.shape(weights[k])) != tuple(s)]
+            if missing or unexpected or bad:
+                raise ValueError('load_state_dict: model does not fit this %s configuration -- missing %s; unexpected %s; '
+                                 'shape mismatches (key, got, wanted) %s' % (self.__class__.__name__, missing[:6],
+                                                                             unexpected[:6], bad[:6]))
+            self._loaded, self._creatable = True, set(opt)
         for k, v in weights.items():
             self._vars[k] = torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(self.device)
 
     def initialize(self):
         """Create every variable without running a tile (same draws as a first build)."""
-        self.load_state_dict(init_unet_weights(self._params, self._seed))
+        self.load_state_dict(self._initial_weights(), strict=False)      # a fresh net: hooks may still add variables
         return self
+
+    def _initial_weights(self):
+        return init_unet_weights(self._params, self._seed)
 
     # -- input ---------------------------------------------------------------------------
     def reshape_input(self, features):
@@ -517,6 +554,18 @@ class UNet_LEGACY(UNet2D):
     def __init__(self, params, mode=PREDICT):
         UNet2D.__init__(self, dict(params, fuse=False), mode)
         self._auto = {}
+
+    def expected_variables(self):
+        req, opt = UNet2D.expected_variables(self)
+        _, back = legacy_state_dict({k: None for k in req}, self._params)
+        fwd = {v: k for k, v in back.items()}                  # scoped name -> tf.layers automatic name
+
+        def rename(d):
+            return {fwd[k.rsplit('/', 1)[0]] + '/' + k.rsplit('/', 1)[1]: s for k, s in d.items()}
+        return rename(req), rename(opt)
+
+    def _initial_weights(self):                                # the same draws, under the automatic names
+        return legacy_state_dict(init_unet_weights(self._params, self._seed), self._params)[0]
 
     def _auto_scope(self, kind):
         n = self._auto.get(kind, 0)

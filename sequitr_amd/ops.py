@@ -110,11 +110,19 @@ class mixed_precision:
         return False
 
 
-# packed bf16 filters of PARAMETERS (leaf tensors that require grad), valid until the outermost mixed_precision
-# block ends: a solver step evaluates the discriminator three times and differentiates it twice with the same
-# weights, and the optimiser only writes them as the step's last act.  Entries hold the parameter itself, so its
-# storage cannot be recycled under the key.
+# packed bf16 filters of PARAMETERS (leaf tensors that require grad), valid until the weights change: a solver step
+# evaluates the discriminator three times and differentiates it twice with the same weights, and the optimiser only
+# writes them as the step's last act.  Invalidation is tied to the weight UPDATE, not to the nesting depth of the
+# precision contexts: every Adam wrapper below calls invalidate_packs() (the kernels update the weights in place
+# through raw pointers, which no tensor version counter sees), the GAN's solver steps clear on the way out, and
+# leaving the outermost mixed_precision block clears as before.  Entries hold the parameter itself, so its storage
+# cannot be recycled under the key.
 _PACKS = {}
+
+
+def invalidate_packs():
+    """drop every cached bf16 filter pack (call after anything that writes parameters in place)"""
+    _PACKS.clear()
 
 
 def _packed_filter(w, K, Cin, Cout, wscale, transform):
@@ -499,6 +507,16 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     _lib.check(lib.sq_adam_step_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
                                    float(beta2), float(eps), int(step), float(grad_scale), _stream()),
                "sq_adam_step_f32")
+    invalidate_packs()
+
+
+def axpy_(y, x, alpha=1.0):
+    """y += alpha * x in place over flat fp32 buffers (gradient accumulation across micro-batches)."""
+    _chk(y, "y"), _chk(x, "x")
+    if y.numel() != x.numel():
+        raise ValueError("axpy_: buffers differ in size")
+    _lib.check(_lib.load().sq_axpy_f32(_ptr(y), _ptr(x), float(alpha), y.numel(), _stream()), "sq_axpy_f32")
+    return y
 
 
 # ----------------------------------------------------------------------------------------------
@@ -737,6 +755,7 @@ def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, state, grad_scale=1.0):
     _lib.check(lib.sq_adam_step_dev_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
                                        float(beta2), float(eps), _ptr(state), float(grad_scale), _stream()),
                "sq_adam_step_dev_f32")
+    invalidate_packs()
 
 
 def adam_advance_dev(state, lr, beta1, beta2):
@@ -754,6 +773,7 @@ def adam_apply_dev(p, g, m, v, beta1, beta2, eps, state, grad_scale=1.0):
     _lib.check(_lib.load().sq_adam_apply_dev_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(beta1), float(beta2),
                                                 float(eps), _ptr(state), float(grad_scale), _stream()),
                "sq_adam_apply_dev_f32")
+    invalidate_packs()
 
 
 # ----------------------------------------------------------------------------------------------

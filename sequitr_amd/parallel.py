@@ -42,6 +42,26 @@ def shard_range(n_items, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def epoch_schedule(n_items, batch, world):
+    """Data-parallel epoch plan with the SAME number of full-batch steps on every rank (each step is one gradient
+    all-reduce: ranks that disagree on the count dead-lock RCCL).  steps = (n_items // world) // batch; one seeded
+    permutation of the whole stack per epoch is cut into world x steps x batch indices and the remainder of the
+    epoch is dropped.  Returns (order(epoch, rank) -> steps*batch item indices, steps).  Raises when a rank would
+    not get one full batch -- a short batch would be mis-weighted by Adam's 1/world gradient scale."""
+    n_items, batch, world = int(n_items), int(batch), int(world)
+    steps = (n_items // world) // batch
+    if steps < 1:
+        raise ValueError("data-parallel training needs at least batch_size x world = %d x %d tiles, got %d"
+                         % (batch, world, n_items))
+    per_rank = steps * batch
+
+    def order(epoch, rank):
+        import numpy as np
+        perm = np.random.default_rng(int(epoch)).permutation(n_items)
+        return perm[rank * per_rank:(rank + 1) * per_rank]
+    return order, steps
+
+
 def allreduce_sum_(flat, group=None):
     """One in-place SUM all-reduce of the flat gradient bucket (no-op without a process group)."""
     import torch.distributed as dist

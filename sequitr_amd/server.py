@@ -3,7 +3,8 @@
 processes (``python -m sequitr_amd.worker --job X.job --out OUTDIR/JOB_<ID>``, the reference's
 ``python worker.py --job ... --out ...``, worker.py:307-316), hands each GPU job one of the allowed GPUs
 (least loaded first; ``--gpus`` or DEFAULT_GPUS, core.py:41-42) through LOCAL_RANK, which
-jobs._resolve_device reads, and renames a finished job file to ``.job.complete`` (worker.py:218-239).
+jobs._resolve_device reads, and renames a finished job file to ``.job.complete`` (worker.py:218-239) -- or to
+``.job.failed`` when the worker exits non-zero (its job function raised), ``.job.invalid`` when it cannot be parsed.
 ``--setup`` writes ``server.config`` (sections config / tensorflow / cpu / gpu, core.py:57-87).
 
 One process per job, one GPU per process: the reference's process model, which is also the MI355X one.
@@ -70,6 +71,9 @@ class Server(object):
             job = worker.parse_job_file(fn, header_only=True)
             if job is not None:
                 jobs.append(job)
+            else:                                              # logged once by the parser; never polled again
+                logger.error('Job file {0} cannot be parsed: renamed to .job.invalid'.format(fn))
+                os.rename(fn, fn + '.invalid')
         return sorted(jobs, key=lambda j: -int(j.priority))
 
     def _free_gpu(self):
@@ -89,7 +93,10 @@ class Server(object):
             self.finished.append((job.ID, rc))
             logger.info('Job {0} finished with code {1}'.format(job.ID, rc))
             if os.path.exists(fn):
-                job.complete = True                            # X.job -> X.job.complete
+                if rc == 0:
+                    job.complete = True                        # X.job -> X.job.complete
+                else:                                          # the worker logs and swallows the exception but exits 1
+                    os.rename(fn, fn + '.failed')              # X.job -> X.job.failed: visible, not retried for ever
 
     def launch(self, job):
         gpu = self._free_gpu() if str(job.device).upper() == 'GPU' else None

@@ -52,13 +52,23 @@ def get_logger(loggers=core.DEFAULT_LOGGER_PROCESSES):
     return next((lg for lg in configured if lg.handlers), None)
 
 
+_FAILURES = [0]
+
+
+def failure_count():
+    """number of exceptions exception_logger has swallowed in this process (the worker's exit code reads it)"""
+    return _FAILURES[0]
+
+
 def exception_logger(function):
-    """Log any exception of the wrapped call and return None instead of raising."""
+    """Log any exception of the wrapped call and return None instead of raising (serverlogs.py:113-127); the
+    failure is counted so that the worker PROCESS can still report it to the server through its exit code."""
     @functools.wraps(function)
     def guarded(*args, **kwargs):
         try:
             return function(*args, **kwargs)
         except Exception:
+            _FAILURES[0] += 1
             where = "There was an exception in: {0:s}".format(function.__name__)
             sink = get_logger()
             (sink.exception if sink is not None else print)(where)

@@ -53,6 +53,15 @@ class UNetTrainer(object):
         self._graphs = None
 
     def load_state_dict(self, weights):
+        """strict: every trainable variable of this configuration must be present with its shape; anything else must
+        be one of the net's optional non-trainable variables (BN moving statistics)."""
+        req, opt = self.net.expected_variables()
+        missing = [k for k in self.pbucket.names if k not in weights]
+        unexpected = [k for k in weights if k not in req and k not in opt]
+        bad = [k for k in weights if k in self.pbucket.shapes and tuple(np.shape(weights[k])) != self.pbucket.shapes[k]]
+        if missing or unexpected or bad:
+            raise ValueError('UNetTrainer.load_state_dict: model does not fit this configuration -- missing %s; '
+                             'unexpected %s; wrong shape %s' % (missing[:6], unexpected[:6], bad[:6]))
         with torch.no_grad():
             for name in self.pbucket.names:
                 self.pbucket.view(name).copy_(torch.as_tensor(weights[name]).to(self.pbucket.flat.device))
@@ -100,6 +109,43 @@ class UNetTrainer(object):
         self.step_count += 1
         self._adam(world)
         return loss
+
+    def step_accumulate(self, micro_batches):
+        """One optimiser step over several equally sized micro-batches [(x, onehot, weights), ...]: this rank's share of
+        the global batch when it is larger than one launch batch (BASELINE config 4's global 128 tiles on fewer than 8
+        GPUs).  Each micro-batch runs forward/backward (graph replay when captured); its gradient bucket is added,
+        scaled by 1/k, into an accumulator (sq_axpy_f32), so after the last one the bucket holds the mean gradient
+        of the rank's share; then the usual ONE all-reduce and ONE Adam launch.  Returns the mean loss.  The dropout
+        salt is the optimiser step counter, so the micro-batches of one step share their mask pattern."""
+        k = len(micro_batches)
+        if k == 1:
+            return self.step(*micro_batches[0])
+        if getattr(self, "_acc", None) is None:
+            self._acc = torch.zeros_like(self.gbucket.flat)
+        self._acc.zero_()
+        total = None
+        for x, onehot, weights in micro_batches:
+            if self._graphs is not None:
+                g_fb, _, sx, so, sw, sloss = self._graphs
+                if x.shape != sx.shape:
+                    raise ValueError("UNetTrainer: captured for batch shape %s, got %s" % (tuple(sx.shape), tuple(x.shape)))
+                if x is not sx:
+                    sx.copy_(x), so.copy_(onehot), sw.copy_(weights)
+                g_fb.replay()
+                loss = sloss
+            else:
+                loss = self.forward_backward(x, onehot, weights)
+            ops.axpy_(self._acc, self.gbucket.flat, 1.0 / k)
+            total = loss.clone() if total is None else total + loss
+        self.gbucket.flat.copy_(self._acc)
+        world = allreduce_sum_(self.gbucket.flat, self.group)   # still ONE collective per optimiser step
+        self.step_count += 1
+        if self._graphs is not None:
+            self._graphs[1].replay()
+        else:
+            self._adam(world)
+        self.last_loss = total / k
+        return self.last_loss
 
     # ---- hipGraph replay: the step is ~200 short launches, host-bound when issued from Python ----------
     def capture(self, x, onehot, weights, warmup=2):

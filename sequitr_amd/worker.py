@@ -143,6 +143,7 @@ def worker(args, log=True):
     if log:
         serverlogs.setup_logging(args.out, log_name='worker_process')
         logging.getLogger('worker_process').info(args.job)
+    failures = serverlogs.failure_count()
     try:
         job = JobWrapper.load(args.job)
         if job is not None:
@@ -151,14 +152,17 @@ def worker(args, log=True):
     finally:
         if log:
             serverlogs.shutdown_logging('worker_process')
+    # exceptions are logged and swallowed as in the reference (serverlogs.py:113-127), but the outcome is kept:
+    # False when the job file could not be parsed or the job function raised
+    return job is not None and serverlogs.failure_count() == failures
 
 
 def main(argv=None):
     cli = argparse.ArgumentParser(description='Sequitr worker process')
     cli.add_argument('--job', help='Path to job description file')
     cli.add_argument('--out', help='Path to output folder')
-    worker(cli.parse_args(argv))
+    return 0 if worker(cli.parse_args(argv)) else 1            # the server tells failed jobs from finished ones by this
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -36,6 +36,52 @@ def test_flags_and_work_figures_cpu():
     assert bench.pmc_traffic_per_launch() is None or bench.pmc_traffic_per_launch() > 1e8
 
 
+def test_gpus_n_launcher_fails_loudly_without_gpus():
+    """`python bench.py --gpus N` starts N ranks itself.  Here there is no GPU: with the RCCL
+    backend the launcher refuses before starting anything; in the gloo rehearsal mode the children start, fail at
+    their first HIP call, and the parent must come back non-zero (never hang in a barrier, never print a line)."""
+    b = os.path.join(ROOT, "bench.py")
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has GPUs: covered by the gpu-marked launcher test")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, b, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=dict(env, SQ_BENCH_BACKEND="nccl"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
+    if torch.cuda.device_count() == 0:
+        r = subprocess.run([sys.executable, b, "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           env=dict(env, SQ_BENCH_BACKEND="gloo"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=300)
+        assert r.returncode != 0 and not r.stdout.strip()
+
+
+def test_work_figures_of_the_training_line():
+    import bench
+    f, e, first = bench.unet_work_per_tile()
+    assert f == 19285409792.0 and e == 108003328 and first == 2.0 * 37748736        # SURVEY A.6 totals
+    lab = bench.disk_labels(np.random.default_rng(2), 2, tile=128, disks=10)
+    assert lab.shape == (2, 128, 128) and lab.dtype == np.bool_ and 0.01 < lab.mean() < 0.9
+
+
+@pytest.mark.gpu
+def test_gpus_2_launches_two_ranks_and_reports_strong_scaling():
+    """one-GPU box: SQ_BENCH_BACKEND=gloo puts both ranks on GPU 0 -- it rehearses the N-rank control flow (spawn,
+    barriers, max-over-ranks time, rank 0's single line), not the interconnect."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SQ_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--global-tiles", "64"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["tiles_per_step"] == 64
+    assert d["config"]["tiles_this_rank"] == 32 and d["steps"] == 2
+    assert abs(d["value"] - 64 * 512 * 512 / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["value"]
+    assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0.2
+
+
 @pytest.mark.gpu
 def test_default_line_has_every_contract_field():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"],

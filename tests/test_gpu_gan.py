@@ -337,3 +337,111 @@ def test_stacked_discriminator_pass_equals_separate_passes(level, alpha):
     m = gan.minibatch_stdev(feat, groups=2)
     assert torch.allclose(m[:4], gan.minibatch_stdev(feat[:4])) and torch.allclose(m[4:], gan.minibatch_stdev(feat[4:]))
     assert not torch.allclose(m[:4], gan.minibatch_stdev(feat)[:4])
+
+
+# ---- BASELINE configs[4] at FULL size: level 6 = 256x256x2, batch 32, filters [512 ... 8] ----------
+FULL = {"num_levels": 7, "batch_size": 32, "repeat_batch": 1, "learning_rate": 1e-3, "device": "cuda:0", "seed": 0}
+
+
+def _full_inputs(n=32):
+    rng = np.random.default_rng(3)
+    return (dev(rng.standard_normal((n, 256, 256, 2)).astype(np.float32)),
+            dev(rng.standard_normal((n, 1, 1, 512)).astype(np.float32)))
+
+
+def test_config5_level6_forward_vs_fp64_batch2():
+    """generator / discriminator at level 6 with the reference's filter schedule vs oracle/torch_gan_ref.py (fp64)."""
+    g = gan.GenerativeAdverserialNetwork(dict(FULL), mode=None)
+    g.build()
+    assert g.filters == [512, 256, 128, 64, 32, 16, 8] and g.get_size(6) == (256, 256)
+    W = ref.to_torch(g.store.state_dict(), requires_grad=False)
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal((2, 1, 1, 512)).astype(np.float32)
+    x = rng.standard_normal((2, 256, 256, 2)).astype(np.float32)
+    with torch.no_grad():
+        outs, last = g.generator(dev(z), g.filters)
+        _, logits = g.discriminator(dev(x), g.filters[::-1])
+    routs, _ = ref.generator(torch.as_tensor(z, dtype=torch.float64), W, g.filters)
+    assert tuple(last.shape) == (2, 256, 256, 2) and len(outs) == 7
+    for a, b in zip(outs, routs):
+        close(a.cpu().numpy(), b.numpy(), 5e-5, "generator image, level-6 schedule")
+    close(logits.cpu().numpy(), ref.discriminator(torch.as_tensor(x, dtype=torch.float64), W, g.filters[::-1]).numpy(),
+          5e-5, "D logits, level 6")
+
+
+def test_config5_level6_batch32_bf16_replay_equals_eager():
+    """one d_solver + g_solver at config 5's full size in its dtype (bf16-multiply convolutions): finite losses, and
+    three iterations (eager warm-up, capture, replay) leave bit-identical weights with and without hipGraph replay."""
+    X, Z = _full_inputs()
+
+    def run(graph):
+        g = gan.GenerativeAdverserialNetwork(dict(FULL, dtype="bf16", graph=graph), mode=None)
+        g.build()
+        g.set_level(6)
+        for _ in range(3):
+            g.d_solver(X, Z, 1.0)
+            g.g_solver(X, Z, 1.0)
+        assert all(np.isfinite(v) for v in g.last_losses)
+        return g
+    a, b = run(False), run(True)
+    assert len(b._graphs) == 2 and all(isinstance(v, tuple) for v in b._graphs.values())
+    assert a.last_losses == b.last_losses
+    wa, wb = a.store.state_dict(), b.store.state_dict()
+    changed = 0
+    for k in wa:
+        assert np.array_equal(wa[k], wb[k]), k
+        assert np.isfinite(wa[k]).all(), k
+    w0 = gan.GenerativeAdverserialNetwork(dict(FULL), mode=None)
+    w0.build()
+    w0 = w0.store.state_dict()
+    changed = sum(1 for k in wa if not np.array_equal(wa[k], w0[k]))
+    assert changed >= 40, changed                                 # every trained D and G variable moved
+
+
+def test_config5_level6_batch32_stacked_d_equals_separate_passes():
+    """params['batch_d'] at full size (f32: the exact-f32 kernels make the comparison sharp)."""
+    X, Z = _full_inputs()
+    r = dev(np.random.default_rng(6).random(32).astype(np.float32))
+    res = {}
+    for bd in (True, False):
+        g = gan.GenerativeAdverserialNetwork(dict(FULL, batch_d=bd), mode=None)
+        g.build()
+        g.set_level(6)
+        _, d_loss, g_loss = g._build_network(X, Z, 1.0, r=r, need_g_graph=False)
+        d_vars, _ = g.get_training_variables(6)
+        dg = torch.autograd.grad(d_loss, [v for _, v in d_vars], allow_unused=True)
+        res[bd] = (d_loss.item(), g_loss.item(), [None if t is None else t.cpu().numpy() for t in dg])
+        del g, dg, d_loss, g_loss
+        torch.cuda.empty_cache()
+    a, b = res[True], res[False]
+    assert abs(a[0] - b[0]) <= 1e-5 * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 1e-5 * max(1.0, abs(b[1]))
+    for u, v in zip(a[2], b[2]):
+        assert (u is None) == (v is None)
+        if u is not None:
+            close(u, v, 5e-4, "gradient, stacked vs separate, level 6")
+
+
+def test_nested_precision_blocks_do_not_reuse_stale_filter_packs():
+    """under an outer `with net.precision():` the inner solver blocks used to leave the packed bf16 filters
+    cached across the Adam update (eager: stale weights in the next step; graphed: no pack kernel captured).  The cache
+    is now invalidated by the weight update itself: nested and un-nested runs give the same bits, eager and graphed."""
+    rng = np.random.default_rng(12)
+    z = dev(rng.standard_normal((4, 1, 1, 512)).astype(np.float32))
+    x = dev(rng.standard_normal((4, 8, 8, 2)).astype(np.float32))
+
+    def run(graph, nested):
+        g = make_gan(graph=graph, dtype="bf16")
+        g.set_level(1)
+        import contextlib
+        with (g.precision() if nested else contextlib.nullcontext()):
+            for _ in range(4):
+                g.d_solver(x, z, 1.0)
+                g.g_solver(x, z, 1.0)
+            assert not nested or ops.MIXED
+            assert not ops._PACKS                                  # nothing survives a solver step
+        return g.store.state_dict()
+    want = run(False, False)
+    for graph, nested in ((False, True), (True, False), (True, True)):
+        got = run(graph, nested)
+        for k in want:
+            assert np.array_equal(want[k], got[k]), (graph, nested, k)

@@ -289,3 +289,68 @@ def test_training_other_configurations_vs_fp64(cfg):
     g = t.grads()
     for k in rgrads:
         assert np.max(np.abs(g[k] - rgrads[k])) <= 1e-3 * np.max(np.abs(rgrads[k])) + 1e-7, k
+
+
+def test_config3_full_size_bf16_training_step():
+    """BASELINE configs[2] at FULL size under -m gpu: one bf16 UNetTrainer.step on 16 x 512x512x1
+    tiles with config 3's inputs (60-disk labels, ImageWeightMap(10,5) weights from sq_weightmap_edt_f32).
+      * run to run bit-identical (fixed-order reductions, no float atomics) -- loss and every weight after the step;
+      * hipGraph replay == eager, bit for bit, at this size too;
+      * sample k's logits in the batch == the same sample run alone (per-sample arithmetic, dropout 0);
+      * loss equal to the f32 trainer's within the 2 % the 64x64 test uses (bf16 rounding of activations)."""
+    import bench
+    d = torch.device("cuda:0")
+    x, onehot, wmap = bench.config3_inputs(d, seed=2, nb=16)
+    assert tuple(x.shape) == (16, 512, 512, 1) and tuple(onehot.shape) == (16, 512, 512, 2) and onehot.dtype == torch.uint8
+    assert tuple(wmap.shape) == (16, 512, 512, 1) and 1.0 <= float(wmap.min()) and 10.0 < float(wmap.max()) < 11.5
+    assert torch.equal(onehot.sum(-1), torch.ones_like(onehot[..., 0]))
+    base = {"shape": (512, 512), "dropout": 0.4, "device": "cuda:0", "seed": 0, "dtype": "bf16"}
+    a, b, c = UNetTrainer(base), UNetTrainer(base), UNetTrainer(base)
+    c.capture(x, onehot, wmap, warmup=1)
+    la, lb = a.step(x, onehot, wmap).item(), b.step(x, onehot, wmap).item()
+    la2, lb2, lc2 = a.step(x, onehot, wmap).item(), b.step(x, onehot, wmap).item(), c.step(x, onehot, wmap).item()
+    assert np.isfinite(la) and la == lb and la2 == lb2 == lc2 and la2 != la
+    wa, wb, wc = a.state_dict(), b.state_dict(), c.state_dict()
+    for k in wa:
+        assert np.array_equal(wa[k], wb[k]) and np.array_equal(wa[k], wc[k]), k
+    del b, c
+    # per-sample independence of the forward (dropout off)
+    nodrop = dict(base, dropout=0.0)
+    t16, t32 = UNetTrainer(nodrop), UNetTrainer(dict(nodrop, dtype="f32"))
+    l16 = t16.forward_backward(x, onehot, wmap).item()
+    logits = t16.net.logits().detach().clone()
+    assert tuple(logits.shape) == (16, 512, 512, 2)
+    for k in (0, 7, 15):
+        t16.forward_backward(x[k:k + 1].contiguous(), onehot[k:k + 1].contiguous(), wmap[k:k + 1].contiguous())
+        assert torch.equal(t16.net.logits().detach()[0], logits[k]), k
+    l32 = t32.forward_backward(x, onehot, wmap).item()
+    assert abs(l16 - l32) <= 0.02 * abs(l32), (l16, l32)
+    g16, g32 = t16.grads(), t32.grads()
+    assert all(np.isfinite(v).all() for v in g16.values())
+    k = "UNet/to_image/kernel"                       # the head's gradient sees the least bf16 rounding: same direction
+    cos = float((g16[k].ravel() @ g32[k].ravel()) / (np.linalg.norm(g16[k]) * np.linalg.norm(g32[k]) + 1e-30))
+    assert cos > 0.98, cos
+
+
+def test_step_accumulate_equals_one_big_batch_f32():
+    """UNetTrainer.step_accumulate (config 4's global batch on fewer GPUs): k micro-batches accumulated with sq_axpy_f32
+    give the gradient of the concatenated batch (mean of equal-sized means) to f32 summation order, and one Adam step."""
+    params = {"shape": (64, 64), "dropout": 0.0, "device": "cuda:0", "seed": 3, "filters": (16, 32, 64)}
+    parts = [_batch(20 + i, 2, 64) for i in range(3)]
+    whole = [np.concatenate([p[j] for p in parts]) for j in range(3)]
+    a, b = UNetTrainer(params, learning_rate=0.003), UNetTrainer(params, learning_rate=0.003)
+    la = a.step_accumulate([tuple(dev(t) for t in p) for p in parts]).item()
+    ga = {k: v.copy() for k, v in a.grads().items()}
+    lb = b.step(*[dev(t) for t in whole]).item()
+    gb = b.grads()
+    assert abs(la - lb) <= 1e-5 * abs(lb) and a.step_count == b.step_count == 1
+    for k in gb:
+        close(ga[k], gb[k], 2e-4, "accumulated grad " + k)
+    w0, wa = UNetTrainer(params).state_dict(), a.state_dict()
+    for k in wa:                                                 # ONE Adam step happened (|step| <= lr at t = 1)
+        delta = np.abs(wa[k] - w0[k]).max()
+        assert 0 < delta <= 0.003 * 1.01, (k, delta)
+    x = torch.ones(1001, device="cuda:0")
+    y = torch.arange(1001, dtype=torch.float32, device="cuda:0")
+    ops.axpy_(y[1:], x[1:], 0.5)                                 # misaligned views: scalar path
+    assert torch.equal(y[1:], torch.arange(1, 1001, dtype=torch.float32, device="cuda:0") + 0.5) and y[0] == 0

@@ -173,3 +173,29 @@ def test_legacy_variable_names_mapping_is_a_bijection_in_creation_order():
     for k, scoped in back.items():
         assert flat[k + "/kernel"] is w[scoped + "/kernel"]
     assert [k for k, _ in unet_variable_shapes(params)][0] == "UNet/down0/conv1/kernel"
+
+
+def test_load_state_dict_validates_the_model_against_the_configuration():
+    """ADVICE r1 (unet.py load_state_dict): a model that does not fit the configuration raises at load time -- before any
+    byte goes to the GPU, so this runs on the CPU -- instead of segmenting with partly random weights."""
+    from sequitr_amd.networks.unet import UNet2D, UNet_LEGACY, init_unet_weights, legacy_state_dict
+    params = {"shape": (32, 32), "filters": (16, 32), "device": "cuda:0"}
+    w = init_unet_weights(params, 0)
+    flat, _ = legacy_state_dict(w, params)
+    with pytest.raises(ValueError, match="missing"):
+        UNet2D(params, "infer").load_state_dict(flat)                       # UNet_LEGACY names in a scoped net
+    with pytest.raises(ValueError, match="missing"):
+        UNet_LEGACY(params, "infer").load_state_dict(w)                     # ... and the other way round
+    with pytest.raises(ValueError, match="missing"):
+        UNet2D(dict(params, filters=(16, 32, 64)), "infer").load_state_dict(w)      # another depth
+    with pytest.raises(ValueError, match="shape mismatches"):
+        UNet2D(dict(params, filters=(16, 64)), "infer").load_state_dict(w)          # another filter schedule
+    wbn = init_unet_weights(dict(params, batch_norm=True), 0)
+    with pytest.raises(ValueError, match="unexpected"):
+        UNet2D(params, "infer").load_state_dict(wbn)                        # BN checkpoint, non-BN net
+    with pytest.raises(ValueError, match="missing"):
+        UNet2D(dict(params, batch_norm=True), "infer").load_state_dict(w)   # non-BN checkpoint, BN net
+    req, opt = UNet2D(dict(params, batch_norm=True), "infer").expected_variables()
+    assert set(req) == set(wbn) and "UNet/down0/conv1/moving_mean" in opt and len(opt) == 2 * 6
+    req, _ = UNet_LEGACY(params, "infer").expected_variables()
+    assert set(req) == set(flat)

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sequitr_amd.parallel import FlatBucket, allreduce_sum_, shard_range
+from sequitr_amd.parallel import FlatBucket, allreduce_sum_, shard_range, epoch_schedule
 
 
 def test_flat_bucket_views_share_storage_and_stay_aligned():
@@ -29,6 +29,45 @@ def test_shard_range_partitions_tiles():
         assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
         sizes = [e - b for b, e in r]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_epoch_schedule_same_step_count_on_every_rank_full_batches_only():
+    """63 tiles, world 2, batch 16 used to give rank 0 two steps and rank 1 one (a dead-locked all-reduce)."""
+    for n, batch, world in ((63, 16, 2), (64, 16, 2), (65, 16, 3), (129, 16, 8)):
+        order, steps = epoch_schedule(n, batch, world)
+        assert steps == (n // world) // batch
+        seen = [order(0, r) for r in range(world)]
+        assert all(len(o) == steps * batch for o in seen)                    # every rank: same count, full batches
+        allidx = np.concatenate(seen)
+        assert len(set(allidx.tolist())) == len(allidx) and allidx.max() < n  # disjoint shards of one permutation
+        assert not np.array_equal(order(0, 0), order(1, 0))                   # reshuffled every epoch
+    with pytest.raises(ValueError):
+        epoch_schedule(31, 16, 2)                                             # no rank may step with a short batch
+
+
+def _sched_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        order, steps = epoch_schedule(63, 16, world)                          # odd tile count
+        n = 0
+        for epoch in range(2):
+            idx = order(epoch, rank)
+            for s in range(steps):
+                t = torch.tensor([float(idx[s * 16:(s + 1) * 16].sum())])
+                allreduce_sum_(t)                                             # one collective per step, as trainer.step
+                n += 1
+        ret[rank] = n
+    finally:
+        dist.destroy_process_group()
+
+
+def test_odd_tile_count_does_not_desynchronise_the_allreduce():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sched_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: 2, 1: 2}
 
 
 def _free_port():

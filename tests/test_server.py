@@ -37,3 +37,20 @@ def test_server_runs_jobs_by_priority_and_marks_them_complete(tmp_path):
     for i in range(3):
         t = json.load(open(os.path.join(str(out), "JOB_job%d" % i, "test.json")))
         assert "tag" in t["params"]
+
+
+def test_failed_and_unparsable_jobs_are_told_apart_from_finished_ones(tmp_path):
+    """ADVICE r1 (server.reap): a job whose function raises (here: device = CPU, which this back end refuses loudly)
+    ends as .job.failed with a non-zero worker exit code; a .job file that cannot be parsed becomes .job.invalid and is
+    not polled (and logged) again every DELAY seconds; a good job still ends as .job.complete."""
+    jobs, out = tmp_path / "jobs", tmp_path / "out"
+    jobs.mkdir(), out.mkdir()
+    write_job(jobs, func="SERVER_test", params="{}", options="{}", ID="good", name="JOB_good.job")
+    write_job(jobs, func="SERVER_segment", params=repr({"input": {"synthetic": True}}), options="{}", ID="bad",
+              device="CPU", name="JOB_bad.job")
+    (jobs / "JOB_garbage.job").write_text("[job]\nID = x\n")               # header fields missing
+    srv = server.Server(str(jobs), str(out), gpus=[0], max_processes=2, delay=0.05)
+    done = dict(srv.serve(once=True))
+    assert done["good"] == 0 and done["bad"] != 0
+    assert sorted(os.listdir(str(jobs))) == ["JOB_bad.job.failed", "JOB_garbage.job.invalid", "JOB_good.job.complete"]
+    assert srv.pending() == []
