@@ -220,9 +220,13 @@ def pmc_traffic_per_launch():
     try:
         fn = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]   # newest round
         with open(fn) as f:
+            pmc_traffic_per_launch.source = os.path.relpath(fn, ROOT)
             return round(json.load(f)["_summary"]["conv_mfma_hbm_bytes_per_launch_avg"], 1)
     except Exception:
         return None
+
+
+pmc_traffic_per_launch.source = None
 
 
 def pmc_mfma_busy():
@@ -232,12 +236,16 @@ def pmc_mfma_busy():
     import glob
     try:
         fn = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_summary.json")))[-1]
+        pmc_mfma_busy.source = os.path.relpath(fn, ROOT)
         with open(fn) as f:
             d = json.load(f)
         return {k.replace("conv_mfma_f32_v2_kernel", "v2"): v["mfma_busy_frac"] for k, v in d.items()
                 if "mfma_busy_frac" in v and k.startswith("conv_mfma_f32_v2")}
     except Exception:
         return None
+
+
+pmc_mfma_busy.source = None
 
 
 def iou_per_class(a, b, nclass=2):
@@ -1081,6 +1089,8 @@ def main():
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": pmc_traffic_per_launch(),
                 "mfma_busy_pmc": pmc_mfma_busy(),
+                # PMC counters cannot be read inside the timed run: these two come from committed rocprofv3 passes
+                "pmc_source": {"traffic": pmc_traffic_per_launch.source, "mfma_busy_pmc": pmc_mfma_busy.source},
                 "launches_per_step": nlaunch // max(1, args.steps),
                 "kernel_ms_per_step": round(conv_ms / max(1, args.steps), 4),
                 "flops_per_step": conv_flops / max(1, args.steps),

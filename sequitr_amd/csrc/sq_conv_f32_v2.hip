@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
     float4 wr[C::WSLOTS];
     float inr[2];                                           // FIRST: 400 input pixels over 256 threads
     float4 lr[4];                                           // UP: 100 px x 8 float4 of the low-res patch over 256 threads
+    float4 sr[6];                                           // UP: the skip halo in the transpose conv's own fragment layout
 
     // Buffer resources: out-of-range offsets read as 0 / drop the store, so image borders,
     // ragged tiles and the "idx >= items" tail need no branches (hipcc otherwise wraps every
@@ -183,13 +184,31 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         } else {
             const int x0 = tx * TW - PAD, y0 = ty * TH - PAD;
             const int base = (((n * H + y0) * W + x0) * Cin + cc) * 4;     // may be "negative": wraps back
+            if constexpr (!UP) {
 #pragma unroll
-            for (int sl = 0; sl < C::XSLOTS; ++sl) {
-                const bool inb = live && (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
-                                 xrel[sl] != (int)OOB;
-                const unsigned off = inb ? (unsigned)(base + xrel[sl]) : OOB;
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
-                xr[sl] = *reinterpret_cast<const float4 *>(&v);
+                for (int sl = 0; sl < C::XSLOTS; ++sl) {
+                    const bool inb = live && (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
+                                     xrel[sl] != (int)OOB;
+                    const unsigned off = inb ? (unsigned)(base + xrel[sl]) : OOB;
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+                    xr[sl] = *reinterpret_cast<const float4 *>(&v);
+                }
+            } else {
+                // UP: the skip halo is fetched in the fragment layout of the transpose conv it will be merged with
+                // (wave = parity class, 6 blocks of 16 class pixels, lane (li, kk) = channels 4kk..4kk+3 of pixel li):
+                // the bridge then runs in registers and the merged value is written to LDS once.  The in-place merge
+                // (commit the skip halo, read it back, write the product) ran at 92 % LDS bank conflicts
+                // (profiles/r01u_pmc_sq_summary.json): 544 -> 505 us per launch.
+                const int oy = ((wv >> 1) + 1) & 1, ox = ((wv & 1) + 1) & 1;
+#pragma unroll
+                for (int blk = 0; blk < 6; ++blk) {
+                    const int j = blk * 16 + li;
+                    const int hy = 2 * (j / 9) + oy, hx = 2 * (j % 9) + ox;
+                    const bool inb = live && j < 81 && (unsigned)(y0 + hy) < (unsigned)H && (unsigned)(x0 + hx) < (unsigned)W;
+                    const unsigned off = inb ? (unsigned)(base + ((hy * W + hx) * Cin + 4 * kk) * 4) : OOB;
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+                    sr[blk] = *reinterpret_cast<const float4 *>(&v);
+                }
             }
         }
         if constexpr (UP) {
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
                 const int idx = tid + sl * 256;
                 if (idx < C::IN_FLOATS) xin[idx] = inr[sl];
             }
-        } else {
+        } else if constexpr (!UP) {
 #pragma unroll
             for (int sl = 0; sl < C::XSLOTS; ++sl) {
                 const int idx = tid + sl * 256;
@@ -303,7 +322,8 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         }
     };
 
-    // ---- UP: merged = bridge(convT2x2s2(up_x) + bias, skip) for the 18x18 halo, in place in the halo image.
+    // ---- UP: merged = bridge(convT2x2s2(up_x) + bias, skip) for the 18x18 halo, written straight into the halo image
+    // (the skip operand is already in this lane's registers, sr[blk]).
     // Wave w owns parity class (a, b) = (w >> 1, w & 1) of the transpose conv: its 81 halo pixels in 6 column
     // blocks of 16; per block 8 MFMA steps over the 32 input channels (one fmaf chain c = 0..31 per output,
     // then + bias, then the bridge: exactly sq_convT2x2s2_nhwc_fwd_f32 / the oracle).  A = the class's 16x32
@@ -320,7 +340,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         const int pa = wv >> 1, pb = wv & 1;
         // halo row hy has parity (hy + 1) & 1 (global row 16 ty - 1 + hy): class rows are hy = 2 jy + ((pa + 1) & 1)
         const int oy = (pa + 1) & 1, ox = (pb + 1) & 1;
-#pragma nounroll
+#pragma unroll
         for (int blk = 0; blk < 6; ++blk) {
             const int j = blk * 16 + li, jc = j < 81 ? j : 80;
             const int hy = 2 * (jc / 9) + oy, hx = 2 * (jc % 9) + ox;
@@ -332,9 +352,8 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
             const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
             if (j < 81) {
                 float *d = xs + (hy * C::HALO_W + hx) * C::PS + 4 * kk;
-                const float2 s01 = *reinterpret_cast<const float2 *>(d), s23 = *reinterpret_cast<const float2 *>(d + 2);
                 const float u[4] = {c1[0] + upb.x, c1[1] + upb.y, c1[2] + upb.z, c1[3] + upb.w};
-                const float sk[4] = {s01.x, s01.y, s23.x, s23.y};
+                const float sk[4] = {sr[blk].x, sr[blk].y, sr[blk].z, sr[blk].w};
                 float m[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
