@@ -370,6 +370,11 @@ int sq_bridge_bwd_s2d_bf16(const void *dy, const void *up, const void *skip, voi
 /* max-pool backward + the other gradient of the pooled tensor (the U-Net skip path): dx = scatter(dy) + add */
 int sq_maxpool2x2_bwd_add_bf16(const void *x, const void *dy, const void *add, void *dx, int N, int H, int W, int C,
                                void *stream);
+/* ... and through the gate of the conv block that produced x = dropout(ReLU(.)) (unet.py:265-277): dx = x > 0 ?
+ * (scatter(dy) + add) * gate_scale : 0, gate_scale = 1 / (1 - rate); 0 = no gate.  Replaces a stand-alone
+ * sq_relu_scale_bwd_bf16 pass bit for bit (x is already read for the arg-max). */
+int sq_maxpool2x2_bwd_add_gate_bf16(const void *x, const void *dy, const void *add, void *dx, int N, int H, int W, int C,
+                                    float gate_scale, void *stream);
 int sq_act_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, int act, void *stream);
 /* dropout backward + the backward of the activation in front of it, one pass:
  * dx = act'(y) * (mask ? dy / (1 - rate) : 0), y = the activation output that entered the dropout */
@@ -387,6 +392,9 @@ int sq_relu_scale_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, f
  * with the transposed packed filter, passed only where gate > 0 (the upstream ReLU backward fused in) */
 int sq_conv2d_nhwc_dgrad_relu_bf16(const void *dy, const void *wp_t, const void *gate, void *dx, int N, int H, int W,
                                    int Cin, int Cout, int K, void *stream);
+/* the same with a factor on what passes (backward of dropout(ReLU(.)) = `gate`): gate > 0 ? dgrad * gate_scale : 0 */
+int sq_conv2d_nhwc_dgrad_gate_bf16(const void *dy, const void *wp_t, const void *gate, float gate_scale, void *dx, int N,
+                                   int H, int W, int Cin, int Cout, int K, void *stream);
 int sq_bridge_fwd_bf16(const void *a, const void *b, void *y, int64_t n, int bridge, void *stream);
 int sq_bridge_bwd_bf16(const void *dy, const void *a, const void *b, void *da, void *db, int64_t n, int bridge,
                        void *stream);
@@ -410,6 +418,9 @@ int sq_conv1x1_head_fwd_bf16(const void *x, const float *w, const float *bias, f
 int64_t sq_conv1x1_head_bwd_workspace_bf16(int64_t npix, int Cin, int Cout);
 int sq_conv1x1_head_bwd_bf16(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db,
                              float *workspace, int64_t npix, int Cin, int Cout, void *stream);
+/* gate_scale > 0: x = dropout(ReLU(.)) of the last conv block; dx leaves through that gate (x > 0 ? dx * gate_scale : 0) */
+int sq_conv1x1_head_bwd_gate_bf16(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db,
+                                  float *workspace, int64_t npix, int Cin, int Cout, float gate_scale, void *stream);
 
 /* weight gradient of the first (Cin -> Cout, Cin 1..7) 3x3 convolution from the f32 image and a bf16 dY:
  * dW (3,3,Cin,Cout) f32, db (Cout) f32 or NULL */

@@ -41,6 +41,7 @@ struct SqDropEpi {
     float inv;
     unsigned seed;
     const int *step;
+    float gscale = 1.f;     // factor applied where the gate passes (1: plain ReLU backward; 1/(1-rate): dropout + ReLU)
 };
 
 __device__ __forceinline__ unsigned conv_hash32(unsigned a, unsigned b) {       // = hash32 of sq_ops_bf16.hip
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                 o[3] = (__bf16)actf(acc[r][nb][3] + bv.w);
                 if (gate) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (float)gv[r][j] > 0.f ? o[j] : (__bf16)0.f;
+                    for (int j = 0; j < 4; ++j)         // bf16(o * 1.0f) == o: the plain ReLU gate costs no rounding
+                        o[j] = (float)gv[r][j] > 0.f ? (__bf16)((float)o[j] * drop.gscale) : (__bf16)0.f;
                 }
                 if (drop.thr) {
                     const unsigned e0 = offs[r] >> 1;          // flat element index (offsets are in bytes)
@@ -610,6 +612,18 @@ extern "C" int sq_conv2d_nhwc_dgrad_relu_bf16(const void *dy, const void *wp_t, 
                                               int W, int Cin, int Cout, int K, void *stream) {
     SQ_REQUIRE(gate, "sq_conv2d_nhwc_dgrad_relu_bf16: null gate");
     return conv_fwd_bf16_impl(dy, wp_t, nullptr, dx, N, H, W, Cin, Cout, K, SQ_ACT_NONE, stream, gate);
+}
+
+// the same with a factor on what passes: dx = gate > 0 ? bf16(bf16(dgrad) * gate_scale) : 0 -- the backward of
+// dropout(ReLU(.)) whose output is `gate` (gate > 0 <=> kept and active, gate_scale = 1 / (1 - rate)), with the two
+// roundings of the stand-alone sq_relu_scale_bwd_bf16 pass it replaces (bit-identical to dgrad followed by that pass).
+extern "C" int sq_conv2d_nhwc_dgrad_gate_bf16(const void *dy, const void *wp_t, const void *gate, float gate_scale,
+                                              void *dx, int N, int H, int W, int Cin, int Cout, int K, void *stream) {
+    SQ_REQUIRE(gate, "sq_conv2d_nhwc_dgrad_gate_bf16: null gate");
+    SQ_REQUIRE(gate_scale > 0.f, "sq_conv2d_nhwc_dgrad_gate_bf16: gate_scale must be positive");
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    d.gscale = gate_scale;
+    return conv_fwd_bf16_impl(dy, wp_t, nullptr, dx, N, H, W, Cin, Cout, K, SQ_ACT_NONE, stream, gate, d);
 }
 
 // first conv of down0 in the bf16 graph: f32 image (1..7 channels) in, bf16 activation out.

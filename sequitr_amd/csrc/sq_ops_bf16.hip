@@ -178,9 +178,12 @@ __global__ __launch_bounds__(256) void bridge_bwd_s2d_bf16_kernel(const bf16x8 *
 
 // max-pool backward that also adds a second gradient of the pooled tensor's INPUT (the skip path of the
 // U-Net): dx = scatter(dy) + add, the bf16 sum torch's gradient accumulation would form in its own kernel
+// gscale > 0: x is the dropout(ReLU(.)) output of the conv block in front of the pool, and the gradient is handed on
+// already through that gate, dx = (x > 0) ? bf16(bf16(scatter + add) * gscale) : 0 -- the two roundings of the
+// stand-alone sq_relu_scale_bwd_bf16 pass it replaces (same bits), with x already in registers for the arg-max.
 __global__ __launch_bounds__(256) void maxpool_bwd_add_bf16_kernel(const bf16x8 *__restrict__ x, const bf16x8 *__restrict__ dy,
                                                                     const bf16x8 *__restrict__ add, bf16x8 *__restrict__ dx,
-                                                                    int N, int H, int W, int C8) {
+                                                                    int N, int H, int W, int C8, float gscale) {
     const int Ho = H >> 1, Wo = W >> 1;
     const int64_t total = (int64_t)N * Ho * Wo * C8;
     SQ_GRID_STRIDE(i, total) {
@@ -207,6 +210,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_bf16_kernel(const bf16x8 
             rb[j] = (__bf16)((k == 1 ? gg : 0.f) + (float)sb[j]);
             rd[j] = (__bf16)((k == 2 ? gg : 0.f) + (float)sd[j]);
             re[j] = (__bf16)((k == 3 ? gg : 0.f) + (float)se[j]);
+            if (gscale > 0.f) {
+                ra[j] = (float)a[j] > 0.f ? (__bf16)((float)ra[j] * gscale) : (__bf16)0.f;
+                rb[j] = (float)b[j] > 0.f ? (__bf16)((float)rb[j] * gscale) : (__bf16)0.f;
+                rd[j] = (float)d[j] > 0.f ? (__bf16)((float)rd[j] * gscale) : (__bf16)0.f;
+                re[j] = (float)e[j] > 0.f ? (__bf16)((float)re[j] * gscale) : (__bf16)0.f;
+            }
         }
         dx[b00] = ra; dx[b01] = rb; dx[b10] = rd; dx[b11] = re;
     }
@@ -398,7 +407,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
                                                              const float *__restrict__ dz, __bf16 *__restrict__ dx,
-                                                             float *__restrict__ partials, int64_t npix) {
+                                                             float *__restrict__ partials, int64_t npix, float gscale) {
     constexpr int NVAL = CIN * COUT + COUT;
     __shared__ float red[4][NVAL];
     float gw[CIN][COUT], gb[COUT];
@@ -428,6 +437,9 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const __bf16 *__rest
                         gw[c8 * 8 + j][o] = __builtin_fmaf((float)v[j], g[o], gw[c8 * 8 + j][o]);
                     }
                     r[j] = (__bf16)s;
+                    // gscale > 0: x is a dropout(ReLU(.)) block output; dx leaves already through that gate (the
+                    // two roundings of the sq_relu_scale_bwd_bf16 pass this replaces)
+                    if (gscale > 0.f) r[j] = (float)v[j] > 0.f ? (__bf16)((float)r[j] * gscale) : (__bf16)0.f;
                 }
                 if (dx) *reinterpret_cast<bf16x8 *>(dx + p * CIN + c8 * 8) = r;
             }
@@ -507,13 +519,18 @@ extern "C" int sq_maxpool2x2_bwd_bf16(const void *x, const void *dy, void *dx, i
 }
 extern "C" int sq_maxpool2x2_bwd_add_bf16(const void *x, const void *dy, const void *add, void *dx, int N, int H, int W,
                                           int C, void *stream) {
+    return sq_maxpool2x2_bwd_add_gate_bf16(x, dy, add, dx, N, H, W, C, 0.f, stream);
+}
+extern "C" int sq_maxpool2x2_bwd_add_gate_bf16(const void *x, const void *dy, const void *add, void *dx, int N, int H,
+                                               int W, int C, float gate_scale, void *stream) {
     SQ_REQUIRE(x && dy && add && dx, "sq_maxpool2x2_bwd_add_bf16: null tensor pointer");
+    SQ_REQUIRE(gate_scale >= 0.f, "sq_maxpool2x2_bwd_add_gate_bf16: gate_scale must be >= 0 (0 = no gate)");
     SQ_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0,
                "sq_maxpool2x2_bwd_add_bf16: H, W even, C %% 8 == 0");
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(add); SQ_REQUIRE_ALIGNED(dx);
     hipLaunchKernelGGL(maxpool_bwd_add_bf16_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0,
                        SQ_ST(stream), reinterpret_cast<const bf16x8 *>(x), reinterpret_cast<const bf16x8 *>(dy),
-                       reinterpret_cast<const bf16x8 *>(add), reinterpret_cast<bf16x8 *>(dx), N, H, W, C / 8);
+                       reinterpret_cast<const bf16x8 *>(add), reinterpret_cast<bf16x8 *>(dx), N, H, W, C / 8, gate_scale);
     return sq_check_launch("sq_maxpool2x2_bwd_add_bf16");
 }
 extern "C" int sq_bridge_bwd_s2d_bf16(const void *dy, const void *up, const void *skip, void *g, void *dskip, int N, int H,
@@ -651,11 +668,17 @@ extern "C" int64_t sq_conv1x1_head_bwd_workspace_bf16(int64_t npix, int Cin, int
 
 extern "C" int sq_conv1x1_head_bwd_bf16(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db,
                                         float *workspace, int64_t npix, int Cin, int Cout, void *stream) {
+    return sq_conv1x1_head_bwd_gate_bf16(x, w, dz, dx, dw, db, workspace, npix, Cin, Cout, 0.f, stream);
+}
+extern "C" int sq_conv1x1_head_bwd_gate_bf16(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db,
+                                             float *workspace, int64_t npix, int Cin, int Cout, float gate_scale,
+                                             void *stream) {
     SQ_REQUIRE(x && w && dz && dw && workspace && npix > 0, "sq_conv1x1_head_bwd_bf16: null pointer");
+    SQ_REQUIRE(gate_scale >= 0.f, "sq_conv1x1_head_bwd_gate_bf16: gate_scale must be >= 0 (0 = no gate)");
     SQ_REQUIRE((Cin == 16 || Cin == 32) && Cout >= 1 && Cout <= 5, "sq_conv1x1_head_bwd_bf16: Cin=%d (16|32), Cout=%d (1..5)", Cin, Cout);
     const int nb = head_blocks(npix);
     hipStream_t st = SQ_ST(stream);
-#define SQ_HEAD_BWD(CI, CO) hipLaunchKernelGGL((head_bwd_bf16_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix)
+#define SQ_HEAD_BWD(CI, CO) hipLaunchKernelGGL((head_bwd_bf16_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix, gate_scale)
     if (Cin == 16) {
         switch (Cout) {
         case 1: SQ_HEAD_BWD(16, 1); break;

@@ -10,7 +10,6 @@ from . import ops_bf16 as ob
 from .functional import grad_sink, convT_param_grads
 
 
-
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, act):
@@ -65,6 +64,33 @@ def conv3x3_first(x, w, bias, act='relu'):
     return _ConvFirst.apply(x, w, bias, act)
 
 
+class BlockGate(object):
+    """The backward gate of a conv block's output, out = dropout(ReLU(conv2)): d(pre-activation) = out > 0 ?
+    d(out) * scale : 0 (scale = 1 / (1 - rate); 1 without dropout).  It is a pointwise function of `out` alone, so
+    the kernel that PRODUCES d(out) can apply it in its epilogue -- every such kernel reads `out` anyway or for 2
+    bytes per element -- instead of a stand-alone pass (read d(out), read out, write: sq_relu_scale_bwd_bf16, 7 %
+    of the step).  conv_block() hangs one of these on its output; the tape entries that consume that tensor as
+    their ONLY differentiable use (the pool + skip junction pair of an encoder level, the transpose conv of the
+    next decoder level, the 1x1 head) pick it up, apply the gate and set `applied`; _ConvBlock.backward then skips
+    its own pass.  Same two bf16 roundings as the stand-alone pass: the gradients are bit-identical."""
+
+    def __init__(self, scale):
+        self.scale, self.applied = float(scale), False
+
+    def take(self):
+        """the consumer's side: returns the factor to apply and marks the gate as applied"""
+        self.applied = True
+        return self.scale
+
+
+def _gate_of(t):
+    g = getattr(t, '_sq_gate', None)
+    return g if isinstance(g, BlockGate) else None
+
+
+FUSE_GATE = __import__("os").environ.get("SQ_FUSE_GATE", "1") != "0"    # A/B switch
+
+
 class _ConvBlock(torch.autograd.Function):
     """conv_block of the U-Net (sequitr/networks/unet.py:265-277) as ONE tape entry:
     relu(conv1) -> relu(conv2) -> dropout.  The two activations between the three ops have exactly one
@@ -74,8 +100,9 @@ class _ConvBlock(torch.autograd.Function):
     x is the bf16 block input, or the f32 single-channel image for down0."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, rate, seed, mask, step_dev):
+    def forward(ctx, x, w1, b1, w2, b2, rate, seed, mask, step_dev, gate):
         first = x.dtype == torch.float32
+        ctx.gate = gate
         f = w1.shape[3]
         y1 = ob.conv3x3_first(x, w1, b1, act='relu') if first else ob.conv2d(x, ob.pack_weights(w1), b1, 3, f, act='relu')
         m = y2 = None
@@ -99,7 +126,12 @@ class _ConvBlock(torch.autograd.Function):
         s1w, s1b, s2w, s2b = ctx.sinks
         f = w2.shape[3]
         dout = dout.contiguous()
-        if m is not None:
+        pre = ctx.gate is not None and ctx.gate.applied
+        if ctx.gate is not None:
+            ctx.gate.applied = False
+        if pre:
+            d2 = dout                                           # the producer of dout applied the gate (BlockGate)
+        elif m is not None:
             d2 = ob.act_dropout_bwd(dout, m, y2, ctx.rate, 'relu')
         elif ctx.rate > 0.0:
             inv = float(np.float32(1.0) / (np.float32(1.0) - np.float32(ctx.rate)))    # as the kernels compute it
@@ -115,11 +147,18 @@ class _ConvBlock(torch.autograd.Function):
             dw1, db1 = ob.conv2d_wgrad(x, d1, 3, want_bias=True, dw_out=s1w, db_out=s1b)
             dx = ob.conv2d(d1, ob.pack_weights(w1, transform=True), None, 3, x.shape[3]) if ctx.needs_input_grad[0] else None
         return (dx, None if s1w is not None else dw1, None if s1b is not None else db1,
-                None if s2w is not None else dw2, None if s2b is not None else db2, None, None, None, None)
+                None if s2w is not None else dw2, None if s2b is not None else db2, None, None, None, None, None)
 
 
 def conv_block(x, w1, b1, w2, b2, rate=0.0, seed=0, mask=None, step_dev=None):
-    return _ConvBlock.apply(x, w1, b1, w2, b2, float(rate), int(seed), mask, step_dev)
+    gate = None
+    if FUSE_GATE and mask is None:                               # pinned masks keep the separate mask kernels
+        rate = float(rate)
+        gate = BlockGate(float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) if rate > 0.0 else 1.0)
+    out = _ConvBlock.apply(x, w1, b1, w2, b2, float(rate), int(seed), mask, step_dev, gate)
+    if gate is not None:
+        out._sq_gate = gate
+    return out
 
 
 class _MaxPool(torch.autograd.Function):
@@ -129,9 +168,9 @@ class _MaxPool(torch.autograd.Function):
     instead of two that autograd would have to sum in an extra kernel."""
 
     @staticmethod
-    def forward(ctx, x, box):
+    def forward(ctx, x, box, gate):
         ctx.save_for_backward(x)
-        ctx.box = box
+        ctx.box, ctx.gate = box, gate
         return ob.maxpool2x2(x)
 
     @staticmethod
@@ -140,12 +179,15 @@ class _MaxPool(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         other = ctx.box.pop('dskip', None) if ctx.box is not None else None
         if other is not None:
-            return ob.maxpool2x2_bwd_add(x, dy.contiguous(), other), None
-        return ob.maxpool2x2_bwd(x, dy.contiguous()), None
+            # x has exactly two differentiable uses, this pool and the junction whose gradient is `other`: the sum is
+            # the whole gradient of x, so the block gate of x (if it is a conv block's output) is applied here too
+            gs = ctx.gate.take() if ctx.gate is not None else 0.0
+            return ob.maxpool2x2_bwd_add(x, dy.contiguous(), other, gate_scale=gs), None, None
+        return ob.maxpool2x2_bwd(x, dy.contiguous()), None, None
 
 
 def maxpool2x2(x, box=None):
-    return _MaxPool.apply(x, box)
+    return _MaxPool.apply(x, box, _gate_of(x) if box is not None else None)
 
 
 _UPJ_BOTH = __import__("os").environ.get("SQ_UPJ_BOTH", "1") != "0"   # A/B: dual-output convT+bridge kernel
@@ -158,7 +200,8 @@ class _UpJunction(torch.autograd.Function):
     skip tensor's pool shares a `box`, hands d_skip to that pool's backward instead of to autograd."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, skip, kind, box):
+    def forward(ctx, x, w, bias, skip, kind, box, gate):
+        ctx.gate = gate
         if kind == 'eltwise_mul' and _UPJ_BOTH:                 # `up` is needed by the backward: both from one pass
             up, merged = ob.convT2x2s2_bridge_both(x, ob.to_bf16(w), bias, skip, kind)
         elif kind == 'eltwise_mul':
@@ -184,17 +227,22 @@ class _UpJunction(torch.autograd.Function):
             wp = packs.get('convT_dgrad')
             if wp is None:
                 wp = ob.pack_weights(w.reshape(1, 1, 4 * Cout, Cin))
-            dx = ob.conv2d(g, wp, None, 1, Cin)
+            if ctx.gate is not None:        # x = the previous block's output, used here only: its gate in the epilogue
+                dx = ob.conv2d_dgrad_relu(g, wp, x, 1, scale=ctx.gate.take())
+            else:
+                dx = ob.conv2d(g, wp, None, 1, Cin)
         dwp, dbp = ob.conv2d_wgrad(x, g, 1, want_bias=ctx.has_bias)
         dw, db = convT_param_grads(dwp, dbp if ctx.has_bias else None, Cin, Cout, ctx.sinks)
         if ctx.box is not None and ctx.needs_input_grad[3]:
             ctx.box['dskip'] = dskip                            # picked up by the skip tensor's pool backward
             dskip = None
-        return dx, dw, db, dskip, None, None
+        return dx, dw, db, dskip, None, None, None
 
 
-def up_junction(x, w, bias, skip, kind, box=None):
-    return _UpJunction.apply(x, w, bias, skip, kind, box)
+def up_junction(x, w, bias, skip, kind, box=None, x_single_use=False):
+    """x_single_use: the caller guarantees this junction is the only differentiable consumer of x (U-Net wiring:
+    net[-1] feeds the next up_layer and nothing else), which lets x's block gate ride in the dgrad epilogue."""
+    return _UpJunction.apply(x, w, bias, skip, kind, box, _gate_of(x) if x_single_use else None)
 
 
 class _ConvT(torch.autograd.Function):
@@ -271,8 +319,9 @@ class _Head(torch.autograd.Function):
     """to_image on a bf16 activation: f32 logits out, f32 dlogits in."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, gate):
         logits, _ = ob.head_fwd(x, w, bias, want_mask=False)
+        ctx.gate = gate
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.sinks = (grad_sink(w), grad_sink(bias))
@@ -283,10 +332,11 @@ class _Head(torch.autograd.Function):
     def backward(ctx, dz):
         x, w = ctx.saved_tensors
         sw, sb = ctx.sinks
+        gs = ctx.gate.take() if (ctx.gate is not None and ctx.needs_input_grad[0]) else 0.0
         dx, dw, db = ob.head_bwd(x, w, dz.contiguous(), want_dx=ctx.needs_input_grad[0], dw_out=sw,
-                                 db_out=sb if ctx.has_bias else None)
-        return dx, (None if sw is not None else dw), (db if ctx.has_bias and sb is None else None)
+                                 db_out=sb if ctx.has_bias else None, gate_scale=gs)
+        return dx, (None if sw is not None else dw), (db if ctx.has_bias and sb is None else None), None
 
 
-def conv1x1_head(x, w, bias=None):
-    return _Head.apply(x, w, bias)
+def conv1x1_head(x, w, bias=None, x_single_use=False):
+    return _Head.apply(x, w, bias, _gate_of(x) if x_single_use else None)

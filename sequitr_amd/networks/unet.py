@@ -706,7 +706,8 @@ class UNet2DBf16(UNet2D):
     def conv_layer_1x1(self, x, filters):
         w, b = self._kernel((1, 1, x.shape[-1], filters)), self._bias(filters)
         if self.training:
-            return FB.conv1x1_head(x, w, b)
+            # build() hands the last block's output to the head and to nothing else (unet.py:252-253)
+            return FB.conv1x1_head(x, w, b, x_single_use=x is self._net[-1])
         from .. import ops_bf16 as ob
         logits, self._mask = ob.head_fwd(x, w, b)
         return logits
@@ -741,7 +742,8 @@ class UNet2DBf16(UNet2D):
                 w, b = self._kernel((2, 2, filters, x.shape[-1])), self._bias(filters)
             entry = self._skip_boxes.get(id(bridge))
             box = entry[1] if entry is not None and entry[0] is bridge else None
-            merged = FB.up_junction(x, w, b, bridge, self.bridge_type, box)
+            # build() feeds net[-1] to this up_layer only (unet.py:248): its block gate can ride in the dgrad epilogue
+            merged = FB.up_junction(x, w, b, bridge, self.bridge_type, box, x_single_use=x is self._net[-1])
             out = self.conv_block(merged, filters)
         return out
 

@@ -78,8 +78,9 @@ def relu_scale_bwd(dy, y, scale):
     return dx
 
 
-def conv2d_dgrad_relu(dy, wp_t, gate, K):
-    """dX of a conv whose input was the ReLU output `gate`: conv(dy, wp_t) passed where gate > 0."""
+def conv2d_dgrad_relu(dy, wp_t, gate, K, scale=1.0):
+    """dX of a conv whose input was the ReLU output `gate`: conv(dy, wp_t) passed where gate > 0; scale != 1: the
+    input was dropout(ReLU(.)) = `gate` and what passes is multiplied by scale = 1 / (1 - rate)."""
     _chk(dy, "dy", ndim=4), _chk(wp_t, "wp_t"), _chk(gate, "gate", ndim=4)
     N, H, W, Cin = dy.shape
     Cout = gate.shape[3]
@@ -87,8 +88,12 @@ def conv2d_dgrad_relu(dy, wp_t, gate, K):
         raise ValueError("gate %s does not match dy %s" % (tuple(gate.shape), tuple(dy.shape)))
     dx = torch.empty((N, H, W, Cout), dtype=BF16, device=dy.device)
     lib = _lib.load()
-    _lib.check(lib.sq_conv2d_nhwc_dgrad_relu_bf16(_ptr(dy), _ptr(wp_t), _ptr(gate), _ptr(dx), N, H, W, Cin, Cout, K,
-                                                 _stream()), "sq_conv2d_nhwc_dgrad_relu_bf16")
+    if scale == 1.0:
+        _lib.check(lib.sq_conv2d_nhwc_dgrad_relu_bf16(_ptr(dy), _ptr(wp_t), _ptr(gate), _ptr(dx), N, H, W, Cin, Cout, K,
+                                                     _stream()), "sq_conv2d_nhwc_dgrad_relu_bf16")
+    else:
+        _lib.check(lib.sq_conv2d_nhwc_dgrad_gate_bf16(_ptr(dy), _ptr(wp_t), _ptr(gate), float(scale), _ptr(dx), N, H, W,
+                                                     Cin, Cout, K, _stream()), "sq_conv2d_nhwc_dgrad_gate_bf16")
     return dx
 
 
@@ -323,14 +328,15 @@ def bridge_bwd_s2d(dy, up, skip, kind):
     return g, dskip
 
 
-def maxpool2x2_bwd_add(x, dy, add):
-    """max-pool backward plus a second gradient of x (same shape as x), one pass."""
+def maxpool2x2_bwd_add(x, dy, add, gate_scale=0.0):
+    """max-pool backward plus a second gradient of x (same shape as x), one pass.  gate_scale > 0: x is a
+    dropout(ReLU(.)) block output and the sum leaves through that gate (x > 0 ? sum * gate_scale : 0)."""
     _chk(x, "x", ndim=4), _chk(dy, "dy", ndim=4), _chk(add, "add", ndim=4)
     N, H, W, C = x.shape
     dx = torch.empty_like(x)
     lib = _lib.load()
-    _lib.check(lib.sq_maxpool2x2_bwd_add_bf16(_ptr(x), _ptr(dy), _ptr(add), _ptr(dx), N, H, W, C, _stream()),
-               "sq_maxpool2x2_bwd_add_bf16")
+    _lib.check(lib.sq_maxpool2x2_bwd_add_gate_bf16(_ptr(x), _ptr(dy), _ptr(add), _ptr(dx), N, H, W, C, float(gate_scale),
+                                                  _stream()), "sq_maxpool2x2_bwd_add_gate_bf16")
     return dx
 
 
@@ -357,7 +363,7 @@ def head_fwd(x, w, bias, want_mask=True):
     return logits, mask
 
 
-def head_bwd(x, w, dz, want_dx=True, dw_out=None, db_out=None):
+def head_bwd(x, w, dz, want_dx=True, dw_out=None, db_out=None, gate_scale=0.0):
     _chk(x, "x", ndim=4), _chk(dz, "dz", dtype=torch.float32)
     N, H, W, Cin = x.shape
     Cout = w.shape[3]
@@ -367,8 +373,8 @@ def head_bwd(x, w, dz, want_dx=True, dw_out=None, db_out=None):
     dx = torch.empty_like(x) if want_dx else None
     dw = _grad_out(dw_out, (1, 1, Cin, Cout), x.device)
     db = _grad_out(db_out, (Cout,), x.device)
-    _lib.check(lib.sq_conv1x1_head_bwd_bf16(_ptr(x), _ptr(w), _ptr(dz), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), npix, Cin,
-                                           Cout, _stream()), "sq_conv1x1_head_bwd_bf16")
+    _lib.check(lib.sq_conv1x1_head_bwd_gate_bf16(_ptr(x), _ptr(w), _ptr(dz), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), npix,
+                                                Cin, Cout, float(gate_scale), _stream()), "sq_conv1x1_head_bwd_gate_bf16")
     return dx, dw, db
 
 
