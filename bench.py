@@ -248,6 +248,58 @@ def pmc_mfma_busy():
 pmc_mfma_busy.source = None
 
 
+def o1_weights(params, seed=0, gain=1.35, bias_std=0.05):
+    """Non-degenerate parity fixture: the seeded initial weights with every 3x3 kernel scaled by
+    `gain` and seeded N(0, bias_std) biases.  With variance_scaling kernels, zero biases and eltwise_mul bridges the
+    benchmark net's logits are ~1e-5 (positively homogeneous of degree ~39 in the kernel scale); gain 1.35 puts them at
+    std ~ 1, max ~ 10, and the biases break the homogeneity, so tolerance statements (north_star: logits within 1e-3)
+    and IoU figures are made on logits of order one.  A deterministic function of (params, seed): no file."""
+    from sequitr_amd.networks.unet import init_unet_weights
+    w = init_unet_weights(params, seed)
+    rng = np.random.default_rng(seed + 7)
+    for k in sorted(w):
+        if k.endswith("kernel") and "upscale" not in k and "to_image" not in k:
+            w[k] = (w[k] * np.float32(gain)).astype(np.float32)
+        elif k.endswith("bias"):
+            w[k] = (rng.standard_normal(w[k].shape) * bias_std).astype(np.float32)
+    return w
+
+
+def parity_on_o1_fixture(params, device, with_cpu=True):
+    """IoU / logits parity of the GPU path on the O(1)-logit fixture: (a) one 512x512 tile against the C oracle
+    (oracle/sq_oracle.c: bit-exact logits and mask expected), (b) 8 tiles against the torch-oneDNN CPU restatement
+    (another summation order: logits within 1e-3, masks equal except near-ties), with the near-tie pixel counts SURVEY 7
+    asks for (|z1 - z0| below 1e-3 / 1e-6)."""
+    from oracle import unet_oracle
+    from oracle.torch_ref import TorchCpuUNet
+    from sequitr_amd.networks.unet import UNet2D
+    w = o1_weights(params)
+    net = UNet2D(dict(params, device=str(device)), "infer")
+    net.load_state_dict(w)
+    xb = np.random.default_rng(11).standard_normal((8, TILE, TILE, 1)).astype(np.float32)
+    gmask = net.predict(torch.from_numpy(xb).to(device)).cpu().numpy()
+    glog = net.logits().cpu().numpy()
+    gap = np.abs(glog[..., 1] - glog[..., 0])
+    out = {"weights": "bench.o1_weights(seed 0, gain 1.35, bias std 0.05)", "logits_std": float("%.3g" % glog.std()),
+           "logits_max_abs": float("%.3g" % np.abs(glog).max()), "foreground_fraction": round(float(gmask.mean()), 4),
+           "near_tie_pixels": {"below_1e-3": int((gap < 1e-3).sum()), "below_1e-6": int((gap < 1e-6).sum()),
+                               "of": int(gap.size)}}
+    ref = unet_oracle.unet_forward(xb[:1], w, params)                         # ~5 s of scalar C on one tile
+    out["vs_c_oracle_one_tile"] = {"logits_bit_exact": bool(np.array_equal(glog[:1], ref)),
+                                   "mask_bit_exact": bool(np.array_equal(gmask[:1], unet_oracle.predict_mask(ref))),
+                                   "logits_max_abs_diff": float(np.abs(glog[:1] - ref).max())}
+    if with_cpu:
+        threads = int(os.environ.get("SQ_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+        cl = TorchCpuUNet(w, params, threads=threads)(xb)
+        cm = np.argmax(cl, -1).astype(np.uint8)
+        diff = gmask != cm
+        out["vs_cpu_onednn_8_tiles"] = {"iou_per_class": [round(v, 6) for v in iou_per_class(gmask, cm)],
+                                        "pixels_differing": int(diff.sum()),
+                                        "largest_gap_at_a_differing_pixel": float(gap[diff].max()) if diff.any() else 0.0,
+                                        "logits_max_abs_diff": float("%.3g" % np.abs(glog - cl).max())}
+    return out
+
+
 def iou_per_class(a, b, nclass=2):
     out = []
     for c in range(nclass):
@@ -744,7 +796,7 @@ def main_infer_bf16(args):
     from sequitr_amd.networks.unet import UNet2D, UNet2DBf16, init_unet_weights
     params = {"shape": (TILE, TILE), "num_inputs": 1, "num_outputs": 2, "filters": FILTERS, "bridge": "eltwise_mul",
               "device": str(dev)}
-    weights = init_unet_weights(params, seed=0)
+    weights = o1_weights(params)          # logits of order one: the IoU is about bf16, not about 1e-5-sized near-ties
     x = torch.from_numpy(np.random.default_rng(1).standard_normal((BATCH, TILE, TILE, 1)).astype(np.float32)).to(dev)
     ref = UNet2D(params, "infer")
     ref.load_state_dict(weights)
@@ -1103,6 +1155,10 @@ def main():
             except Exception as e:                              # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+            try:                                                # IoU / logits parity on logits of order one
+                out["parity_o1"] = parity_on_o1_fixture(params, dev)
+            except Exception as e:                              # noqa: BLE001
+                out["parity_o1"] = {"failed": repr(e)}
         if world == 1 and not args.no_end_to_end:
             try:
                 out["end_to_end"] = end_to_end_rate(net, x)

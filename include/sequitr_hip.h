@@ -280,6 +280,12 @@ int sq_wgrad1x1_small_f32(const float *a, const float *b, float *m, float *works
  * Fused inference variants of the 3x3 convolution (bit-identical to the unfused sequence).
  * ---------------------------------------------------------------------------------------- */
 
+/* conv_layer on the concat bridge (sequitr/networks/unet.py:196-197, 321): y = act(conv(concat([xa, xb], -1)) + bias);
+ * xa, xb (N,H,W,Ca) each (the up-scaled tensor first, the skip tensor second), w (K,K,2*Ca,Cout); the concatenated
+ * tensor is never written.  Bit-identical to sq_conv2d_nhwc_fwd_f32 on the materialised concat. */
+int sq_conv2d_concat_nhwc_fwd_f32(const float *xa, const float *xb, const float *w, const float *bias, float *y, int N,
+                                  int H, int W, int Ca, int Cout, int K, int act, void *stream);
+
 /* conv_block tail + max_pool_layer (sequitr/networks/unet.py:241-243,265-277): 3x3 conv + bias + act
  * that writes y (N,H,W,Cout) AND its 2x2 max-pool (N,H/2,W/2,Cout) from the same accumulators. */
 int sq_conv3x3_pool_fwd_f32(const float *x, const float *w, const float *bias, float *y, float *pooled,

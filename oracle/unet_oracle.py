@@ -21,8 +21,6 @@ def unet_forward(x, weights, params=None, return_net=False):
     params = params or {}
     filters = tuple(params.get("filters", DEFAULT_FILTERS))
     bridge = params.get("bridge", "eltwise_mul")               # unet.py:138
-    if bridge == "concat":
-        raise NotImplementedError("concat bridge is restated in torch_ref only")
 
     bn = bool(params.get("batch_norm", False))                 # SURVEY A.1 optional BN, inference form
     eps = float(params.get("bn_epsilon", 1e-3))
@@ -51,6 +49,9 @@ def unet_forward(x, weights, params=None, return_net=False):
             up = convT3x3s2(net[-1], weights[s + "/upscale/kernel"], weights[s + "/upscale/bias"])
             up = {"eltwise_add": up + net[i], "eltwise_mul": up * net[i], "eltwise_sub": up - net[i],
                   None: up}[bridge]
+        elif bridge == "concat":                                # unet.py:196-197: tf.concat([upscale, skip], -1)
+            up = co.convT2x2s2(net[-1], weights[s + "/upscale/kernel"], weights[s + "/upscale/bias"])
+            up = np.ascontiguousarray(np.concatenate([up, net[i]], axis=-1))
         else:
             up = co.convT2x2s2(net[-1], weights[s + "/upscale/kernel"], weights[s + "/upscale/bias"],
                                skip=net[i], bridge=bridge)     # unet.py:312-319

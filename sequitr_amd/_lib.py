@@ -83,6 +83,7 @@ SIGNATURES = {
     "sq_mbstd_fwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_int64, c_void_p]),
     "sq_wgrad1x1_small_workspace_f32": (c_int64, [c_int64, c_int, c_int]),
     "sq_wgrad1x1_small_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
+    "sq_conv2d_concat_nhwc_fwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "sq_conv3x3_pool_fwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "sq_conv3x3_head_fwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     "sq_conv3x3_first_block_fwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),

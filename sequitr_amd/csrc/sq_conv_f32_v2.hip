@@ -44,6 +44,8 @@ struct SqConvEpi {
     const float *up_w;      //          transpose-conv kernel (2,2,16,32) and bias (16)
     const float *up_b;
     int up_bridge;          //          SQ_BRIDGE_*: merged = bridge(convT(up_x), x)
+    const float *x2;        // concat bridge (unet.py:196-197): channels [Cin/2, Cin) of the input come from this second
+                            // tensor (N,H,W,Cin/2), channels [0, Cin/2) from x: tf.concat([upscale, skip], -1) never exists
 };
 
 namespace {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
     // predicated load in its own s_cbranch_execz block and the loads stop overlapping).
     // All descriptor inputs are kernel arguments => provably wave-uniform (no waterfall loop).
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(x), 0, (int)((size_t)N * H * W * (FIRST ? 1 : Cin) * 4), 0x00020000);
+        const_cast<float *>(x), 0, (int)((size_t)N * H * W * (FIRST ? 1 : (epi.x2 ? Cin / 2 : Cin)) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(w), 0, KS * KS * (FIRST ? 16 : Cin) * Cout * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -143,6 +145,10 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         const_cast<float *>(epi.up_x), 0, UP ? (int)((size_t)N * (H / 2) * (W / 2) * C::UP_CIN * 4) : 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;   // tensors are < 2 GiB (checked on the host)
     const int CinW = FIRST ? 16 : Cin;      // input channels of the MFMA convolution
+    // two-source input (concat bridge): both tensors carry Cs = Cin / 2 channels; a 16-channel chunk lies wholly in one
+    const int Cs = epi.x2 ? Cin / 2 : Cin;
+    const __amdgpu_buffer_rsrc_t x2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(epi.x2), 0, epi.x2 ? (int)((size_t)N * H * W * Cs * 4) : 0, 0x00020000);
 
     // per-thread, tile-independent part of the halo addresses
     int xrel[C::XSLOTS], xpy[C::XSLOTS], xpx[C::XSLOTS];
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         const int pix = idx / C::QPP, q = idx % C::QPP;
         xpy[sl] = pix / C::HALO_W;
         xpx[sl] = pix % C::HALO_W;
-        xrel[sl] = idx < C::XITEMS ? ((xpy[sl] * W + xpx[sl]) * Cin + q * 4) * 4 : (int)OOB;
+        xrel[sl] = idx < C::XITEMS ? ((xpy[sl] * W + xpx[sl]) * Cs + q * 4) * 4 : (int)OOB;
     }
     int wrel[C::WSLOTS];
 #pragma unroll
@@ -183,14 +189,16 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
             }
         } else {
             const int x0 = tx * TW - PAD, y0 = ty * TH - PAD;
-            const int base = (((n * H + y0) * W + x0) * Cin + cc) * 4;     // may be "negative": wraps back
+            const bool second = cc >= Cs;                                  // wave-uniform: which tensor holds this chunk
+            const int base = (((n * H + y0) * W + x0) * Cs + (second ? cc - Cs : cc)) * 4;   // may be "negative": wraps back
             if constexpr (!UP) {
+                const __amdgpu_buffer_rsrc_t rs = second ? x2rsrc : xrsrc;      // wave-uniform select (4 s_cselect)
 #pragma unroll
                 for (int sl = 0; sl < C::XSLOTS; ++sl) {
                     const bool inb = live && (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
                                      xrel[sl] != (int)OOB;
                     const unsigned off = inb ? (unsigned)(base + xrel[sl]) : OOB;
-                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
                     xr[sl] = *reinterpret_cast<const float4 *>(&v);
                 }
             } else {
@@ -654,6 +662,27 @@ int sq_conv_mfma_v2(const float *x, const float *w, const float *bias, float *y,
                       : dispatch_bn<1, 16>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
     return K == 3 ? dispatch_bn<3, 8>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st)
                   : dispatch_bn<1, 8>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
+}
+
+// conv_layer on the concat bridge (unet.py:196-197, 321): y = act(conv(concat([xa, xb], -1)) + bias) with the
+// concatenated tensor never materialised -- the chunk loop takes its first Cin/2 channels from xa (the up-scaled
+// tensor), the rest from xb (the skip tensor).  Same chain as sq_conv2d_nhwc_fwd_f32 on torch.cat([xa, xb], -1).
+extern "C" int sq_conv2d_concat_nhwc_fwd_f32(const float *xa, const float *xb, const float *w, const float *bias, float *y,
+                                             int N, int H, int W, int Ca, int Cout, int K, int act, void *stream) {
+    SQ_REQUIRE(xa && xb && w && y, "sq_conv2d_concat_nhwc_fwd_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && (K == 1 || K == 3), "sq_conv2d_concat_nhwc_fwd_f32: bad shape / K");
+    SQ_REQUIRE(Ca % 16 == 0 && Ca > 0 && Cout % 4 == 0 && Cout > 0,
+               "sq_conv2d_concat_nhwc_fwd_f32: channels per source %d (multiple of 16), Cout=%d (multiple of 4)", Ca, Cout);
+    SQ_REQUIRE(fits32(N, H, W, 2 * Ca > Cout ? 2 * Ca : Cout), "sq_conv2d_concat_nhwc_fwd_f32: tensors must be < 2 GiB");
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_conv2d_concat_nhwc_fwd_f32: bad activation %d", act);
+    SQ_REQUIRE_ALIGNED(xa); SQ_REQUIRE_ALIGNED(xb); SQ_REQUIRE_ALIGNED(w); SQ_REQUIRE_ALIGNED(y);
+    if (bias) SQ_REQUIRE_ALIGNED(bias);
+    SqConvEpi epi = {};
+    epi.store_y = 1;
+    epi.x2 = xb;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return K == 3 ? dispatch_bn<3, 16>(xa, w, bias, y, N, H, W, 2 * Ca, Cout, 1.0f, act, epi, st)
+                  : dispatch_bn<1, 16>(xa, w, bias, y, N, H, W, 2 * Ca, Cout, 1.0f, act, epi, st);
 }
 
 // conv_block tail + max_pool_layer (sequitr/networks/unet.py:241-243, 265-277): 3x3 conv + bias + act,

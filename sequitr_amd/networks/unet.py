@@ -423,6 +423,21 @@ class UNet2D(UNet):
                  and type(self).conv_transpose_layer is UNet2D.conv_transpose_layer
                  and self.bridge is self._default_bridge
                  and self.bridge_type in ('eltwise_add', 'eltwise_mul', 'eltwise_sub'))
+        if (not self.training and self.bridge_type == 'concat' and self.bridge is self._default_bridge
+                and type(self).conv_layer is UNet2D.conv_layer and type(self).conv_block is UNet2D.conv_block
+                and not self.batch_norm and filters % 16 == 0 and tuple(self.kernel) == (3, 3)):
+            # concat bridge (unet.py:196-197) without the concatenated tensor: conv1 of the block takes its first
+            # `filters` input channels from the up-scaled tensor and the rest from the skip tensor (sq_conv2d_concat_*)
+            with self.variable_scope('up{0:d}'.format(name)):
+                with self.variable_scope('upscale'):
+                    upscale = self.conv_transpose_layer(x, filters)
+                with self.variable_scope('conv1'):
+                    w1, b1 = self._kernel((3, 3, 2 * filters, filters)), self._bias(filters)
+                    conv1 = ops.conv2d_concat(upscale, bridge, w1, b1, act='relu')
+                with self.variable_scope('conv2'):
+                    conv2 = self.conv_layer(conv1, filters)
+                out = self.dropout_layer(conv2)
+            return out
         if not fused:
             return UNet.up_layer(self, x, filters, bridge, name=name)
         with self.variable_scope('up{0:d}'.format(name)):

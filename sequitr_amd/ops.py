@@ -208,6 +208,24 @@ def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None, _dgrad=False):
     return y
 
 
+def conv2d_concat(xa, xb, w, bias=None, act=None):
+    """conv_layer on the concat bridge: act(conv(concat([xa, xb], -1)) + bias) without materialising the concatenation
+    (unet.py:196-197: the up-scaled tensor first, the skip tensor second).  xa, xb (N,H,W,Ca), w (K,K,2Ca,Cout)."""
+    _chk(xa, "xa", ndim=4), _chk(xb, "xb", ndim=4), _chk(w, "w", ndim=4)
+    if tuple(xa.shape) != tuple(xb.shape):
+        raise ValueError("conv2d_concat: the two sources differ in shape: %s vs %s" % (tuple(xa.shape), tuple(xb.shape)))
+    N, H, W, Ca = xa.shape
+    K, K2, Cin, Cout = w.shape
+    if K != K2 or Cin != 2 * Ca:
+        raise ValueError("conv2d_concat: weight %s does not match 2 x %d input channels" % (tuple(w.shape), Ca))
+    if bias is not None:
+        _chk(bias, "bias")
+    y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=xa.device)
+    _lib.check(_lib.load().sq_conv2d_concat_nhwc_fwd_f32(_ptr(xa), _ptr(xb), _ptr(w), _ptr(bias), _ptr(y), N, H, W, Ca, Cout,
+                                                        K, ACT[act], _stream()), "sq_conv2d_concat_nhwc_fwd_f32")
+    return y
+
+
 def _pool(x, fn_name, out):
     _chk(x, "x", ndim=4)
     N, H, W, C = x.shape

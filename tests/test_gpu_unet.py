@@ -8,9 +8,13 @@ import torch
 from oracle import unet_oracle
 from sequitr_amd import ops
 from sequitr_amd.networks.unet import UNet2D, init_unet_weights
-from tests.util import tiles, assert_bit_exact
+from tests.util import tiles, rand_weights, assert_bit_exact
 
 pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
 def make(params, seed=0, cls=UNet2D):
@@ -127,13 +131,29 @@ def test_hook_override_and_unfused_path():
     assert b.pool_calls == 4
 
 
-def test_concat_bridge_runs():
-    params = {"shape": (32, 32), "bridge": "concat", "filters": (16, 32, 64)}
+@pytest.mark.parametrize("filters,size", [((16, 32, 64), 32), ((16, 32, 64, 128, 256), 64)])
+def test_concat_bridge_bit_exact_without_materialising_the_concat(filters, size):
+    """bridge = 'concat' (unet.py:196-197): conv1 of every up block reads its input channels from TWO tensors (the
+    up-scaled one first, the skip one second; sq_conv2d_concat_nhwc_fwd_f32) -- logits, every layer and the mask are
+    bit-identical to the C oracle run on the materialised concatenation, and to the torch.cat graph (fused = same bits)."""
+    params = {"shape": (size, size), "bridge": "concat", "filters": filters}
     net, w = make(params, seed=1)
-    logits = net.build(tiles(3, 1, 32, 32))
+    x = tiles(3, 2, size, size)
+    mask = net.predict(x)
+    ref_logits, ref_net = unet_oracle.unet_forward(x, w, params, return_net=True)
+    assert w["UNet/up0/conv1/kernel"].shape == (3, 3, 2 * filters[0], filters[0])
+    for i, (a, b) in enumerate(zip(net._net, ref_net)):
+        assert_bit_exact(a.cpu().numpy(), b, "concat net[%d]" % i)
+    assert_bit_exact(mask.cpu().numpy(), unet_oracle.predict_mask(ref_logits), "concat mask")
     from oracle import torch_ref
-    ref = torch_ref.unet_forward(tiles(3, 1, 32, 32), w, params)
-    assert np.max(np.abs(logits.cpu().numpy() - ref)) < 1e-4
+    assert np.max(np.abs(net.logits().cpu().numpy() - torch_ref.unet_forward(x, w, params))) < 1e-4
+    # the operator alone against the conv on torch.cat, ragged tile sizes and a 1x1 kernel
+    for (n, h, wd, ca, co, k) in ((2, 20, 27, 16, 32, 3), (1, 16, 16, 64, 16, 3), (1, 9, 33, 32, 32, 1)):
+        xa, xb = tiles(5, n, h, wd, ca), tiles(6, n, h, wd, ca)
+        wt, bs = rand_weights(7, (k, k, 2 * ca, co)), rand_weights(8, (co,), 0.1)
+        got = ops.conv2d_concat(dev(xa), dev(xb), dev(wt), dev(bs), act="relu")
+        want = ops.conv2d(torch.cat([dev(xa), dev(xb)], -1).contiguous(), dev(wt), dev(bs), act="relu")
+        assert torch.equal(got, want), (n, h, wd, ca, co, k)
 
 
 def test_rejects_cpu_device_and_bad_bridge():
@@ -310,3 +330,40 @@ def test_legacy_wiring_same_bits_flat_variable_names():
     fresh = UNet_LEGACY(dict(params, device="cuda:0"), "infer")
     fresh.predict(x)
     assert sorted(fresh.state_dict()) == sorted(flat)
+
+
+def test_o1_logit_fixture_512_tile_bit_exact_and_near_ties_counted():
+    """with seeded variance-scaling weights and eltwise_mul bridges the benchmark net's logits are
+    ~1e-5, so every tolerance statement was made on near-ties.  bench.o1_weights (3x3 kernels x 1.35, N(0, 0.05)
+    biases) gives logits of order one.  On it: a full 512x512 tile is BIT-EXACT against the C oracle (logits, mask),
+    the fused and the hook-by-hook graphs agree bit for bit on a 32-tile batch, tile k of the batch equals tile k run
+    alone, and the near-tie pixels (|z1 - z0| < 1e-6, where another summation order could flip the argmax) are counted:
+    bounded here at 1e-5 of the pixels (SURVEY 7 "Bit-exact argmax")."""
+    import bench
+    params = {"shape": (512, 512), "filters": (16, 32, 64, 128, 256), "bridge": "eltwise_mul"}
+    w = bench.o1_weights(params)
+    net = UNet2D(dict(params, device="cuda:0"), "infer")
+    net.load_state_dict(w)
+    x = tiles(11, 32, 512, 512)
+    mask = net.predict(x).cpu().numpy()
+    logits = net.logits().cpu().numpy()
+    assert 0.3 < logits.std() < 5.0 and np.abs(logits).max() > 3.0, (logits.std(), np.abs(logits).max())   # order one
+    ref = unet_oracle.unet_forward(x[:1], w, params)
+    assert_bit_exact(logits[:1], ref, "O(1) fixture, 512x512 tile, logits")
+    assert_bit_exact(mask[:1], unet_oracle.predict_mask(ref), "O(1) fixture, 512x512 tile, mask")
+    gap = np.abs(logits[..., 1] - logits[..., 0])
+    assert (gap < 1e-6).mean() <= 1e-5 and 0.05 < mask.mean() < 0.6, ((gap < 1e-6).sum(), mask.mean())
+    unfused = UNet2D(dict(params, device="cuda:0", fuse=False), "infer")
+    unfused.load_state_dict(w)
+    assert np.array_equal(unfused.predict(x).cpu().numpy(), mask) and np.array_equal(unfused.logits().cpu().numpy(), logits)
+    for k in (5, 31):
+        assert np.array_equal(net.predict(x[k:k + 1]).cpu().numpy()[0], mask[k])
+        assert np.array_equal(net.logits().cpu().numpy()[0], logits[k])
+    # the torch-oneDNN restatement (bench.py's cpu_baseline leg) on two tiles: logits within north_star's 1e-3 of O(1)
+    # logits; masks differ only where the gap is below the logits' disagreement
+    from oracle.torch_ref import TorchCpuUNet
+    cl = TorchCpuUNet(w, params, threads=8)(x[:2])
+    err = float(np.abs(cl - logits[:2]).max())
+    assert err <= 1e-3, err
+    diff = np.argmax(cl, -1).astype(np.uint8) != mask[:2]
+    assert (gap[:2][diff] <= 2 * err).all() and diff.mean() < 1e-4

@@ -150,3 +150,17 @@ def test_convT3x3s2_restatement_matches_torch_conv_transpose():
     ref = torch.nn.functional.conv_transpose2d(xt, wt, torch.tensor(b, dtype=torch.float64), stride=2)
     ref = ref[:, :, :10, :12].permute(0, 2, 3, 1).numpy()
     assert y.shape == (2, 10, 12, 4) and np.allclose(y, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_unet_oracle_concat_bridge_matches_fp64():
+    """bridge = 'concat' (unet.py:196-197, tf.concat([upscale, skip], -1)): the C-oracle wiring (convT, numpy
+    concatenate, conv over 2f input channels in the chunk / tap / channel chain order) vs the fp64 torch graph."""
+    params = {"shape": (32, 32), "bridge": "concat", "filters": (16, 32, 64)}
+    w = init_unet_weights(params, seed=1)
+    assert w["UNet/up1/conv1/kernel"].shape == (3, 3, 64, 32)
+    x = tiles(3, 2, 32, 32)
+    logits, net = unet_oracle.unet_forward(x, w, params, return_net=True)
+    rlogits, rnet = tr.unet_forward(x, w, params, return_net=True)
+    assert len(net) == len(rnet) == 6
+    for i, (a, b) in enumerate(zip(net, rnet)):
+        assert a.shape == b.shape and np.max(np.abs(a - b)) < 1e-4 * max(1.0, float(np.max(np.abs(b)))), i
