@@ -734,6 +734,69 @@ def main_weightmap(args):
     print(json.dumps(res))
 
 
+def main_weightmap2(args):
+    """SURVEY 8f rank 2, second half: ImageWeightMap2 (pipeline.py:482-571) of 16 x 512x512 label tiles (config 3's
+    labels).  Host: boundary points + scipy Delaunay per tile; GPU: point location (simplex rasterisation), the
+    Gaussian and the weight expression (sq_weightmap2_delaunay_f32).  value = end to end incl. the host triangulation;
+    the roofline object is the device part.  CPU leg: the vectorised numpy/scipy restatement (oracle/weightmap_ref.py
+    image_weight_map2: the reference's own per-pixel Python loop takes 2.7 s per tile)."""
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from sequitr_amd import ops as sq_ops
+    from sequitr_amd.weightmap import boundary_triangulation
+    nb = 16
+    lab = disk_labels(np.random.default_rng(2), nb)
+    t0 = time.perf_counter()
+    rows, longest = [], []
+    for n in range(nb):
+        v, l = boundary_triangulation(lab[n])
+        rows.append(np.concatenate([np.full((len(v), 1), n, np.int32), v.reshape(len(v), 6)], axis=1))
+        longest.append(l)
+    host_s = time.perf_counter() - t0
+    simp = torch.from_numpy(np.ascontiguousarray(np.concatenate(rows))).to(dev)
+    lng = torch.from_numpy(np.ascontiguousarray(np.concatenate(longest))).to(dev)
+    img = torch.from_numpy(lab.astype(np.float32)).to(dev)
+    for _ in range(max(args.warmup, 1)):
+        w = sq_ops.weightmap_delaunay(img, simp, lng, 10., 5.)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(args.steps):
+        w = sq_ops.weightmap_delaunay(img, simp, lng, 10., 5.)
+    e.record()
+    torch.cuda.synchronize()
+    kms = s.elapsed_time(e) / args.steps
+    npx = nb * TILE * TILE
+    alg = npx * (8 + 4 + 8 + 8 + 8 * 2 + 4 + 4)                  # cover zero + image + cover read + tmp write/read(+halo) + image + f32 map
+    res = {"metric": "Delaunay weight maps (ImageWeightMap2) Mpixels/sec on 512x512 label tiles",
+           "value": round(npx / (host_s + kms * 1e-3) / 1e6, 2), "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(host_s * 1e3 + kms, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "int64/f64", "data": "synthetic",
+           "config": {"workload": "ImageWeightMap2(w0=10, sigma=5) on 16 x 512x512 binary label tiles: host scipy "
+                                  "Delaunay of the boundary points, device point location + Gaussian + weights",
+                      "simplices": int(simp.shape[0]), "host_triangulation_ms": round(host_s * 1e3, 2),
+                      "device_ms": round(kms, 4)},
+           "roofline": {"bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(alg / (kms * 1e-3) / 8e12, 4), "traffic": None, "kernel_ms_per_step": round(kms, 4),
+                        "algorithmic_bytes_per_pixel": 52}}
+    if not args.no_cpu_baseline:
+        from oracle import weightmap_ref
+        t0 = time.perf_counter()
+        ref = [weightmap_ref.image_weight_map2(lab[i].astype(np.float32)) for i in range(2)]
+        ct = time.perf_counter() - t0
+        wn = w[:2].cpu().numpy()
+        err = max(float(np.abs(wn[i] - ref[i][..., 0]).max()) for i in range(2))
+        frac = float(np.mean([np.mean(np.abs(wn[i] - ref[i][..., 0]) > 1e-4) for i in range(2)]))
+        res["cpu_baseline"] = {"value": round(2 * TILE * TILE / ct / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                               "sample": "vectorised numpy/scipy restatement with scipy's find_simplex "
+                                         "(oracle/weightmap_ref.py) on 2 of the 16 tiles; the reference's per-pixel "
+                                         "Python loop is ~20x slower still (2.7 s per tile)",
+                               "max_abs_diff_vs_cpu": err, "fraction_of_pixels_differing_by_1e-4": round(frac, 4),
+                               "why_they_differ": "pixels on simplex edges / vertices: scipy's walk is path dependent, the "
+                                                  "kernel takes the longest candidate (tests/test_gpu_weightmap.py)"}
+    print(json.dumps(res))
+
+
 def main_frontend(args):
     """8 raw uint16 camera frames of 1200x1600 -> ImageNorm -> 512x512 tiles (margin 32) on the
     GPU, and the streamed end-to-end path (host frames -> masks on the host) through the default U-Net."""
@@ -1023,7 +1086,7 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive rate (infer mode)")
     ap.add_argument("--graph", type=int, default=1, help="--mode train / gan: replay the step as hipGraphs (1) or eager (0)")
     ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
-    ap.add_argument("--mode", choices=["infer", "infer-bf16", "train", "gan", "centroids", "weightmap", "frontend"], default="infer",
+    ap.add_argument("--mode", choices=["infer", "infer-bf16", "train", "gan", "centroids", "weightmap", "weightmap2", "frontend"], default="infer",
                     help="infer = the headline metric (BASELINE configs[1]); train = configs[2]/[3] "
                          "(U-Net training step, batch 16 per GPU) for DESIGN.md, not the driver's line")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
@@ -1048,6 +1111,8 @@ def main():
         return main_centroids(args)
     if args.mode == "weightmap":
         return main_weightmap(args)
+    if args.mode == "weightmap2":
+        return main_weightmap2(args)
     if args.mode == "frontend":
         return main_frontend(args)
 

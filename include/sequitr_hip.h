@@ -469,6 +469,16 @@ int sq_edt_sq_f32(const float *img, int32_t *d2, void *workspace, int N, int H, 
 int sq_weightmap_edt_f32(const float *img, double *out64, float *out32, void *workspace, int N, int H, int W,
                          double w0, double sigma, void *stream);
 
+/* ImageWeightMap2 (sequitr/pipeline.py:482-571), the per-pixel part on the device: `simplices` (nsimp,7) int32 rows
+ * {tile, x0, y0, x1, y1, x2, y2} (x = row, y = column, as np.where orders them) and `longest` (nsimp) float64 = the
+ * longest edge of each simplex, from scipy.spatial.Delaunay of the boundary points (host); img (N,H,W) binary f32.
+ * Rasterises the simplices (point location; a pixel covered by several takes the largest value), builds the
+ * pre-filter map (1024 where uncovered, 0 on foreground), applies scipy's gaussian_filter(sigma = 1) and the
+ * reference's float64 expression.  out64 (N,H,W) and / or out32; workspace of sq_weightmap2_workspace bytes. */
+int64_t sq_weightmap2_workspace(int N, int H, int W);
+int sq_weightmap2_delaunay_f32(const float *img, const int32_t *simplices, const double *longest, int nsimp, double *out64,
+                               float *out32, void *workspace, int N, int H, int W, double w0, double sigma, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Tile front end: raw single-channel camera frames in HBM (OctopusData .dat memmap,
  * sequitr/dataio/octopus.py:231-245) -> ImageNorm (sequitr/pipeline.py:350-356) -> network tiles, and the

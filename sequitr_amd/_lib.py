@@ -49,6 +49,9 @@ SIGNATURES = {
     "sq_edt_sq_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sq_weightmap_edt_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      ctypes.c_double, ctypes.c_double, c_void_p]),
+    "sq_weightmap2_workspace": (c_int64, [c_int, c_int, c_int]),
+    "sq_weightmap2_delaunay_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                           c_int, ctypes.c_double, ctypes.c_double, c_void_p]),
     "sq_frame_stats_workspace": (c_int64, [c_int, c_int, c_int]),
     "sq_frame_stats": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sq_frames_to_tiles": (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),

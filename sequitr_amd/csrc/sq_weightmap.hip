@@ -173,3 +173,125 @@ extern "C" int sq_weightmap_edt_f32(const float *img, double *out64, float *out3
                        out64, out32, (int *)nullptr, N, H, W, w0, denom);
     return sq_check_launch("sq_weightmap_edt_f32");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// ImageWeightMap2 (sequitr/pipeline.py:482-571): the Delaunay "narrowness" map.  The triangulation of the <= ~10^4
+// boundary points is scipy's (Qhull) on the host -- 1 % of the reference's 2.7 s per tile and the only way to get
+// its choice among co-circular lattice points; the per-PIXEL part that is the other 99 % runs here:
+//   1. point location = rasterisation of the simplices: one wave per simplex walks its bounding box, a pixel is
+//      inside when the three integer edge functions agree in sign (exact, 64-bit), and takes the simplex's longest
+//      edge.  Where ONE simplex covers a pixel this is tri.find_simplex + edist of the reference exactly.  A pixel on
+//      an edge or vertex is covered by several; scipy's walk returns whichever it reaches first (path-dependent), here
+//      the largest longest-edge wins (atomicMax on the bit pattern of a positive double: order-independent);
+//   2. weight_map = longest edge on background pixels (1024 where no simplex covers, :556), 0 on foreground;
+//      gaussian_filter(sigma = 1) as scipy applies it: 9 taps (truncate 4), 'reflect' borders, axis 0 then axis 1;
+//   3. w0 * (1 - mask) * exp(-(wm * wm) / (2 sigma^2 + 1e-99)) + 1 + mask, float64, operation by operation.
+namespace {
+
+__global__ __launch_bounds__(256) void wm2_raster_kernel(const int *__restrict__ simp, const double *__restrict__ longest,
+                                                         int nsimp, u64 *__restrict__ cover, int H, int W) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= nsimp) return;
+    const int *v = simp + (size_t)s * 7;                        // tile, x0, y0, x1, y1, x2, y2 (x = row, y = column as np.where)
+    const int n = v[0];
+    const long long x0 = v[1], y0 = v[2], x1 = v[3], y1 = v[4], x2 = v[5], y2 = v[6];
+    const int xmin = (int)min(x0, min(x1, x2)), xmax = (int)max(x0, max(x1, x2));
+    const int ymin = (int)min(y0, min(y1, y2)), ymax = (int)max(y0, max(y1, y2));
+    const int bw = ymax - ymin + 1, bh = xmax - xmin + 1;
+    const u64 key = (u64)__double_as_longlong(longest[s]);
+    u64 *img = cover + (size_t)n * H * W;
+    for (int i = lane; i < bw * bh; i += 64) {
+        const long long X = xmin + i / bw, Y = ymin + i % bw;
+        if (X < 0 || X >= H || Y < 0 || Y >= W) continue;
+        const long long e0 = (x1 - x0) * (Y - y0) - (y1 - y0) * (X - x0);
+        const long long e1 = (x2 - x1) * (Y - y1) - (y2 - y1) * (X - x1);
+        const long long e2 = (x0 - x2) * (Y - y2) - (y0 - y2) * (X - x2);
+        if ((e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0)) atomicMax(img + X * W + Y, key);
+    }
+}
+
+__device__ __forceinline__ int wm2_reflect(int i, int n) {     // scipy 'reflect': d c b a | a b c d | d c b a
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i - 1 : 2 * n - 1 - i;
+    return i;
+}
+
+// pass along axis 0 (rows): builds the pre-filter map from (image, cover) on the fly, 9 taps, symmetric accumulation
+// as ndimage.correlate1d does for symmetric weights: centre first, then pairs k = 1 .. 4
+__global__ __launch_bounds__(256) void wm2_gauss0_kernel(const float *__restrict__ img, const u64 *__restrict__ cover,
+                                                         double *__restrict__ tmp, int N, int H, int W, double w_0,
+                                                         double w_1, double w_2, double w_3, double w_4) {
+    const double wk[5] = {w_0, w_1, w_2, w_3, w_4};
+    const int64_t total = (int64_t)N * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int y = (int)(i % W);
+        const int x = (int)((i / W) % H);
+        const int64_t base = (i / ((int64_t)H * W)) * H * W;
+        auto val = [&](int xx) {
+            const int64_t j = base + (int64_t)wm2_reflect(xx, H) * W + y;
+            if (img[j] != 0.f) return 0.0;                      // foreground: weight_map stays 0
+            const u64 c = cover[j];
+            return c ? __longlong_as_double((long long)c) : 1024.0;
+        };
+        double acc = val(x) * wk[0];
+        for (int k = 4; k >= 1; --k) acc += (val(x - k) + val(x + k)) * wk[k];    // ni_filters.c: ii = -size1 .. -1
+        tmp[i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void wm2_gauss1_weight_kernel(const float *__restrict__ img, const double *__restrict__ tmp,
+                                                                double *__restrict__ out64, float *__restrict__ out32, int N,
+                                                                int H, int W, double w_0, double w_1, double w_2, double w_3,
+                                                                double w_4, double wsum, double w0, double denom) {
+    const double wk[5] = {w_0, w_1, w_2, w_3, w_4};
+    const int64_t total = (int64_t)N * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int y = (int)(i % W);
+        const int64_t row = i - y;
+        double acc = tmp[i] * wk[0];
+        for (int k = 4; k >= 1; --k) acc += (tmp[row + wm2_reflect(y - k, W)] + tmp[row + wm2_reflect(y + k, W)]) * wk[k];
+        const double wm = acc * wsum;                           // the singleton channel axis: every tap reads the same value
+        const double mask = (double)(img[i] != 0.f ? 1.0f : 0.0f);
+        const double r = w0 * (1.0 - mask) * exp(-(wm * wm) / denom) + 1.0 + mask;
+        if (out64) out64[i] = r;
+        if (out32) out32[i] = (float)r;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t sq_weightmap2_workspace(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0 || (int64_t)N * H * W >= ((int64_t)1 << 31)) return -1;
+    return (int64_t)N * H * W * 16;                             // cover (u64) + one filter pass (f64)
+}
+
+extern "C" int sq_weightmap2_delaunay_f32(const float *img, const int32_t *simplices, const double *longest, int nsimp,
+                                          double *out64, float *out32, void *workspace, int N, int H, int W, double w0,
+                                          double sigma, void *stream) {
+    SQ_REQUIRE(img && simplices && longest && workspace, "sq_weightmap2_delaunay_f32: null pointer");
+    SQ_REQUIRE(out64 || out32, "sq_weightmap2_delaunay_f32: no output requested");
+    SQ_REQUIRE(nsimp > 0 && sq_weightmap2_workspace(N, H, W) > 0, "sq_weightmap2_delaunay_f32: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    u64 *cover = (u64 *)workspace;
+    double *tmp = (double *)workspace + (size_t)N * H * W;
+    const hipError_t e = hipMemsetAsync(cover, 0, (size_t)N * H * W * 8, st);
+    SQ_REQUIRE(e == hipSuccess, "sq_weightmap2_delaunay_f32: memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(wm2_raster_kernel, dim3((nsimp + 3) / 4), dim3(256), 0, st, simplices, longest, nsimp, cover, H, W);
+    int rc = sq_check_launch("sq_weightmap2_delaunay_f32(raster)");
+    if (rc) return rc;
+    // scipy.ndimage.gaussian_filter(sigma = 1.0): radius int(4.0 * 1.0 + 0.5) = 4, exp(-0.5 x^2) normalised by its sum
+    double w[5], sum = 0.0;
+    for (int k = -4; k <= 4; ++k) sum += exp(-0.5 * (double)(k * k));
+    for (int k = 0; k <= 4; ++k) w[k] = exp(-0.5 * (double)(k * k)) / sum;
+    double wsum = 0.0;                                          // what the pass over the length-1 channel axis multiplies by
+    for (int k = -4; k <= 4; ++k) wsum += w[k < 0 ? -k : k];
+    const unsigned grid = wm_grid((int64_t)N * H * W);
+    hipLaunchKernelGGL(wm2_gauss0_kernel, dim3(grid), dim3(256), 0, st, img, cover, tmp, N, H, W, w[0], w[1], w[2], w[3], w[4]);
+    rc = sq_check_launch("sq_weightmap2_delaunay_f32(gauss axis 0)");
+    if (rc) return rc;
+    const double denom = 2.0 * (sigma * sigma) + 1e-99;
+    hipLaunchKernelGGL(wm2_gauss1_weight_kernel, dim3(grid), dim3(256), 0, st, img, tmp, out64, out32, N, H, W, w[0], w[1], w[2],
+                       w[3], w[4], wsum, w0, denom);
+    return sq_check_launch("sq_weightmap2_delaunay_f32(gauss axis 1 + weights)");
+}

@@ -933,3 +933,30 @@ def weightmap_edt(img, w0=10.0, sigma=5.0, dtype=torch.float32):
     _lib.check(lib.sq_weightmap_edt_f32(_ptr(img), o64, o32, _ptr(ws), N, H, W, float(w0), float(sigma), _stream()),
                "sq_weightmap_edt_f32")
     return out
+
+
+def weightmap_delaunay(img, simplices, longest, w0=10.0, sigma=5.0, dtype=torch.float32):
+    """The per-pixel part of ImageWeightMap2 (pipeline.py:514-566) on the device: img (N,H,W) binary f32, simplices
+    (S,7) int32 {tile, x0,y0, x1,y1, x2,y2}, longest (S) float64 -- see sq_weightmap2_delaunay_f32."""
+    _chk(img, "img")
+    if img.dim() == 4 and img.shape[-1] == 1:
+        img = img.reshape(img.shape[:3])
+    if img.dim() != 3:
+        raise ValueError("img must be (N,H,W) or (N,H,W,1), got %s" % (tuple(img.shape),))
+    _chk(simplices, "simplices", dtype=torch.int32, ndim=2), _chk(longest, "longest", dtype=torch.float64, ndim=1)
+    if simplices.shape[1] != 7 or simplices.shape[0] != longest.shape[0] or simplices.shape[0] == 0:
+        raise ValueError("simplices must be (S,7) int32 with S = len(longest) > 0")
+    if dtype not in (torch.float64, torch.float32):
+        raise TypeError("weightmap_delaunay: dtype must be float32 or float64")
+    N, H, W = img.shape
+    lib = _lib.load()
+    nbytes = lib.sq_weightmap2_workspace(N, H, W)
+    if nbytes < 0:
+        raise ValueError("weight map batch %s is too large for one call" % (tuple(img.shape),))
+    ws = _workspace(nbytes, img.device)
+    out = torch.empty((N, H, W), dtype=dtype, device=img.device)
+    o64, o32 = (_ptr(out), None) if dtype == torch.float64 else (None, _ptr(out))
+    _lib.check(lib.sq_weightmap2_delaunay_f32(_ptr(img), _ptr(simplices), _ptr(longest), int(simplices.shape[0]), o64, o32,
+                                             _ptr(ws), N, H, W, float(w0), float(sigma), _stream()),
+               "sq_weightmap2_delaunay_f32")
+    return out

@@ -85,3 +85,65 @@ def test_full_batch_feeds_the_loss_kernel():
     onehot = dev(np.stack([1 - lab, lab], -1).astype(np.uint8))
     loss, dl = ops.wsoftmax_ce(logits, onehot, w.reshape(16, 512, 512, 1))
     assert np.isfinite(float(loss))
+
+
+# ---- ImageWeightMap2 (sequitr/pipeline.py:482-571): host Delaunay + per-pixel work on the GPU -----------------------------
+def _wm2_check(lab, ref, w0=10., sigma=5., ref_is_f32=False, window=None):
+    """GPU map vs (a) the rasterising CPU restatement of the SAME rule (oracle/weightmap_ref.py: exact emulation, so
+    1e-12: it pins the kernels) and (b) the reference-generated vector: equal to 1e-12 (1e-6 for a float32 vector)
+    wherever the reference's answer is determined by the geometry, i.e. at every pixel whose 9x9 Gaussian window holds
+    no background pixel lying on a simplex edge / vertex (there scipy's find_simplex returns whichever incident simplex
+    its walk reaches first and the kernel takes the one with the longest edge); elsewhere within the map's range w0."""
+    from scipy.ndimage import maximum_filter
+    from sequitr_amd.weightmap import device_weightmaps2
+    got = device_weightmaps2(lab[None], w0, sigma, device="cuda:0", dtype=torch.float64).cpu().numpy()[0]
+    emu, count = weightmap_ref.image_weight_map2_raster(lab, w0, sigma)
+    assert got.shape == emu.shape and np.abs(got - emu).max() <= 1e-12, np.abs(got - emu).max()
+    tie = (count >= 2) & (lab == 0)
+    clean = maximum_filter(tie.astype(np.uint8), size=9) == 0
+    g, r, c = got[..., 0], ref, clean
+    if window is not None:
+        g, c = g[window], c[window]
+    err = np.abs(g - r)
+    tol = 1e-6 if ref_is_f32 else 1e-12
+    assert err[c].max() <= tol, err[c].max()
+    assert err.max() <= w0 + 1e-6
+    return float(tie.mean()), float(c.mean()), float(err.max()), float((err > 1e-6).mean())
+
+
+def test_weightmap2_reference_vectors_64px_and_512px():
+    for s in (0, 1, 2):
+        _wm2_check(G["wm_in_%d" % s], G["wm2_out_%d" % s][..., 0])
+    lab = G["wm_in_512"].astype(np.float32)
+    tie, clean, emax, efrac = _wm2_check(lab, G["wm2_out_512_centre"], ref_is_f32=True,
+                                         window=(slice(128, 384), slice(128, 384)))
+    # at the benchmark size the lattice ties are a few per cent of the pixels and most of the map is determined
+    assert tie < 0.08 and clean > 0.5 and efrac < 0.25, (tie, clean, emax, efrac)
+    # float32 maps for the training step: the float64 map rounded once
+    from sequitr_amd.weightmap import device_weightmaps2
+    w32 = device_weightmaps2(lab[None], 10., 5., device="cuda:0")
+    w64 = device_weightmaps2(lab[None], 10., 5., device="cuda:0", dtype=torch.float64)
+    assert w32.dtype == torch.float32 and tuple(w32.shape) == (1, 512, 512, 1) and torch.equal(w32, w64.float())
+
+
+def test_create_weightmaps_gpu_methods_write_the_reference_layout(tmp_path):
+    """create_weightmaps (weightmap.py:171-205) with both GPU methods: folder weights_w0-.._sigma-.., file
+    <stem>_weights.tif, float32 -- 'edt' = ImageWeightMap, 'delaunay_gpu' = ImageWeightMap2 -- against the host
+    restatements of the same pipes."""
+    from sequitr_amd import weightmap as wmod
+    from sequitr_amd import pipeline
+    lab = (G["wm_in_512"][128:384, 128:384] > 0).astype(np.uint8)
+    d = tmp_path / "set1" / "label"
+    d.mkdir(parents=True)
+    wmod.imsave(str(d / "img_0001_label.tif"), lab)
+    for method, pipe in (("edt", pipeline.ImageWeightMap(10., 5.)), ("delaunay_gpu", None)):
+        files = wmod.create_weightmaps(str(tmp_path), ["set1"], w0=10., sigma=5., method=method)
+        assert files == [str(tmp_path / "set1" / "weights_w0-10.00_sigma-5.00" / "img_0001_weights.tif")]
+        got = wmod.imread(files[0])
+        assert got.dtype == np.float32 and got.shape == (256, 256)
+        if pipe is not None:
+            want = np.squeeze(pipe(lab.astype(np.float32)[..., None])).astype(np.float32)
+        else:
+            want = weightmap_ref.image_weight_map2_raster(lab.astype(np.float32), 10., 5.)[0][..., 0].astype(np.float32)
+        assert np.abs(got - want).max() <= 1e-6, method
+        os.remove(files[0])
