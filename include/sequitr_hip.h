@@ -255,6 +255,23 @@ int sq_dot_per_sample_f32(const float *a, const float *b, float *out, float *wor
 /* minibatch stdev scalar (gan.py:204-211): sqrt(mean over positions of the batch variance).
  * workspace: 256 floats. */
 int sq_mbstd_fwd_f32(const float *x, float *out, float *workspace, int N, int64_t per_sample, void *stream);
+/* The discriminator's minibatch-stdev FEATURE MAP (gan.py:204-212) up to second order (two launches per call):
+ * x (groups*n, per_sample) -> y (groups*n, cells) filled with its group's statistic (cells = 16: the hard-coded
+ * (N,4,4,1) map); bwd: dx from (x, dy); bwd2: with v = dL/d(dx) returns ddy = dL/d(dy) and dx2 = dL/dx.  groups = 2
+ * when D(Gz) and D(X) run as one stacked pass (each minibatch its own statistic). */
+int64_t sq_mbstd_map_workspace(int groups);      /* bytes of the `workspace` the three calls take */
+int sq_mbstd_map_fwd_f32(const float *x, float *y, float *workspace, int groups, int n, int64_t per_sample, int cells,
+                         void *stream);
+int sq_mbstd_map_bwd_f32(const float *x, const float *dy, float *dx, float *workspace, int groups, int n,
+                         int64_t per_sample, int cells, void *stream);
+int sq_mbstd_map_bwd2_f32(const float *x, const float *dy, const float *v, float *ddy, float *dx2, float *workspace,
+                          int groups, int n, int64_t per_sample, int cells, void *stream);
+/* WGAN-GP loss algebra of gan.py:715-729 in one launch: out2 = {d_loss, g_loss} from Dz, Dx (N) and gn2 (N) = squared
+ * norm of dD(mix)/dmix per sample (one-sided penalty, lambda 10, eps drift 0.001 Dx^2); Dx = gn2 = NULL: g_loss only.
+ * bwd: g_dloss / g_gloss = upstream gradients (device scalars, NULL = 0) -> dDz, dDx, dgn2. */
+int sq_wgan_losses_fwd_f32(const float *Dz, const float *Dx, const float *gn2, float *out2, int N, void *stream);
+int sq_wgan_losses_bwd_f32(const float *Dz, const float *Dx, const float *gn2, const float *g_dloss, const float *g_gloss,
+                           float *dDz, float *dDx, float *dgn2, int N, void *stream);
 
 /* Small-image batches (the 4x4 / 8x8 levels of generator_network / discriminator_network,
  * gan.py:246-316,149-240) as ONE image of R x Cc cells of pitch (H+1, W+1): m (1, R*(H+1), Cc*(W+1), C),
@@ -349,6 +366,12 @@ int sq_conv2d_nhwc_fwd_mixed_f32(const float *x, const void *wp, const float *bi
 int64_t sq_conv2d_nhwc_wgrad_workspace_mixed_f32(int N, int H, int W, int Cin, int Cout, int K);
 int sq_conv2d_nhwc_wgrad_mixed_f32(const float *x, const float *dy, float *dw, float *db, float *workspace, int N,
                                    int H, int W, int Cin, int Cout, int K, void *stream);
+/* the same with dW (not db) multiplied by dw_scale in the finish kernel: the gradient of an equalised-learning-rate
+ * kernel is wscale * raw dW (gan.py:75-79); saves the scalar-multiply pass over every weight gradient */
+int sq_conv2d_nhwc_wgrad_scaled_mixed_f32(const float *x, const float *dy, float *dw, float *db, float *workspace, int N,
+                                          int H, int W, int Cin, int Cout, int K, float dw_scale, void *stream);
+int sq_conv2d_nhwc_wgrad_scaled_f32(const float *x, const float *dy, float *dw, float *db, float *workspace, int N, int H,
+                                    int W, int Cin, int Cout, int K, float dw_scale, void *stream);
 
 /* first conv of down0 in the bf16 graph: f32 (N,H,W,Cin) image, Cin 1..7 -> bf16 (N,H,W,Cout), 3x3, f32 HWIO
  * weights (`num_inputs`, unet.py:131). */

@@ -84,6 +84,12 @@ SIGNATURES = {
     "sq_dot_per_sample_workspace_f32": (c_int64, [c_int]),
     "sq_dot_per_sample_f32": (c_int, [c_void_p] * 4 + [c_int, c_int64, c_void_p]),
     "sq_mbstd_fwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_int64, c_void_p]),
+    "sq_mbstd_map_workspace": (c_int64, [c_int]),
+    "sq_mbstd_map_fwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int64, c_int, c_void_p]),
+    "sq_mbstd_map_bwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int64, c_int, c_void_p]),
+    "sq_mbstd_map_bwd2_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int64, c_int, c_void_p]),
+    "sq_wgan_losses_fwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
+    "sq_wgan_losses_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_void_p]),
     "sq_wgrad1x1_small_workspace_f32": (c_int64, [c_int64, c_int, c_int]),
     "sq_wgrad1x1_small_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
     "sq_conv2d_concat_nhwc_fwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
@@ -96,6 +102,8 @@ SIGNATURES = {
     "sq_conv2d_nhwc_fwd_mixed_f32": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "sq_conv2d_nhwc_wgrad_workspace_mixed_f32": (c_int64, [c_int] * 6),
     "sq_conv2d_nhwc_wgrad_mixed_f32": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "sq_conv2d_nhwc_wgrad_scaled_mixed_f32": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),
+    "sq_conv2d_nhwc_wgrad_scaled_f32": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),
     "sq_conv3x3_first_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "sq_conv2d_nhwc_wgrad_workspace_bf16": (c_int64, [c_int] * 6),
     "sq_conv2d_nhwc_wgrad_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),

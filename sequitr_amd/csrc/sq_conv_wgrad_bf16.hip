@@ -236,10 +236,13 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
     for (int i = tid; i < C::RED_FLOATS; i += 256) out[i] = red[i];
 }
 
+// factor the finish kernel applies to dW (not db): set by the *_scaled_* entry points around their dispatch, 1 otherwise
+thread_local float t_dw_scale = 1.0f;
+
 template <int KS, int NI, int NO>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float *__restrict__ partials,
                                                                       float *__restrict__ dw, float *__restrict__ db,
-                                                                      int nblk, int Cin, int Cout, int G) {
+                                                                      int nblk, int Cin, int Cout, int G, float dw_scale) {
     using C = WB<KS, NI, NO>;
     const int nco = Cout / C::CO, npairs = (Cin / C::CI) * nco;
     const int total = C::NTAP * Cin * Cout;
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float
         const size_t off = (size_t)((ci / C::CI) * nco + co / C::CO) * C::RED_FLOATS +
                            (tap * C::CI + ci % C::CI) * C::CO + co % C::CO;
         const float s = sq_group_reduce(partials + off, stride, nblk, g, G);
-        if (g == 0) dw[i] = s;
+        if (g == 0) dw[i] = dw_scale == 1.0f ? s : s * dw_scale;      // the equalised-LR factor of gan.py:79, one f32 multiply
     } else if (i < total + Cout) {
         const int co = i - total;
         const size_t off = (size_t)(co / C::CO) * C::RED_FLOATS + (C::NTAP * C::CI) * C::CO + co % C::CO;
@@ -304,7 +307,7 @@ int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, 
     const int G = sq_group_size(gx);
     const int64_t total = ((int64_t)KS * KS * Cin * Cout + Cout) * G;
     hipLaunchKernelGGL((conv_wgrad_bf16_finish_kernel<KS, NI, NO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       ws, dw, db, gx, Cin, Cout, G);
+                       ws, dw, db, gx, Cin, Cout, G, t_dw_scale);
     return sq_check_launch("sq_conv2d_nhwc_wgrad_bf16(finish)");
 }
 
@@ -432,4 +435,15 @@ extern "C" int sq_conv2d_nhwc_wgrad_mixed_f32(const float *x, const float *dy, f
                Cout, K);
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(workspace);
     return launch_any_mixed(x, dy, dw, db, workspace, N, H, W, Cin, Cout, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+// dW additionally multiplied by dw_scale in the finish kernel (db is not): the gradient of a weighted_conv2d kernel is
+// wscale * (raw dW), gan.py:75-79 -- one f32 multiply per element, exactly what a separate scalar-multiply pass gives.
+extern "C" int sq_conv2d_nhwc_wgrad_scaled_mixed_f32(const float *x, const float *dy, float *dw, float *db, float *workspace,
+                                                     int N, int H, int W, int Cin, int Cout, int K, float dw_scale,
+                                                     void *stream) {
+    t_dw_scale = dw_scale;
+    const int rc = sq_conv2d_nhwc_wgrad_mixed_f32(x, dy, dw, db, workspace, N, H, W, Cin, Cout, K, stream);
+    t_dw_scale = 1.0f;
+    return rc;
 }

@@ -207,11 +207,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
     for (int i = tid; i < C::RED_FLOATS; i += 256) out[i] = red[i];
 }
 
+// factor the finish kernel applies to dW (not db): set by sq_conv2d_nhwc_wgrad_scaled_f32 around its dispatch
+thread_local float t_dw_scale_f32 = 1.0f;
+
 // second stage: dW[tap][ci][co] = sum_b partials[b][pair][tap*16 + ci%16][co%BN], b ascending
 template <int BN, int KS, int KC>
 __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const float *__restrict__ partials,
                                                                  float *__restrict__ dw, float *__restrict__ db,
-                                                                 int nblk, int Cin, int Cout, int G) {
+                                                                 int nblk, int Cin, int Cout, int G, float dw_scale) {
     using C = WCfg<BN, KS, KC>;
     const int nco = (Cout + BN - 1) / BN, npairs = (Cin / KC) * nco;
     const int total = C::NTAP * Cin * Cout;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const float *__r
         const int pair = (ci / KC) * nco + co / BN;
         const size_t off = (size_t)pair * C::RED_FLOATS + (tap * 16 + ci % KC) * BN + co % BN;
         const float s = sq_group_reduce(partials + off, stride, nblk, g, G);
-        if (g == 0) dw[i] = s;
+        if (g == 0) dw[i] = dw_scale == 1.0f ? s : s * dw_scale;
     } else if (i < total + Cout) {
         const int co = i - total;
         const size_t off = (size_t)(co / BN) * C::RED_FLOATS + (C::NTAP * 16) * BN + co % BN;
@@ -273,7 +276,7 @@ int launch(const float *x, const float *dy, float *dw, float *db, float *ws, int
     const int G = sq_group_size(gx);
     const int64_t total = ((int64_t)KS * KS * Cin * Cout + Cout) * G;
     hipLaunchKernelGGL((conv_wgrad_finish_kernel<BN, KS, KC>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws,
-                       dw, db, gx, Cin, Cout, G);
+                       dw, db, gx, Cin, Cout, G, t_dw_scale_f32);
     return sq_check_launch("sq_conv2d_nhwc_wgrad_f32(finish)");
 }
 
@@ -450,6 +453,17 @@ extern "C" int sq_conv2d_nhwc_wgrad_f32(const float *x, const float *dy, float *
         return launch_cin_small<float>(x, dy, dw, db, workspace, N, H, W, Cin, Cout, reinterpret_cast<hipStream_t>(stream),
                                        "sq_conv2d_nhwc_wgrad_f32(small Cin)");
     return launch_dispatch(x, dy, dw, db, workspace, N, H, W, Cin, Cout, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+// dW multiplied by dw_scale in the finish kernel (MFMA kernels: Cin 8 or a multiple of 16; the small-Cin kernel has no
+// scaled form): see sq_conv2d_nhwc_wgrad_scaled_mixed_f32
+extern "C" int sq_conv2d_nhwc_wgrad_scaled_f32(const float *x, const float *dy, float *dw, float *db, float *workspace,
+                                               int N, int H, int W, int Cin, int Cout, int K, float dw_scale, void *stream) {
+    SQ_REQUIRE(Cin > 7 || dw_scale == 1.0f, "sq_conv2d_nhwc_wgrad_scaled_f32: Cin=%d has no scaled form", Cin);
+    t_dw_scale_f32 = dw_scale;
+    const int rc = sq_conv2d_nhwc_wgrad_f32(x, dy, dw, db, workspace, N, H, W, Cin, Cout, K, stream);
+    t_dw_scale_f32 = 1.0f;
+    return rc;
 }
 
 // first-layer weight gradient with a bf16 dY (the bf16 training graph): same MFMA-over-taps kernel

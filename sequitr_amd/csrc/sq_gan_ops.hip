@@ -430,3 +430,220 @@ extern "C" int sq_mosaic_unpack_f32(const float *m, float *y, int N, int H, int 
                        reinterpret_cast<const float4 *>(m), reinterpret_cast<float4 *>(y), N, H, W, C / 4, R, Cc);
     return sq_check_launch("sq_mosaic_unpack_f32");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// minibatch-stdev feature of the discriminator (gan.py:204-212) up to second order, and the WGAN-GP loss algebra
+// (gan.py:709-729): tiny tensors (32 x 16 x 512 values; N scalars) that ran as ~200 framework element-wise / reduce
+// launches per iteration.  Two launches per op: 64 blocks per minibatch group reduce their share of the positions
+// (fixed order), then every block of the second launch folds the 64 partials itself, in index order, and applies
+// the element-wise part to its share -- no atomics, run-to-run identical.
+//   x (G*n, P) -- G groups of n samples (the stacked D(Gz) | D(X) pass has G = 2), P = 4*4*C values per sample.
+//   forward : s_g = sqrt( (1/P) sum_j (1/n) sum_i (x_ij - mu_j)^2 ),  y (G*n, cells) = s_g   (cells = 16: the (N,4,4,1) map)
+//   backward: ds_g = sum of dy over the group;  dx_ij = ds_g * c * (x_ij - mu_j) / s_g,  c = 1 / (P n)
+//   backward of the backward, cotangent V of dx:  A = sum_ij V_ij (x_ij - mu_j)
+//             d(dy) = c A / s_g  (every element of the group)
+//             d x_kl = ds_g c / s_g * ( (V_kl - Vbar_l) - A c (x_kl - mu_l) / s_g^2 )
+namespace {
+
+constexpr int MB_T = 1024;     // the loss kernels: one workgroup
+constexpr int MB_B = 64;       // blocks per group of the statistic kernels
+constexpr int MB_BT = 256;
+
+__device__ __forceinline__ float mb_block_sum(float v, float *red) {
+    const int t = threadIdx.x, T = blockDim.x;
+    red[t] = v;
+    __syncthreads();
+    for (int k = T / 2; k > 0; k >>= 1) {
+        if (t < k) red[t] += red[t + k];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// stage 1, grid (MB_B, groups): block b sums its positions' batch variances (and, with v, its share of
+// A = sum_ij V_ij (x_ij - mu_j)) -> partials[g][b] = {var sum, A}
+__global__ __launch_bounds__(MB_BT) void mbstd_stats_kernel(const float *__restrict__ x, const float *__restrict__ v,
+                                                            float *__restrict__ partials, int n, int64_t P) {
+    __shared__ float red[MB_BT];
+    const int g = blockIdx.y;
+    const float *xg = x + (int64_t)g * n * P;
+    const float *vg = v ? v + (int64_t)g * n * P : nullptr;
+    float acc = 0.f, aa = 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * MB_BT + threadIdx.x; p < P; p += (int64_t)MB_B * MB_BT) {
+        float mu = 0.f;
+        for (int i = 0; i < n; ++i) mu += xg[(int64_t)i * P + p];
+        mu /= (float)n;
+        float var = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float d = xg[(int64_t)i * P + p] - mu;
+            var = __builtin_fmaf(d, d, var);
+            if (vg) aa = __builtin_fmaf(vg[(int64_t)i * P + p], d, aa);
+        }
+        acc += var / (float)n;
+    }
+    const float sv = mb_block_sum(acc, red), sa = mb_block_sum(aa, red);
+    if (threadIdx.x == 0) {
+        partials[((int64_t)g * MB_B + blockIdx.x) * 2] = sv;
+        partials[((int64_t)g * MB_B + blockIdx.x) * 2 + 1] = sa;
+    }
+}
+
+// every block of stage 2 folds the MB_B partials itself, in index order: the same s (and A) in every block
+__device__ __forceinline__ void mb_fold(const float *partials, int g, int64_t P, float *s, float *A) {
+    float sv = 0.f, sa = 0.f;
+    for (int b = 0; b < MB_B; ++b) {
+        sv += partials[((int64_t)g * MB_B + b) * 2];
+        sa += partials[((int64_t)g * MB_B + b) * 2 + 1];
+    }
+    *s = __builtin_sqrtf(sv / (float)P);
+    *A = sa;
+}
+
+__device__ __forceinline__ float mb_group_dy_sum(const float *dyg, int count, float *red) {
+    float a = 0.f;
+    for (int e = threadIdx.x; e < count; e += MB_BT) a += dyg[e];
+    return mb_block_sum(a, red);
+}
+
+__global__ __launch_bounds__(MB_BT) void mbstd_map_fill_kernel(const float *__restrict__ partials, float *__restrict__ y, int n,
+                                                               int64_t P, int cells) {
+    const int g = blockIdx.x;
+    float s, A;
+    mb_fold(partials, g, P, &s, &A);
+    for (int e = threadIdx.x; e < n * cells; e += MB_BT) y[(int64_t)g * n * cells + e] = s;
+}
+
+__global__ __launch_bounds__(MB_BT) void mbstd_map_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                              const float *__restrict__ partials, float *__restrict__ dx, int n,
+                                                              int64_t P, int cells) {
+    __shared__ float red[MB_BT];
+    const int g = blockIdx.y;
+    const float *xg = x + (int64_t)g * n * P;
+    float s, A;
+    mb_fold(partials, g, P, &s, &A);
+    const float ds = mb_group_dy_sum(dy + (int64_t)g * n * cells, n * cells, red);
+    const float k = ds / ((float)P * (float)n) / s;
+    for (int64_t p = (int64_t)blockIdx.x * MB_BT + threadIdx.x; p < P; p += (int64_t)MB_B * MB_BT) {
+        float mu = 0.f;
+        for (int i = 0; i < n; ++i) mu += xg[(int64_t)i * P + p];
+        mu /= (float)n;
+        for (int i = 0; i < n; ++i) dx[((int64_t)g * n + i) * P + p] = k * (xg[(int64_t)i * P + p] - mu);
+    }
+}
+
+__global__ __launch_bounds__(MB_BT) void mbstd_map_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                               const float *__restrict__ v, const float *__restrict__ partials,
+                                                               float *__restrict__ ddy, float *__restrict__ dx2, int n, int64_t P,
+                                                               int cells) {
+    __shared__ float red[MB_BT];
+    const int g = blockIdx.y;
+    const float *xg = x + (int64_t)g * n * P, *vg = v + (int64_t)g * n * P;
+    float s, A;
+    mb_fold(partials, g, P, &s, &A);
+    const float ds = mb_group_dy_sum(dy + (int64_t)g * n * cells, n * cells, red);
+    const float c = 1.0f / ((float)P * (float)n);
+    if (blockIdx.x == 0) {
+        const float gdy = c * A / s;
+        for (int e = threadIdx.x; e < n * cells; e += MB_BT) ddy[(int64_t)g * n * cells + e] = gdy;
+    }
+    const float k1 = ds * c / s, k2 = A * c / (s * s);
+    for (int64_t p = (int64_t)blockIdx.x * MB_BT + threadIdx.x; p < P; p += (int64_t)MB_B * MB_BT) {
+        float mu = 0.f, vb = 0.f;
+        for (int i = 0; i < n; ++i) { mu += xg[(int64_t)i * P + p]; vb += vg[(int64_t)i * P + p]; }
+        mu /= (float)n;
+        vb /= (float)n;
+        for (int i = 0; i < n; ++i)
+            dx2[((int64_t)g * n + i) * P + p] = k1 * ((vg[(int64_t)i * P + p] - vb) - k2 * (xg[(int64_t)i * P + p] - mu));
+    }
+}
+
+// WGAN-GP losses of one level (gan.py:715-729): gn2 = squared norm of d D(mix) / d mix per sample.
+//   pen_i = 10 max(sqrt(gn2_i) - 1, 0)^2, eps_i = 0.001 Dx_i^2, d_loss = mean(-Dx + Dz + pen + eps), g_loss = mean(-Dz)
+// out[0] = d_loss, out[1] = g_loss.  Dx / gn2 may be NULL (generator step: g_loss only).  Single workgroup.
+__global__ __launch_bounds__(MB_T) void wgan_losses_fwd_kernel(const float *__restrict__ Dz, const float *__restrict__ Dx,
+                                                               const float *__restrict__ gn2, float *__restrict__ out, int N) {
+    __shared__ float red[MB_T];
+    float d = 0.f, gl = 0.f;
+    for (int i = threadIdx.x; i < N; i += MB_T) {
+        const float z = Dz[i];
+        gl += -z;
+        if (Dx) {
+            const float xv = Dx[i], nrm = __builtin_sqrtf(gn2[i]), ex = nrm - 1.0f > 0.0f ? nrm - 1.0f : 0.0f;
+            d += ((-xv + z) + 10.0f * (ex * ex)) + 0.001f * (xv * xv);
+        }
+    }
+    const float sd = mb_block_sum(d, red), sg = mb_block_sum(gl, red);
+    if (threadIdx.x == 0) {
+        out[0] = sd / (float)N;
+        out[1] = sg / (float)N;
+    }
+}
+
+// gd, gg: upstream gradients of d_loss / g_loss (device scalars; NULL = 0)
+__global__ __launch_bounds__(MB_T) void wgan_losses_bwd_kernel(const float *__restrict__ Dz, const float *__restrict__ Dx,
+                                                               const float *__restrict__ gn2, const float *__restrict__ gd,
+                                                               const float *__restrict__ gg, float *__restrict__ dDz,
+                                                               float *__restrict__ dDx, float *__restrict__ dgn2, int N) {
+    const float ud = gd ? gd[0] / (float)N : 0.f, ug = gg ? gg[0] / (float)N : 0.f;
+    for (int i = threadIdx.x; i < N; i += MB_T) {
+        dDz[i] = (Dx ? ud : 0.f) - ug;
+        if (Dx) {
+            const float xv = Dx[i], nrm = __builtin_sqrtf(gn2[i]), ex = nrm - 1.0f > 0.0f ? nrm - 1.0f : 0.0f;
+            dDx[i] = ud * (-1.0f + 0.002f * xv);
+            dgn2[i] = ex > 0.0f ? ud * 10.0f * ex / nrm : 0.f;   // d/d(gn2) of 10 (sqrt(gn2) - 1)^2 = 10 (sqrt - 1) / sqrt
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t sq_mbstd_map_workspace(int groups) { return groups > 0 ? (int64_t)groups * MB_B * 2 * 4 : -1; }
+
+extern "C" int sq_mbstd_map_fwd_f32(const float *x, float *y, float *workspace, int groups, int n, int64_t per_sample,
+                                    int cells, void *stream) {
+    SQ_REQUIRE(x && y && workspace && groups > 0 && n > 0 && per_sample > 0 && cells > 0, "sq_mbstd_map_fwd_f32: bad arguments");
+    hipLaunchKernelGGL(mbstd_stats_kernel, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, (const float *)nullptr,
+                       workspace, n, per_sample);
+    int rc = sq_check_launch("sq_mbstd_map_fwd_f32(stats)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mbstd_map_fill_kernel, dim3(groups), dim3(MB_BT), 0, SQ_ST(stream), workspace, y, n, per_sample, cells);
+    return sq_check_launch("sq_mbstd_map_fwd_f32");
+}
+extern "C" int sq_mbstd_map_bwd_f32(const float *x, const float *dy, float *dx, float *workspace, int groups, int n,
+                                    int64_t per_sample, int cells, void *stream) {
+    SQ_REQUIRE(x && dy && dx && workspace && groups > 0 && n > 0 && per_sample > 0 && cells > 0,
+               "sq_mbstd_map_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(mbstd_stats_kernel, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, (const float *)nullptr,
+                       workspace, n, per_sample);
+    int rc = sq_check_launch("sq_mbstd_map_bwd_f32(stats)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mbstd_map_bwd_kernel, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, dy, workspace, dx, n,
+                       per_sample, cells);
+    return sq_check_launch("sq_mbstd_map_bwd_f32");
+}
+extern "C" int sq_mbstd_map_bwd2_f32(const float *x, const float *dy, const float *v, float *ddy, float *dx2,
+                                     float *workspace, int groups, int n, int64_t per_sample, int cells, void *stream) {
+    SQ_REQUIRE(x && dy && v && ddy && dx2 && workspace && groups > 0 && n > 0 && per_sample > 0 && cells > 0,
+               "sq_mbstd_map_bwd2_f32: bad arguments");
+    hipLaunchKernelGGL(mbstd_stats_kernel, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, v, workspace, n, per_sample);
+    int rc = sq_check_launch("sq_mbstd_map_bwd2_f32(stats)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mbstd_map_bwd2_kernel, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, dy, v, workspace, ddy, dx2,
+                       n, per_sample, cells);
+    return sq_check_launch("sq_mbstd_map_bwd2_f32");
+}
+extern "C" int sq_wgan_losses_fwd_f32(const float *Dz, const float *Dx, const float *gn2, float *out2, int N, void *stream) {
+    SQ_REQUIRE(Dz && out2 && N > 0 && ((Dx == nullptr) == (gn2 == nullptr)), "sq_wgan_losses_fwd_f32: bad arguments");
+    hipLaunchKernelGGL(wgan_losses_fwd_kernel, dim3(1), dim3(MB_T), 0, SQ_ST(stream), Dz, Dx, gn2, out2, N);
+    return sq_check_launch("sq_wgan_losses_fwd_f32");
+}
+extern "C" int sq_wgan_losses_bwd_f32(const float *Dz, const float *Dx, const float *gn2, const float *g_dloss,
+                                      const float *g_gloss, float *dDz, float *dDx, float *dgn2, int N, void *stream) {
+    SQ_REQUIRE(Dz && dDz && N > 0 && ((Dx == nullptr) == (gn2 == nullptr)) && (!Dx || (dDx && dgn2)),
+               "sq_wgan_losses_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(wgan_losses_bwd_kernel, dim3(1), dim3(MB_T), 0, SQ_ST(stream), Dz, Dx, gn2, g_dloss, g_gloss, dDz, dDx,
+                       dgn2, N);
+    return sq_check_launch("sq_wgan_losses_bwd_f32");
+}

@@ -25,6 +25,44 @@ def grad_sink(param):
     return getattr(param, '_sq_grad_sink', None) if param is not None else None
 
 
+# Which PARAMETER gradients the running backward pass is for.  A custom Function only knows that a weight
+# "requires grad" (ctx.needs_input_grad), not whether THIS torch.autograd.grad call asked for it, so without a hint
+# every pass through the discriminator computes the weight and bias gradients of all its layers: the WGAN-GP
+# penalty's inner pass (grad of D(mix) w.r.t. mix only, gan.py:721) and the generator step (which differentiates
+# THROUGH the discriminator, gan.py:650) threw away a full set of wgrad + finish + bias-sum launches each.
+# `with grads_wanted(params):` restricts the parameter gradients computed inside to `params` (an empty list: none);
+# gradients of everything else come back as None, which autograd.grad discards anyway.
+_WANTED = None
+
+
+class grads_wanted(object):
+    def __init__(self, params):
+        self.ids = None if params is None else frozenset(id(p) for p in params)
+
+    def __enter__(self):
+        global _WANTED
+        self.prev, _WANTED = _WANTED, self.ids
+        return self
+
+    def __exit__(self, *exc):
+        global _WANTED
+        _WANTED = self.prev
+        return False
+
+
+def _pid(t):
+    """identity of the PARAMETER behind t: layers hand views of their variables to the ops (bias.view(-1), the
+    (1,1,Cin,Cout) form of a dense kernel); the id is taken at forward time, when the variable is certainly alive"""
+    if t is None:
+        return None
+    base = t._base if t._base is not None else t
+    return id(base)
+
+
+def _want(pid):
+    return pid is not None and (_WANTED is None or pid in _WANTED)
+
+
 def convT_param_grads(dwp, dbp, Cin, Cout, sinks):
     """(dW (2,2,Cout,Cin), db (Cout)) of the 2x2/s2 transpose conv from the 1x1 wgrad of its
     space-to-depth form (dwp (1,1,Cin,4Cout), dbp (4Cout) or None); written into the sinks when set."""
@@ -49,7 +87,7 @@ class _ConvFwd(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, wscale):
-        ctx.wscale = wscale
+        ctx.wscale, ctx.w_id = wscale, _pid(w)
         ctx.save_for_backward(x, w)
         return ops.conv2d(x, w, None, act=None, wscale=wscale)
 
@@ -57,7 +95,7 @@ class _ConvFwd(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = _ConvDgrad.apply(dy, w, ctx.wscale) if ctx.needs_input_grad[0] else None
-        dw = _ConvWgrad.apply(x, dy, w.shape[0], ctx.wscale) if ctx.needs_input_grad[1] else None
+        dw = _ConvWgrad.apply(x, dy, w.shape[0], ctx.wscale) if (ctx.needs_input_grad[1] and _want(ctx.w_id)) else None
         return dx, dw, None
 
 
@@ -66,7 +104,7 @@ class _ConvDgrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dy, w, wscale):
-        ctx.wscale = wscale
+        ctx.wscale, ctx.w_id = wscale, _pid(w)
         ctx.save_for_backward(dy, w)
         return ops.conv_dgrad_raw(dy.contiguous(), w, wscale)
 
@@ -74,7 +112,8 @@ class _ConvDgrad(torch.autograd.Function):
     def backward(ctx, ddx):
         dy, w = ctx.saved_tensors
         d_dy = _ConvFwd.apply(ddx.contiguous(), w, ctx.wscale) if ctx.needs_input_grad[0] else None
-        d_w = _ConvWgrad.apply(ddx.contiguous(), dy, w.shape[0], ctx.wscale) if ctx.needs_input_grad[1] else None
+        d_w = (_ConvWgrad.apply(ddx.contiguous(), dy, w.shape[0], ctx.wscale)
+               if (ctx.needs_input_grad[1] and _want(ctx.w_id)) else None)
         return d_dy, d_w, None
 
 
@@ -85,8 +124,8 @@ class _ConvWgrad(torch.autograd.Function):
     def forward(ctx, x, dy, K, wscale):
         ctx.K, ctx.wscale = K, wscale
         ctx.save_for_backward(x, dy)
-        dw, _ = ops.conv_wgrad_raw(x, dy.contiguous(), K, want_bias=False)
-        return dw if wscale == 1.0 else dw * wscale
+        dw, _ = ops.conv_wgrad_raw(x, dy.contiguous(), K, want_bias=False, dw_scale=wscale)   # w' = w * wscale (gan.py:79)
+        return dw
 
     @staticmethod
     def backward(ctx, ddw):
@@ -157,6 +196,7 @@ class _Conv2d(torch.autograd.Function):
     def forward(ctx, x, w, bias, act, wscale):
         y = ops.conv2d(x, w, bias, act=act, wscale=wscale)
         ctx.act, ctx.wscale, ctx.has_bias = act, wscale, bias is not None
+        ctx.w_id, ctx.bias_id = _pid(w), _pid(bias)
         ctx.sinks = (grad_sink(w), grad_sink(bias)) if wscale == 1.0 else (None, None)
         ctx.save_for_backward(x, w, y if ops.ACT[act] else None)
         return y
@@ -168,22 +208,23 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _ConvDgrad.apply(dpre, w, ctx.wscale)
-        need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] and not torch.is_grad_enabled():
+        want_w = ctx.needs_input_grad[1] and _want(ctx.w_id)
+        need_b = ctx.has_bias and ctx.needs_input_grad[2] and _want(ctx.bias_id)
+        if not want_w and not need_b:
+            return dx, None, None, None, None
+        if want_w and not torch.is_grad_enabled():
             # first-order fast path: dW and db from ONE pass of the wgrad kernel
             sw, sb = ctx.sinks
             Cin, Cout = w.shape[2], w.shape[3]
             if sw is None or (Cout % 4) or not (Cin % 8 == 0 or Cin == 1):   # sinks only on the MFMA wgrad kernels
                 sw = sb = None
             dw, db = ops.conv_wgrad_raw(x, dpre, w.shape[0], want_bias=need_b, dw_out=sw,
-                                        db_out=sb if need_b else None)
-            if ctx.wscale != 1.0:
-                dw = dw * ctx.wscale                     # w' = w * wscale (gan.py:79)
+                                        db_out=sb if need_b else None, dw_scale=ctx.wscale)   # w' = w * wscale (gan.py:79)
             if sw is not None:
                 dw = None
                 db = None if sb is not None else db
         else:
-            if ctx.needs_input_grad[1]:
+            if want_w:
                 dw = _ConvWgrad.apply(x, dpre, w.shape[0], ctx.wscale)
             if need_b:
                 db = _ChannelSum.apply(dpre)
@@ -532,3 +573,65 @@ class _ConvT3x3(torch.autograd.Function):
 
 def convT3x3s2(x, w, bias=None):
     return _ConvT3x3.apply(x, w, bias)
+
+
+# ---------------------------------------------------------------------------------------------
+# minibatch-stdev feature map (gan.py:204-212), up to second order; WGAN-GP loss algebra (gan.py:715-729)
+# ---------------------------------------------------------------------------------------------
+class _MbStdMap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, groups, cells):
+        x = x.contiguous()
+        ctx.groups = groups
+        ctx.save_for_backward(x)
+        return ops.mbstd_map(x, groups, cells)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return _MbStdMapBwd.apply(x, dy.contiguous(), ctx.groups), None, None
+
+
+class _MbStdMapBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dy, groups):
+        ctx.groups = groups
+        ctx.save_for_backward(x, dy)
+        return ops.mbstd_map_bwd(x, dy, groups)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v):
+        x, dy = ctx.saved_tensors
+        ddy, dx2 = ops.mbstd_map_bwd2(x, dy, v.contiguous(), ctx.groups)
+        return dx2, ddy, None
+
+
+def mbstd_map(x, groups=1, cells=16):
+    """(N, cells) map holding the minibatch statistic of each of `groups` stacked minibatches; differentiable twice"""
+    return _MbStdMap.apply(x, int(groups), int(cells))
+
+
+class _WganLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Dz, Dx, gn2):
+        Dz = Dz.contiguous()
+        Dx = Dx.contiguous() if Dx is not None else None
+        gn2 = gn2.contiguous() if gn2 is not None else None
+        ctx.save_for_backward(Dz, Dx, gn2)
+        out = ops.wgan_losses(Dz, Dx, gn2)
+        return out[0], out[1]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gd, gg):
+        Dz, Dx, gn2 = ctx.saved_tensors
+        dDz, dDx, dgn2 = ops.wgan_losses_bwd(Dz, Dx, gn2, gd.contiguous() if gd is not None else None,
+                                             gg.contiguous() if gg is not None else None)
+        return dDz, dDx, dgn2
+
+
+def wgan_losses(Dz, Dx=None, gn2=None):
+    """(d_loss, g_loss) of gan.py:715-729 from the discriminator outputs and the per-sample squared gradient norm of
+    D(mix); with Dz alone: (unused, g_loss = mean(-Dz))"""
+    return _WganLosses.apply(Dz, Dx, gn2)

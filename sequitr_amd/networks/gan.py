@@ -11,8 +11,8 @@ reference's (``GAN/generator/latent/conv/filter`` ...).
 What differs on purpose: the data source is a ``.npy`` stack or synthetic
 tiles instead of a TFRecord (TFRecord IO is out of scope); checkpoints are ``model_(HxW).npz``;
 ``predict`` uses its ``latent`` argument (the reference feeds an undefined global, gan.py:923);
-the minibatch-stdev statistic (0.26 M elements) and the (N,)-sized loss algebra run as torch
-tensor ops -- everything that touches an image-sized tensor is a hand-written HIP kernel.
+every forward and gradient op, including the minibatch-stdev statistic and the (N,)-sized loss
+algebra, is a hand-written HIP kernel (torch supplies the tape, the concatenation and the copies).
 """
 import json
 import logging
@@ -106,14 +106,10 @@ def dense(inputs, units, activation=None, name='dense'):
 
 def minibatch_stdev(x, groups=1):
     """gan.py:204-212: sqrt(mean over (h,w,c) of the population variance over the batch), as a
-    constant feature map (N,4,4,1).  0.26 M elements: torch tensor ops (differentiable twice).
+    constant feature map (N,4,4,1): one workgroup per minibatch (sq_mbstd_map_*_f32, differentiable twice).
     groups > 1: x is `groups` minibatches stacked along the batch axis, each gets its own statistic
     (the reference evaluates the discriminator once per minibatch; see _build_network)."""
-    n = x.shape[0] // groups
-    xg = x.reshape((groups, n) + tuple(x.shape[1:]))
-    var = xg.var(dim=1, unbiased=False).reshape(groups, -1).mean(dim=1)
-    stdev = torch.sqrt(var).reshape(groups, 1, 1, 1, 1)
-    return (torch.ones((groups, n, 4, 4, 1), dtype=torch.float32, device=x.device) * stdev).reshape(x.shape[0], 4, 4, 1)
+    return F.mbstd_map(x, groups, 16).reshape(x.shape[0], 4, 4, 1)
 
 
 def discriminator_network(x, filters, groups=1):
@@ -395,13 +391,10 @@ class GenerativeAdverserialNetwork(object):
             r = self._mixing_r(X.shape[0])
         mix = F.lerp(X_resized, Gz.detach(), r).detach().requires_grad_(True)
         _, Dmix = self.discriminator(mix, d_filters)
-        grad = torch.autograd.grad(Dmix.sum(), mix, create_graph=True)[0]
-        grad_normed = torch.sqrt(F.dot_per_sample(grad, grad))
-        lipschitz_penalty = torch.square(torch.clamp(grad_normed - 1.0, min=0.0))
-        scaled_penalty = 10.0 * lipschitz_penalty
-        eps_penalty = 0.001 * torch.square(Dx)
-        g_loss = torch.mean(-Dz)
-        d_loss = torch.mean(-Dx + Dz + scaled_penalty + eps_penalty)
+        with F.grads_wanted([]):                                # the input gradient only: no weight / bias gradients
+            grad = torch.autograd.grad(Dmix.sum(), mix, create_graph=True)[0]
+        # one-sided penalty 10 max(|grad| - 1, 0)^2, drift 0.001 Dx^2, the two means: one launch (sq_wgan_losses_*)
+        d_loss, g_loss = F.wgan_losses(Dz, Dx, F.dot_per_sample(grad, grad))
         return Gz_raw, d_loss, g_loss
 
     def _allreduce(self, grads):
@@ -452,15 +445,17 @@ class GenerativeAdverserialNetwork(object):
     def _d_grads(self, X, Z, alpha, r):
         d_vars, _ = self.get_training_variables(self.current_level)
         _, d_loss, g_loss = self._build_network(X, Z, alpha, r=r, need_g_graph=False)
-        grads = torch.autograd.grad(d_loss, [v for _, v in d_vars], allow_unused=True)
+        with F.grads_wanted([v for _, v in d_vars]):            # not the block d_vars leaves out
+            grads = torch.autograd.grad(d_loss, [v for _, v in d_vars], allow_unused=True)
         return d_vars, grads, (d_loss.detach(), g_loss.detach())
 
     def _g_grads(self, X, Z, alpha):
         _, g_vars = self.get_training_variables(self.current_level)
         d_filters, _, Gz, _ = self._prepare(X, Z, alpha, need_g_graph=True)
         _, Dz = self.discriminator(Gz, d_filters)
-        g_loss = torch.mean(-Dz)
-        grads = torch.autograd.grad(g_loss, [v for _, v in g_vars], allow_unused=True)
+        _, g_loss = F.wgan_losses(Dz)
+        with F.grads_wanted([v for _, v in g_vars]):            # the pass runs THROUGH the discriminator: none of its weights
+            grads = torch.autograd.grad(g_loss, [v for _, v in g_vars], allow_unused=True)
         return g_vars, grads, (g_loss.detach(),)
 
     def _d_solver(self, X, Z, alpha, r=None):

@@ -381,9 +381,10 @@ def _grad_out(buf, shape, device):
     return buf
 
 
-def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None):
+def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None, dw_scale=1.0):
     """(dW (K,K,Cin,Cout), db (Cout) or None) from X (N,H,W,Cin) and dY (N,H,W,Cout).  dw_out / db_out:
-    optional float32 destinations the kernel writes straight into."""
+    optional float32 destinations the kernel writes straight into.  dw_scale: factor on dW (not db), applied in the
+    finish kernel (the equalised-LR factor of weighted_conv2d, gan.py:75-79)."""
     _chk(x, "x", ndim=4), _chk(dy, "dy", ndim=4)
     N, H, W, Cin = x.shape
     Cout = dy.shape[3]
@@ -393,10 +394,10 @@ def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None):
         P = N * H * W
         if K == 1 and P % 16 == 0:
             return conv2d_wgrad(x.view(1, P // 16, 16, Cin), dy.view(1, P // 16, 16, Cout), K, want_bias,
-                                dw_out, db_out)
+                                dw_out, db_out, dw_scale)
         plan = _mosaic_plan(N, H, W) if K == 3 else None
         if plan is not None:                                  # separator cells of dY are zero: they add nothing
-            return conv2d_wgrad(mosaic_pack(x, *plan), mosaic_pack(dy, *plan), K, want_bias, dw_out, db_out)
+            return conv2d_wgrad(mosaic_pack(x, *plan), mosaic_pack(dy, *plan), K, want_bias, dw_out, db_out, dw_scale)
     lib = _lib.load()
     mixed = MIXED and lib.sq_conv2d_nhwc_wgrad_workspace_mixed_f32(N, H, W, Cin, Cout, K) >= 0
     nbytes = (lib.sq_conv2d_nhwc_wgrad_workspace_mixed_f32 if mixed else lib.sq_conv2d_nhwc_wgrad_workspace_f32)(
@@ -406,10 +407,12 @@ def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None):
     ws = _workspace(nbytes, x.device)
     dw = _grad_out(dw_out, (K, K, Cin, Cout), x.device)
     db = _grad_out(db_out, (Cout,), x.device) if want_bias else None
-    if mixed:
-        _lib.check(lib.sq_conv2d_nhwc_wgrad_mixed_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin,
-                                                     Cout, K, _stream()), "sq_conv2d_nhwc_wgrad_mixed_f32")
-        return dw, db
+    if Cin <= 7 and dw_scale != 1.0:
+        raise _lib.SequitrHipError("conv2d_wgrad: dw_scale needs the MFMA kernels (Cin=%d)" % Cin)
+    fn = lib.sq_conv2d_nhwc_wgrad_scaled_mixed_f32 if mixed else lib.sq_conv2d_nhwc_wgrad_scaled_f32
+    _lib.check(fn(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout, K, float(dw_scale), _stream()),
+               "sq_conv2d_nhwc_wgrad_scaled_mixed_f32" if mixed else "sq_conv2d_nhwc_wgrad_scaled_f32")
+    return dw, db
     _lib.check(lib.sq_conv2d_nhwc_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout,
                                            K, _stream()), "sq_conv2d_nhwc_wgrad_f32")
     return dw, db
@@ -635,6 +638,64 @@ def mbstd(x):
     return out
 
 
+def mbstd_map(x, groups=1, cells=16):
+    """minibatch-stdev feature map (gan.py:204-212): x (G*n, ...) -> (G*n, cells) filled with each group's statistic"""
+    _chk(x, "x")
+    N = x.shape[0]
+    if N % groups:
+        raise ValueError("mbstd_map: batch %d is not %d equal groups" % (N, groups))
+    y = torch.empty((N, cells), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws = _workspace(lib.sq_mbstd_map_workspace(groups), x.device)
+    _lib.check(lib.sq_mbstd_map_fwd_f32(_ptr(x), _ptr(y), _ptr(ws), groups, N // groups, x.numel() // N, cells, _stream()),
+               "sq_mbstd_map_fwd_f32")
+    return y
+
+
+def mbstd_map_bwd(x, dy, groups=1):
+    _chk(x, "x"), _chk(dy, "dy")
+    N = x.shape[0]
+    dx = torch.empty_like(x)
+    lib = _lib.load()
+    ws = _workspace(lib.sq_mbstd_map_workspace(groups), x.device)
+    _lib.check(lib.sq_mbstd_map_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), _ptr(ws), groups, N // groups, x.numel() // N,
+                                       dy.numel() // N, _stream()), "sq_mbstd_map_bwd_f32")
+    return dx
+
+
+def mbstd_map_bwd2(x, dy, v, groups=1):
+    _chk(x, "x"), _chk(dy, "dy"), _chk(v, "v")
+    N = x.shape[0]
+    ddy, dx2 = torch.empty_like(dy), torch.empty_like(x)
+    lib = _lib.load()
+    ws = _workspace(lib.sq_mbstd_map_workspace(groups), x.device)
+    _lib.check(lib.sq_mbstd_map_bwd2_f32(_ptr(x), _ptr(dy), _ptr(v), _ptr(ddy), _ptr(dx2), _ptr(ws), groups, N // groups,
+                                        x.numel() // N, dy.numel() // N, _stream()), "sq_mbstd_map_bwd2_f32")
+    return ddy, dx2
+
+
+def wgan_losses(Dz, Dx=None, gn2=None):
+    """(d_loss, g_loss) as a 2-element device tensor (gan.py:715-729); Dx = gn2 = None: only g_loss is meaningful"""
+    _chk(Dz, "Dz")
+    if (Dx is None) != (gn2 is None):
+        raise ValueError("wgan_losses: Dx and gn2 go together")
+    if Dx is not None:
+        _chk(Dx, "Dx"), _chk(gn2, "gn2")
+    out = torch.empty((2,), dtype=torch.float32, device=Dz.device)
+    _lib.check(_lib.load().sq_wgan_losses_fwd_f32(_ptr(Dz), _ptr(Dx), _ptr(gn2), _ptr(out), Dz.numel(), _stream()),
+               "sq_wgan_losses_fwd_f32")
+    return out
+
+
+def wgan_losses_bwd(Dz, Dx, gn2, g_dloss, g_gloss):
+    dDz = torch.empty_like(Dz)
+    dDx = torch.empty_like(Dx) if Dx is not None else None
+    dgn2 = torch.empty_like(gn2) if gn2 is not None else None
+    _lib.check(_lib.load().sq_wgan_losses_bwd_f32(_ptr(Dz), _ptr(Dx), _ptr(gn2), _ptr(g_dloss), _ptr(g_gloss), _ptr(dDz),
+                                                 _ptr(dDx), _ptr(dgn2), Dz.numel(), _stream()), "sq_wgan_losses_bwd_f32")
+    return dDz, dDx, dgn2
+
+
 def wgrad1x1_small(a, b):
     """(Ca,Cb) = sum_p a[p,:]^T b[p,:]; a (...,Ca<=4), b (...,Cb%4==0) over the same pixels."""
     _chk(a, "a"), _chk(b, "b")
@@ -674,13 +735,20 @@ def conv_dgrad_raw(dy, w, wscale=1.0):
     return conv2d(dy, w, None, act=None, wscale=wscale, _dgrad=True)
 
 
-def conv_wgrad_raw(x, dy, K, want_bias=False, dw_out=None, db_out=None):
-    """(dW (K,K,Cin,Cout), db or None) for every channel mix the GAN / U-Net graphs use."""
+def conv_wgrad_raw(x, dy, K, want_bias=False, dw_out=None, db_out=None, dw_scale=1.0):
+    """(dW (K,K,Cin,Cout) * dw_scale, db or None) for every channel mix the GAN / U-Net graphs use; the factor rides
+    in the finish kernel on the MFMA paths and is one extra multiply kernel on the small image-side 1x1 forms."""
     Cin, Cout = x.shape[-1], dy.shape[-1]
     N, H, W = x.shape[0], x.shape[1], x.shape[2]
     lib = _lib.load()
     if Cout % 4 == 0 and lib.sq_conv2d_nhwc_wgrad_workspace_f32(N, H, W, Cin, Cout, K) >= 0:
-        return conv2d_wgrad(x, dy, K, want_bias=want_bias, dw_out=dw_out, db_out=db_out)
+        if Cin <= 7 and dw_scale != 1.0:
+            dw, db = conv2d_wgrad(x, dy, K, want_bias=want_bias, dw_out=dw_out, db_out=db_out)
+            return dw * dw_scale, db
+        return conv2d_wgrad(x, dy, K, want_bias=want_bias, dw_out=dw_out, db_out=db_out, dw_scale=dw_scale)
+    if dw_scale != 1.0:
+        dw, db = conv_wgrad_raw(x, dy, K, want_bias=want_bias, dw_out=dw_out, db_out=db_out)
+        return dw * dw_scale, db
     if dw_out is not None or db_out is not None:
         raise _lib.SequitrHipError("conv wgrad: gradient destinations need the MFMA kernel (Cin=%d Cout=%d)" % (Cin, Cout))
     npix = N * H * W

@@ -451,3 +451,64 @@ def test_nested_precision_blocks_do_not_reuse_stale_filter_packs():
         got = run(graph, nested)
         for k in want:
             assert np.array_equal(want[k], got[k]), (graph, nested, k)
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_mbstd_map_first_and_second_order_vs_fp64(groups):
+    """sq_mbstd_map_{fwd,bwd,bwd2}_f32 (the discriminator's minibatch-stdev feature, gan.py:204-212) against torch
+    autograd in fp64 of the reference expression: value, gradient, and the gradient of a function of the gradient
+    (what the WGAN-GP penalty needs), per stacked minibatch group."""
+    n, C = 6, 32
+    x = tiles(21, groups * n, 4, 4, C)
+    cot = tiles(22, groups * n, 4, 4, 1)
+    cot2 = tiles(23, groups * n, 4, 4, C)
+
+    def ref_map(xt):
+        outs = []
+        for g in range(groups):
+            xg = xt[g * n:(g + 1) * n]
+            s = torch.sqrt(xg.var(dim=0, unbiased=False).mean())
+            outs.append(torch.ones((n, 4, 4, 1), dtype=xt.dtype) * s)
+        return torch.cat(outs, 0)
+    xr = torch.as_tensor(x, dtype=torch.float64).requires_grad_(True)
+    cr = torch.as_tensor(cot, dtype=torch.float64).requires_grad_(True)
+    yr = ref_map(xr)
+    g1 = torch.autograd.grad(yr, xr, cr, create_graph=True)[0]
+    obj = (g1 * torch.as_tensor(cot2, dtype=torch.float64)).sum()
+    gx2, gc = torch.autograd.grad(obj, [xr, cr])
+
+    xd, cd = dev(x).requires_grad_(True), dev(cot).requires_grad_(True)
+    y = gan.minibatch_stdev(xd, groups)
+    assert tuple(y.shape) == (groups * n, 4, 4, 1)
+    close(y.detach().cpu().numpy(), yr.detach().numpy(), 1e-6, "mbstd map")
+    d1 = torch.autograd.grad(y, xd, cd, create_graph=True)[0]
+    close(d1.detach().cpu().numpy(), g1.detach().numpy(), 1e-5, "mbstd map gradient")
+    o = (d1 * dev(cot2)).sum()
+    dx2, dc = torch.autograd.grad(o, [xd, cd])
+    close(dx2.cpu().numpy(), gx2.numpy(), 1e-4, "mbstd map second order, d/dx")
+    close(dc.cpu().numpy(), gc.numpy(), 1e-4, "mbstd map second order, d/d(dy)")
+
+
+def test_fused_wgan_losses_vs_the_reference_expression():
+    """sq_wgan_losses_{fwd,bwd}_f32 against gan.py:715-729 written out in torch fp64 (one-sided penalty: samples with
+    |grad| < 1 contribute nothing, also to the gradient)."""
+    rng = np.random.default_rng(30)
+    N = 32
+    dz, dx = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32) * 3
+    gn2 = (rng.random(N).astype(np.float32) * 3.0) ** 2            # norms on both sides of 1
+    tz, tx, tg = [torch.as_tensor(a, dtype=torch.float64).requires_grad_(True) for a in (dz, dx, gn2)]
+    pen = 10.0 * torch.square(torch.clamp(torch.sqrt(tg) - 1.0, min=0.0))
+    rd, rg = torch.mean(-tx + tz + pen + 0.001 * torch.square(tx)), torch.mean(-tz)
+    gz, gxx, ggn = torch.autograd.grad(2.0 * rd + 3.0 * rg, [tz, tx, tg])
+    z, xx, g2 = [dev(a).requires_grad_(True) for a in (dz, dx, gn2)]
+    d_loss, g_loss = F.wgan_losses(z, xx, g2)
+    assert abs(d_loss.item() - rd.item()) <= 1e-5 * abs(rd.item()) and abs(g_loss.item() - rg.item()) <= 1e-6
+    a, b, c = torch.autograd.grad(2.0 * d_loss + 3.0 * g_loss, [z, xx, g2])
+    close(a.cpu().numpy(), gz.numpy(), 1e-5, "dDz")
+    close(b.cpu().numpy(), gxx.numpy(), 1e-5, "dDx")
+    close(c.cpu().numpy(), ggn.numpy(), 1e-5, "d gn2")
+    assert (c.cpu().numpy()[np.sqrt(gn2) < 1.0] == 0).all()
+    _, only_g = F.wgan_losses(z)
+    assert abs(only_g.item() - rg.item()) <= 1e-6
+    (a2,) = torch.autograd.grad(only_g, [z])
+    assert np.allclose(a2.cpu().numpy(), -1.0 / N)
