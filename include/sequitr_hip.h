@@ -232,6 +232,14 @@ int sq_bn_bwd_f32(const float *x, const float *dy, const float *y_act, int act, 
 int sq_pixelnorm_bwd_f32(const float *x, const float *dy, float *dx, int64_t npix, int C, float eps, void *stream);
 int sq_pixelnorm_bwd2_f32(const float *x, const float *g, const float *v, float *dg, float *dx2, int64_t npix,
                           int C, float eps, void *stream);
+/* pixel_norm backward + the backward of the activation that produced x (conv -> leaky -> pixel_norm, gan.py:90-98) in
+ * one pass: dx = act'(x) * pixelnorm_bwd(x, dy) */
+int sq_pixelnorm_bwd_act_f32(const float *x, const float *dy, float *dx, int64_t npix, int C, float eps, int act,
+                             void *stream);
+/* avg-pool backward (scale * 2x nearest up-sampling of src (N,H/2,W/2,C)) + the backward of the activation whose
+ * output is `gate` (N,H,W,C): the discriminator block's conv2 -> leaky -> avg-pool tail (gan.py:171-192) */
+int sq_broadcast2x2_act_bwd_f32(const float *src, const float *gate, float *dst, int N, int H, int W, int C, float scale,
+                                int act, void *stream);
 
 /* half_size / any tf.image.resize_nearest_neighbor(align_corners=True) (gan.py:128-136). */
 int sq_resize_nearest_f32(const float *x, float *y, int N, int Hi, int Wi, int Ho, int Wo, int C, void *stream);
@@ -350,6 +358,10 @@ int sq_conv_pack_weights_bf16(const float *w, void *wp, int K, int Cin, int Cout
  * total_items = sum of the entries' item counts (packed elements, or values for kind 1). */
 int sq_conv_pack_weights_multi_bf16(const float *base, void *out, const int32_t *table, int n_entries,
                                     int total_items, void *stream);
+/* the same with a factor per entry (`scales`, n_entries floats on the device) applied as sq_conv_pack_weights_bf16's
+ * wscale: all filter packs of a GAN solver step in one launch */
+int sq_conv_pack_weights_multi_scaled_bf16(const float *base, void *out, const int32_t *table, const float *scales,
+                                           int n_entries, int total_items, void *stream);
 
 /* conv_layer / weighted_conv2d on bf16 activations: y = act(conv(x, wp) + bias), fp32 accumulate. */
 int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H, int W,

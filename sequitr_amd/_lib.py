@@ -77,6 +77,8 @@ SIGNATURES = {
     "sq_adam_apply_dev_f32": (c_int, [c_void_p] * 4 + [c_int64, c_float, c_float, c_float, c_void_p, c_float, c_void_p]),
     "sq_pixelnorm_bwd_f32": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_float, c_void_p]),
     "sq_pixelnorm_bwd2_f32": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_float, c_void_p]),
+    "sq_pixelnorm_bwd_act_f32": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_float, c_int, c_void_p]),
+    "sq_broadcast2x2_act_bwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float, c_int, c_void_p]),
     "sq_resize_nearest_f32": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
     "sq_lerp_f32": (c_int, [c_void_p] * 3 + [c_int64, c_int64, c_float, c_void_p, c_void_p]),
     "sq_scale_f32": (c_int, [c_void_p] * 2 + [c_int64, c_int64, c_float, c_void_p, c_int, c_void_p]),
@@ -112,6 +114,7 @@ SIGNATURES = {
     "sq_maxpool2x2_fwd_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "sq_maxpool2x2_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "sq_conv_pack_weights_multi_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "sq_conv_pack_weights_multi_scaled_bf16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "sq_conv2d_nhwc_fwd_dropout_bf16": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_float, ctypes.c_uint32, c_void_p, c_void_p]),
     "sq_relu_scale_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_float, c_void_p]),
     "sq_bridge_bwd_s2d_bf16": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),

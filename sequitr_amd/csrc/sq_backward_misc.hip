@@ -92,6 +92,26 @@ __global__ __launch_bounds__(256) void broadcast2x2_kernel(const V *__restrict__
     }
 }
 
+// scale * nearest-neighbour 2x up-sampling, then the backward of the activation whose output `gate` (large side) is:
+// the gradient of avg-pool(act(conv)) w.r.t. the conv's pre-activation in one pass (discriminator blocks, gan.py:171-192)
+__global__ __launch_bounds__(256) void broadcast2x2_gate_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ gate,
+                                                                float4 *__restrict__ dx, int N, int H, int W, int C4,
+                                                                float scale, float slope) {
+    const int64_t total = (int64_t)N * H * W * C4;
+    SQ_GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        int64_t t = i / C4;
+        const int xx = (int)(t % W);
+        t /= W;
+        const int yy = (int)(t % H);
+        const int n = (int)(t / H);
+        const float4 g = vscale(dy[(((int64_t)n * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * C4 + c], scale);
+        const float4 v = gate[i];
+        dx[i] = make_float4(v.x > 0.f ? g.x : g.x * slope, v.y > 0.f ? g.y : g.y * slope,
+                            v.z > 0.f ? g.z : g.z * slope, v.w > 0.f ? g.w : g.w * slope);
+    }
+}
+
 template <typename V>
 __global__ __launch_bounds__(256) void sumpool2x2_kernel(const V *__restrict__ x, V *__restrict__ y,
                                                           int N, int H, int W, int C4, float scale) {
@@ -366,6 +386,20 @@ extern "C" int sq_broadcast2x2_f32(const float *src, float *dst, int N, int H, i
         hipLaunchKernelGGL(broadcast2x2_kernel<float>, dim3(grid_for((int64_t)N * H * W * C)), dim3(256), 0,
                            SQ_ST(stream), src, dst, N, H, W, C, scale);
     return sq_check_launch("sq_broadcast2x2_f32");
+}
+
+extern "C" int sq_broadcast2x2_act_bwd_f32(const float *src, const float *gate, float *dst, int N, int H, int W, int C,
+                                           float scale, int act, void *stream) {
+    SQ_REQUIRE(src && gate && dst, "sq_broadcast2x2_act_bwd_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0,
+               "sq_broadcast2x2_act_bwd_f32: need even H,W (large side) and C %% 4 == 0");
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_broadcast2x2_act_bwd_f32: bad activation %d", act);
+    SQ_REQUIRE_ALIGNED(src); SQ_REQUIRE_ALIGNED(gate); SQ_REQUIRE_ALIGNED(dst);
+    const float slope = act == SQ_ACT_LEAKY ? 0.2f : (act == SQ_ACT_RELU ? 0.0f : 1.0f);
+    hipLaunchKernelGGL(broadcast2x2_gate_kernel, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const float4 *>(src), reinterpret_cast<const float4 *>(gate),
+                       reinterpret_cast<float4 *>(dst), N, H, W, C / 4, scale, slope);
+    return sq_check_launch("sq_broadcast2x2_act_bwd_f32");
 }
 
 extern "C" int sq_sumpool2x2_f32(const float *x, float *y, int N, int H, int W, int C, float scale, void *stream) {

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float *__r
 __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const float *__restrict__ base,
                                                                        __bf16 *__restrict__ out,
                                                                        const int *__restrict__ table, int n_entries,
-                                                                       int total) {
+                                                                       int total, const float *__restrict__ scales) {
     __shared__ int tb[128 * 8];
     for (int i = threadIdx.x; i < n_entries * 8; i += 256) tb[i] = table[i];
     __syncthreads();
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
                 v = w[((size_t)((K - 1 - ky) * K + (K - 1 - kx)) * Cout + co) * Cin + c];
             }
         }
+        if (scales) v *= scales[lo];                           // the equalised-LR factor, as pack_weights_bf16_kernel
         wp[j] = (__bf16)v;
     }
 }
@@ -540,8 +541,21 @@ extern "C" int sq_conv_pack_weights_multi_bf16(const float *base, void *out, con
     int nb = (total_items + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(pack_weights_multi_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       base, reinterpret_cast<__bf16 *>(out), table, n_entries, total_items);
+                       base, reinterpret_cast<__bf16 *>(out), table, n_entries, total_items, (const float *)nullptr);
     return sq_check_launch("sq_conv_pack_weights_multi_bf16");
+}
+
+// the same with one factor per entry (scales: n_entries floats on the device): every filter pack of a GAN solver step
+// -- forward and dgrad form of each weighted_conv2d kernel, equalised-LR factor folded in (gan.py:75-79) -- in ONE launch
+extern "C" int sq_conv_pack_weights_multi_scaled_bf16(const float *base, void *out, const int32_t *table,
+                                                      const float *scales, int n_entries, int total_items, void *stream) {
+    SQ_REQUIRE(base && out && table && scales && n_entries > 0 && n_entries <= 128 && total_items > 0,
+               "sq_conv_pack_weights_multi_scaled_bf16: bad arguments (at most 128 entries)");
+    int nb = (total_items + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(pack_weights_multi_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       base, reinterpret_cast<__bf16 *>(out), table, n_entries, total_items, scales);
+    return sq_check_launch("sq_conv_pack_weights_multi_scaled_bf16");
 }
 
 // conv_layer / weighted_conv2d on bf16 tensors: x (N,H,W,Cin) bf16, wp from sq_conv_pack_weights_bf16,

@@ -30,7 +30,10 @@ __device__ __forceinline__ float group16_sum(float v) {
 template <int MODE>
 __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                                              const float *__restrict__ v, float *__restrict__ out1,
-                                                             float *__restrict__ out2, int64_t npix, int C, float eps) {
+                                                             float *__restrict__ out2, int64_t npix, int C, float eps,
+                                                             float gate_slope) {
+    // gate_slope (MODE 1 only): 1 = plain; otherwise x is the output of an activation (leaky 0.2 / ReLU 0) and dx leaves
+    // already through that activation's backward, x > 0 ? dx : dx * slope -- the act_bwd pass that would follow
     const int lane = threadIdx.x & 63, l16 = lane & 15, sub = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
@@ -60,9 +63,13 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float *__restr
                 const float4 xv = *reinterpret_cast<const float4 *>(x + p * C + c);
                 const float4 gv = *reinterpret_cast<const float4 *>(g + p * C + c);
                 if (MODE == 1) {
-                    *reinterpret_cast<float4 *>(out1 + p * C + c) =
-                        make_float4(r * gv.x - r3 * s * xv.x, r * gv.y - r3 * s * xv.y, r * gv.z - r3 * s * xv.z,
-                                    r * gv.w - r3 * s * xv.w);
+                    float4 o = make_float4(r * gv.x - r3 * s * xv.x, r * gv.y - r3 * s * xv.y, r * gv.z - r3 * s * xv.z,
+                                           r * gv.w - r3 * s * xv.w);
+                    if (gate_slope != 1.0f) {
+                        o.x = xv.x > 0.f ? o.x : o.x * gate_slope; o.y = xv.y > 0.f ? o.y : o.y * gate_slope;
+                        o.z = xv.z > 0.f ? o.z : o.z * gate_slope; o.w = xv.w > 0.f ? o.w : o.w * gate_slope;
+                    }
+                    *reinterpret_cast<float4 *>(out1 + p * C + c) = o;
                 } else {
                     const float4 vv = *reinterpret_cast<const float4 *>(v + p * C + c);
                     *reinterpret_cast<float4 *>(out1 + p * C + c) =
@@ -299,8 +306,21 @@ extern "C" int sq_pixelnorm_bwd_f32(const float *x, const float *dy, float *dx, 
     SQ_REQUIRE(x && dy && dx && npix > 0 && C > 0 && C % 4 == 0, "sq_pixelnorm_bwd_f32: bad arguments (C %% 4 == 0)");
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(dx);
     hipLaunchKernelGGL(pixelnorm_bwd_kernel<1>, dim3(grid_for(npix * 16)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr,
-                       dx, nullptr, npix, C, eps);
+                       dx, nullptr, npix, C, eps, 1.0f);
     return sq_check_launch("sq_pixelnorm_bwd_f32");
+}
+
+// pixel_norm backward followed by the backward of the activation whose output x is (weighted_conv2d: conv -> leaky ->
+// pixel_norm, gan.py:90-98): dx = act'(x) * pixelnorm_bwd(x, dy), one pass instead of two
+extern "C" int sq_pixelnorm_bwd_act_f32(const float *x, const float *dy, float *dx, int64_t npix, int C, float eps, int act,
+                                        void *stream) {
+    SQ_REQUIRE(x && dy && dx && npix > 0 && C > 0 && C % 4 == 0, "sq_pixelnorm_bwd_act_f32: bad arguments (C %% 4 == 0)");
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_pixelnorm_bwd_act_f32: bad activation %d", act);
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(dx);
+    const float slope = act == SQ_ACT_LEAKY ? 0.2f : (act == SQ_ACT_RELU ? 0.0f : 1.0f);
+    hipLaunchKernelGGL(pixelnorm_bwd_kernel<1>, dim3(grid_for(npix * 16)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr,
+                       dx, nullptr, npix, C, eps, slope);
+    return sq_check_launch("sq_pixelnorm_bwd_act_f32");
 }
 
 extern "C" int sq_pixelnorm_bwd2_f32(const float *x, const float *g, const float *v, float *dg, float *dx2,
@@ -309,7 +329,7 @@ extern "C" int sq_pixelnorm_bwd2_f32(const float *x, const float *g, const float
                "sq_pixelnorm_bwd2_f32: bad arguments (C %% 4 == 0)");
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(g); SQ_REQUIRE_ALIGNED(v); SQ_REQUIRE_ALIGNED(dg); SQ_REQUIRE_ALIGNED(dx2);
     hipLaunchKernelGGL(pixelnorm_bwd_kernel<2>, dim3(grid_for(npix * 16)), dim3(256), 0, SQ_ST(stream), x, g, v, dg,
-                       dx2, npix, C, eps);
+                       dx2, npix, C, eps, 1.0f);
     return sq_check_launch("sq_pixelnorm_bwd2_f32");
 }
 

@@ -171,6 +171,43 @@ def act(x, kind):
     return _Act.apply(x, kind) if ops.ACT[kind] else x
 
 
+class ActGate(object):
+    """Backward of a convolution's fused activation as an epilogue of the kernel that produces the gradient.
+    conv2d() hangs one of these on its output y (when FUSE_ACT_GATES is on); an op that is y's ONLY differentiable
+    consumer and whose backward kernel can apply act'(y) for free -- pixel_norm (y is its own input) and the 2x2
+    average pool (y is read for 4 bytes per element) -- takes it in FIRST-ORDER backward passes (grad mode off; the
+    penalty's create_graph pass keeps the separate differentiable _ActBwd), applies the gate and sets `applied`;
+    _Conv2d.backward then skips its own act_bwd pass (12 % of the GAN iteration).  Same multiply, same bits.
+    The single-consumer premise holds for the reference's generator / discriminator wiring (gan.py:149-316: a conv's
+    activation output feeds pixel_norm, the next conv or the pool, never two of them); it is a switch, default off,
+    that GenerativeAdverserialNetwork turns on around its solver steps."""
+
+    def __init__(self, act):
+        self.act, self.applied = act, False
+
+
+FUSE_ACT_GATES = False
+
+
+class fuse_act_gates(object):
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global FUSE_ACT_GATES
+        self.prev, FUSE_ACT_GATES = FUSE_ACT_GATES, self.on
+
+    def __exit__(self, *exc):
+        global FUSE_ACT_GATES
+        FUSE_ACT_GATES = self.prev
+        return False
+
+
+def _gate_of(t):
+    g = getattr(t, '_sq_act_gate', None)
+    return g if isinstance(g, ActGate) else None
+
+
 class _ChannelSum(torch.autograd.Function):
     """db[c] = sum over pixels of t[..., c]."""
 
@@ -193,7 +230,8 @@ class _Conv2d(torch.autograd.Function):
     """Fused forward kernel: act(conv2d(x, w*wscale) + bias)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, act, wscale):
+    def forward(ctx, x, w, bias, act, wscale, gate):
+        ctx.gate = gate
         y = ops.conv2d(x, w, bias, act=act, wscale=wscale)
         ctx.act, ctx.wscale, ctx.has_bias = act, wscale, bias is not None
         ctx.w_id, ctx.bias_id = _pid(w), _pid(bias)
@@ -204,14 +242,17 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        dpre = _ActBwd.apply(dy, y, ctx.act) if y is not None else dy.contiguous()
+        gated = ctx.gate is not None and ctx.gate.applied       # the producer of dy applied act'(y) already (ActGate)
+        if ctx.gate is not None:
+            ctx.gate.applied = False
+        dpre = _ActBwd.apply(dy, y, ctx.act) if (y is not None and not gated) else dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _ConvDgrad.apply(dpre, w, ctx.wscale)
         want_w = ctx.needs_input_grad[1] and _want(ctx.w_id)
         need_b = ctx.has_bias and ctx.needs_input_grad[2] and _want(ctx.bias_id)
         if not want_w and not need_b:
-            return dx, None, None, None, None
+            return dx, None, None, None, None, None
         if want_w and not torch.is_grad_enabled():
             # first-order fast path: dW and db from ONE pass of the wgrad kernel
             sw, sb = ctx.sinks
@@ -228,11 +269,15 @@ class _Conv2d(torch.autograd.Function):
                 dw = _ConvWgrad.apply(x, dpre, w.shape[0], ctx.wscale)
             if need_b:
                 db = _ChannelSum.apply(dpre)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def conv2d(x, w, bias=None, act=None, wscale=1.0):
-    return _Conv2d.apply(x, w, bias, act, float(wscale))
+    gate = ActGate(act) if (FUSE_ACT_GATES and ops.ACT[act]) else None
+    y = _Conv2d.apply(x, w, bias, act, float(wscale), gate)
+    if gate is not None:
+        y._sq_act_gate = gate
+    return y
 
 
 def dense(x, w, bias=None, act=None):
@@ -271,15 +316,18 @@ def conv1x1_head(x, w, bias=None):
 # ---------------------------------------------------------------------------------------------
 class _PixelNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps):
-        ctx.eps = eps
+    def forward(ctx, x, eps, gate):
+        ctx.eps, ctx.gate = eps, gate
         ctx.save_for_backward(x)
         return ops.pixelnorm(x, eps)
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return _PixelNormBwd.apply(x, dy, ctx.eps), None
+        if ctx.gate is not None and not torch.is_grad_enabled():
+            ctx.gate.applied = True                             # x = act(conv): act'(x) rides in this kernel (ActGate)
+            return ops.pixelnorm_bwd(x, dy.contiguous(), ctx.eps, act=ctx.gate.act), None, None
+        return _PixelNormBwd.apply(x, dy, ctx.eps), None, None
 
 
 class _PixelNormBwd(torch.autograd.Function):
@@ -299,7 +347,7 @@ class _PixelNormBwd(torch.autograd.Function):
 
 
 def pixel_norm(x, epsilon=1e-8):
-    return _PixelNorm.apply(x, float(epsilon))
+    return _PixelNorm.apply(x, float(epsilon), _gate_of(x))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -309,15 +357,21 @@ class _Pool2x2(torch.autograd.Function):
     """scale * (sum of each 2x2 patch); scale 0.25 = tf.layers.average_pooling2d (gan.py:189-192)."""
 
     @staticmethod
-    def forward(ctx, x, scale):
-        ctx.scale = scale
+    def forward(ctx, x, scale, gate=None):
+        ctx.scale, ctx.gate = scale, gate
+        if gate is not None:
+            ctx.save_for_backward(x)
         if scale == 0.25 and x.shape[-1] % 4 == 0:
             return ops.avgpool2x2(x)                          # ((a+b)+(c+d))*0.25, the oracle's order
         return ops.sumpool2x2(x.contiguous(), scale)
 
     @staticmethod
     def backward(ctx, dy):
-        return _Bcast2x2.apply(dy, ctx.scale), None
+        if ctx.gate is not None and not torch.is_grad_enabled() and ctx.saved_tensors[0].shape[-1] % 4 == 0:
+            (x,) = ctx.saved_tensors                            # x = act(conv): act'(x) rides in the up-sampling (ActGate)
+            ctx.gate.applied = True
+            return ops.broadcast2x2_act_bwd(dy.contiguous(), x, ctx.scale, ctx.gate.act), None, None
+        return _Bcast2x2.apply(dy, ctx.scale), None, None
 
 
 class _Bcast2x2(torch.autograd.Function):
@@ -330,11 +384,11 @@ class _Bcast2x2(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        return _Pool2x2.apply(dy.contiguous(), ctx.scale), None
+        return _Pool2x2.apply(dy.contiguous(), ctx.scale, None), None
 
 
 def avgpool2x2(x):
-    return _Pool2x2.apply(x, 0.25)
+    return _Pool2x2.apply(x, 0.25, _gate_of(x))
 
 
 def double_size(x):

@@ -233,8 +233,10 @@ class GenerativeAdverserialNetwork(object):
         self.learning_rate = params.get('learning_rate', 1e-3)
         self.batch_d = bool(params.get('batch_d', True))     # D(Gz) and D(X) in one stacked pass (default discriminator only)
         self._default_d = discriminator_fn is discriminator_network
+        self._default_g = generator_fn is generator_network   # ActGate fusion needs the reference's wiring (single consumers)
         self.use_graph = bool(params.get('graph', False))    # replay the solver steps as hipGraphs
         self._graphs = {}
+        self._plan = None
         self._capture_stream = None
         self.dtype = params.get('dtype', 'f32')
         if self.dtype not in ('f32', 'bf16'):
@@ -345,7 +347,23 @@ class GenerativeAdverserialNetwork(object):
                 self.networks.append((i, 'd_loss', 'g_loss', 'd_solver', 'g_solver'))
                 self.expand()
         self.__level = 0
+        self.store.flatten()                                    # one contiguous parameter buffer (views keep their names)
+        self._plan = None
         self.initialized = True
+
+    def _pack_filters(self):
+        """dtype 'bf16': every bf16 filter pack of the solver step (forward + dgrad form of each equalised-LR conv
+        kernel) in one launch; the packs stay valid until the step's Adam update (ops.FilterPackPlan)."""
+        if self.dtype != 'bf16' or self.store.flat is None:
+            return
+        if self._plan is None:
+            named = []
+            for name, v in self.store.vars.items():
+                if name.endswith('/filter') and v.dim() == 4 and name in self.store.offsets:
+                    kh, kw, _, cout = v.shape
+                    named.append((name, v, self.store.offsets[name], float(np.sqrt(np.float32(2.0 / float(kh * kw * cout))))))
+            self._plan = ops.FilterPackPlan(self.store.flat, named)
+        self._plan.run()
 
     def _build_optimizers(self, level=0):
         return _Adam(self.learning_rate, 0.0, 0.99), _Adam(self.learning_rate, 0.0, 0.99)
@@ -424,7 +442,7 @@ class GenerativeAdverserialNetwork(object):
     def d_solver(self, X, Z, alpha, r=None):
         """d_opt.minimize(d_loss, var_list=d_vars) for the current level (gan.py:649)."""
         try:
-            with self.precision():
+            with self.precision(), F.fuse_act_gates(self._default_d and self._default_g):
                 if self._graphable(alpha) and r is None:
                     return self._solver_graphed('d', X, Z, alpha)
                 return self._d_solver(X, Z, alpha, r)
@@ -434,7 +452,7 @@ class GenerativeAdverserialNetwork(object):
     def g_solver(self, X, Z, alpha):
         """g_opt.minimize(g_loss, var_list=g_vars, global_step) for the current level (gan.py:650-651)."""
         try:
-            with self.precision():
+            with self.precision(), F.fuse_act_gates(self._default_d and self._default_g):
                 if self._graphable(alpha):
                     return self._solver_graphed('g', X, Z, alpha)
                 return self._g_solver(X, Z, alpha)
@@ -443,6 +461,7 @@ class GenerativeAdverserialNetwork(object):
 
     # the two halves of a solver step: (losses + gradients) and (Adam); the all-reduce sits between them
     def _d_grads(self, X, Z, alpha, r):
+        self._pack_filters()
         d_vars, _ = self.get_training_variables(self.current_level)
         _, d_loss, g_loss = self._build_network(X, Z, alpha, r=r, need_g_graph=False)
         with F.grads_wanted([v for _, v in d_vars]):            # not the block d_vars leaves out
@@ -450,6 +469,7 @@ class GenerativeAdverserialNetwork(object):
         return d_vars, grads, (d_loss.detach(), g_loss.detach())
 
     def _g_grads(self, X, Z, alpha):
+        self._pack_filters()
         _, g_vars = self.get_training_variables(self.current_level)
         d_filters, _, Gz, _ = self._prepare(X, Z, alpha, need_g_graph=True)
         _, Dz = self.discriminator(Gz, d_filters)

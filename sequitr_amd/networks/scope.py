@@ -20,6 +20,7 @@ class VariableStore(object):
         self.rng = np.random.default_rng(seed)
         self.trainable = trainable
         self.vars = {}                                        # insertion ordered
+        self.flat, self.offsets = None, {}                    # set by flatten()
 
     def __enter__(self):
         _store_stack.append(self)
@@ -39,6 +40,26 @@ class VariableStore(object):
         elif tuple(v.shape) != tuple(int(s) for s in shape):
             raise ValueError('variable %s exists with shape %s, wanted %s' % (name, tuple(v.shape), tuple(shape)))
         return v
+
+    def flatten(self):
+        """Move every variable into ONE contiguous fp32 buffer (each a 16-byte aligned view, a leaf again): what the
+        one-launch filter packing (ops.GanPackPlan) and any flat collective need.  Values, names and order are kept;
+        call after the variables exist (GenerativeAdverserialNetwork.build) and before anything caches their pointers."""
+        offs, total = {}, 0
+        for k, v in self.vars.items():
+            offs[k] = total
+            total += (v.numel() + 3) // 4 * 4
+        flat = torch.zeros(max(total, 4), dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            for k, v in list(self.vars.items()):
+                view = flat[offs[k]:offs[k] + v.numel()].view(v.shape)
+                view.copy_(v)
+                leaf = view.detach()
+                if self.trainable:
+                    leaf.requires_grad_(True)
+                self.vars[k] = leaf
+        self.flat, self.offsets = flat, offs
+        return flat
 
     def trainable_variables(self, scope=''):
         """[(name, tensor)] whose name starts with ``scope`` (tf.trainable_variables(scope=...)):

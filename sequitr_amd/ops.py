@@ -120,14 +120,76 @@ class mixed_precision:
 _PACKS = {}
 
 
+_PLANS = __import__('weakref').WeakSet()     # live FilterPackPlans: their packs go stale with every weight update too
+
+
 def invalidate_packs():
     """drop every cached bf16 filter pack (call after anything that writes parameters in place)"""
     _PACKS.clear()
+    for p in list(_PLANS):
+        p.fresh = False
+
+
+class FilterPackPlan(object):
+    """Every bf16 filter pack a solver step of the mixed-precision GAN needs -- the forward and the dgrad form of each
+    equalised-LR conv kernel, factor folded in -- as ONE launch over the flat parameter buffer
+    (sq_conv_pack_weights_multi_scaled_bf16) instead of one pack launch per use (97 per iteration at level 6).
+    `named` = [(name, leaf view of `flat`, float offset, wscale)].  run() packs and marks the plan fresh; any weight
+    update (invalidate_packs) marks it stale, after which _packed_filter falls back to packing on demand."""
+
+    def __init__(self, flat, named):
+        lib = _lib.load()
+        rows, scales, dst, item = [], [], 0, 0
+        self.views = {}
+        for name, leaf, off, wscale in named:
+            if leaf.dim() != 4 or leaf.shape[0] != leaf.shape[1]:
+                continue
+            K, _, Cin, Cout = leaf.shape
+            for transform, (ci, co) in ((0, (Cin, Cout)), (1, (Cout, Cin))):
+                if ci % 8 or co % 4:
+                    continue
+                n = lib.sq_conv_packed_weights_elems_bf16(K, ci, co)
+                if n <= 0:
+                    continue
+                rows.append([off, dst, K, ci, co, transform, item, 0])
+                scales.append(float(wscale))
+                self.views[(id(leaf), bool(transform))] = (dst, n, float(wscale), K, ci, co)
+                dst += (n + 7) // 8 * 8
+                item += n
+        if len(rows) > 128:
+            raise _lib.SequitrHipError("FilterPackPlan: %d packs exceed the 128-entry table" % len(rows))
+        self.flat, self.n, self.total, self.fresh = flat, len(rows), item, False
+        dev = flat.device
+        self.table = torch.tensor(rows if rows else [[0] * 8], dtype=torch.int32, device=dev).contiguous()
+        self.scales = torch.tensor(scales if scales else [1.0], dtype=torch.float32, device=dev)
+        self.out = torch.zeros(max(dst, 8), dtype=torch.bfloat16, device=dev)
+        self.leaves = [leaf for _, leaf, _, _ in named]         # keep the ids valid
+        _PLANS.add(self)
+
+    def run(self):
+        if self.n:
+            _lib.check(_lib.load().sq_conv_pack_weights_multi_scaled_bf16(
+                _ptr(self.flat), _ptr(self.out), _ptr(self.table), _ptr(self.scales), self.n, self.total, _stream()),
+                "sq_conv_pack_weights_multi_scaled_bf16")
+        self.fresh = True
+
+    def lookup(self, w, K, Cin, Cout, wscale, transform):
+        e = self.views.get((id(w), bool(transform)))
+        if e is None or not self.fresh:
+            return None
+        d0, n, ws, k, ci, co = e
+        if (k, ci, co) != (K, Cin, Cout) or ws != float(wscale):
+            return None
+        return self.out[d0:d0 + n]
 
 
 def _packed_filter(w, K, Cin, Cout, wscale, transform):
     """bf16 pack of the conv Cin -> Cout; transform: `w` is the FORWARD filter (K,K,Cout,Cin) of which this conv
     is the dgrad (taps rotated, channel roles swapped inside the pack kernel -- no separate transform pass)."""
+    for plan in list(_PLANS):                                    # the step's one-launch packs, while they are fresh
+        wp = plan.lookup(w, K, Cin, Cout, wscale, transform)
+        if wp is not None:
+            return wp
     cacheable = w.is_leaf and w.requires_grad
     key = (w.data_ptr(), K, Cin, Cout, float(wscale), bool(transform))
     if cacheable and key in _PACKS:
@@ -448,6 +510,18 @@ def broadcast2x2(src, scale=1.0):
     return dst
 
 
+def broadcast2x2_act_bwd(src, gate, scale, act):
+    """scale * 2x nearest up-sampling of src, passed through the backward of the activation whose output is `gate`"""
+    _chk(src, "src", ndim=4), _chk(gate, "gate", ndim=4)
+    N, h, w, C = src.shape
+    if tuple(gate.shape) != (N, 2 * h, 2 * w, C):
+        raise ValueError("gate %s does not match the up-sampled %s" % (tuple(gate.shape), (N, 2 * h, 2 * w, C)))
+    dst = torch.empty_like(gate)
+    _lib.check(_lib.load().sq_broadcast2x2_act_bwd_f32(_ptr(src), _ptr(gate), _ptr(dst), N, 2 * h, 2 * w, C, float(scale),
+                                                      ACT[act], _stream()), "sq_broadcast2x2_act_bwd_f32")
+    return dst
+
+
 def sumpool2x2(x, scale=1.0):
     """scale * (sum of every 2x2 patch); any channel count."""
     _chk(x, "x", ndim=4)
@@ -543,11 +617,16 @@ def axpy_(y, x, alpha=1.0):
 # ----------------------------------------------------------------------------------------------
 # GAN-side operators (include/sequitr_hip.h "GAN side")
 # ----------------------------------------------------------------------------------------------
-def pixelnorm_bwd(x, dy, eps=1e-8):
+def pixelnorm_bwd(x, dy, eps=1e-8, act=None):
+    """dx of pixel_norm; act: x is the output of that activation and its backward is applied in the same pass"""
     _chk(x, "x"), _chk(dy, "dy")
     C = x.shape[-1]
     dx = torch.empty_like(x)
     lib = _lib.load()
+    if ACT[act]:
+        _lib.check(lib.sq_pixelnorm_bwd_act_f32(_ptr(x), _ptr(dy), _ptr(dx), x.numel() // C, C, float(eps), ACT[act],
+                                               _stream()), "sq_pixelnorm_bwd_act_f32")
+        return dx
     _lib.check(lib.sq_pixelnorm_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), x.numel() // C, C, float(eps), _stream()),
                "sq_pixelnorm_bwd_f32")
     return dx

@@ -512,3 +512,28 @@ def test_fused_wgan_losses_vs_the_reference_expression():
     assert abs(only_g.item() - rg.item()) <= 1e-6
     (a2,) = torch.autograd.grad(only_g, [z])
     assert np.allclose(a2.cpu().numpy(), -1.0 / N)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_act_gate_fusion_gives_the_same_bits(dtype):
+    """functional.ActGate: in first-order backward passes the leaky-ReLU backward of a convolution rides in the kernel
+    that produces the gradient (pixel_norm backward in the generator, the average pool's up-sampling in the
+    discriminator) instead of a separate act_bwd pass.  Same multiply on the same values: weights after D and G
+    steps are bit-identical with the fusion on (default for the reference's networks) and off."""
+    rng = np.random.default_rng(12)
+    z = dev(rng.standard_normal((4, 1, 1, 512)).astype(np.float32))
+    x = dev(rng.standard_normal((4, 16, 16, 2)).astype(np.float32))
+
+    def run(fuse):
+        g = make_gan(dtype=dtype)
+        g._default_g = fuse                                     # the switch the solver steps read
+        g.set_level(2)
+        for alpha in (0.5, 1.0):
+            g.d_solver(x, z, alpha)
+            g.g_solver(x, z, alpha)
+        return g.store.state_dict(), g.last_losses
+    (wa, la), (wb, lb) = run(True), run(False)
+    assert la == lb
+    for k in wa:
+        assert np.array_equal(wa[k], wb[k]), k
+    assert not F.FUSE_ACT_GATES
