@@ -21,6 +21,7 @@
 //     wave w computes parity class w of the 2x2/s2 transpose conv on the matrix cores (A = its 16x32 slice of
 //     the kernel, in registers) and merges it into the halo image in LDS.  The up-scaled / merged level-0
 //     tensor (537 MB per 32-tile batch) is never written or re-read and the HBM-bound convT launch disappears.
+#include <stdlib.h>
 #include "sq_common.h"
 
 #ifndef SQ_TILE_INTERLEAVE
@@ -58,7 +59,11 @@ struct Cfg2 {
     static constexpr int HALO_H = TH + KS - 1;
     static constexpr int HP = HALO_W * HALO_H;
     static constexpr int PS = KC + 2;                       // pixel stride (floats): conflict-free B reads
-    static constexpr int BNS = (BN % 32 == 0) ? BN + 16 : BN;  // weight row stride: conflict-free A reads
+    // weight row stride: conflict-free A reads.  KC <= 16: rows of BN % 32 == 0 floats are padded by 16, so consecutive
+    // rows (= lane groups kk, kk + 1 of one ds_read_b32) alternate bank halves.  KC == 32 (a 32-channel stage, see
+    // load_frag) has no room for the padding: odd rows are stored with their two 16-float halves swapped (col ^ 16).
+    static constexpr int WSWZ = (KC == 32 && BN == 32) ? 16 : 0;
+    static constexpr int BNS = WSWZ ? BN : ((BN % 32 == 0) ? BN + 16 : BN);
     static constexpr int WROWS = KS * KS * KC;
     static constexpr int XS_FLOATS = HP * PS;
     static constexpr int WS_FLOATS = WROWS * BNS;
@@ -79,7 +84,8 @@ struct Cfg2 {
     static constexpr int WITEMS = WROWS * (BN / 4);
     static constexpr int WSLOTS = (WITEMS + 255) / 256;
     static constexpr int NSTEP = KS * KS * (KC / 4);
-    static constexpr int OCC = BN >= 64 ? 2 : (BN >= 32 ? 3 : 4);  // blocks per CU (LDS-limited)
+    static constexpr int OCC = (BN >= 64 || KC == 32) ? 2 : (BN >= 32 ? 3 : 4);  // blocks per CU (LDS-limited)
+    static_assert(KC <= 16 || (KC == 32 && BN == 32), "the 32-channel stage exists for the 32 -> 32 layers (LDS: 2 blocks per CU)");
     static_assert((XS_FLOATS * 4) % 16 == 0, "weight slab must start 16-B aligned");
     static_assert((WS_FLOATS * 4) % 16 == 0, "input patch must start 16-B aligned");
 };
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
                     const int r = idx / (BN / 4), q4 = idx % (BN / 4);
                     float4 v = wr[sl];
                     v.x *= wscale; v.y *= wscale; v.z *= wscale; v.w *= wscale;
-                    *reinterpret_cast<float4 *>(ws + r * C::BNS + q4 * 4) = v;
+                    *reinterpret_cast<float4 *>(ws + r * C::BNS + ((q4 * 4) ^ ((r & 1) ? C::WSWZ : 0))) = v;
                 }
             }
         }
@@ -380,13 +386,22 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
     const float *xb_lds = xs + ((4 * wv) * C::HALO_W + li) * C::PS + kk;
     const float *wa_lds = ws + kk * C::BNS + li;
 
+    // step st of an item.  KC <= 16: taps in raster order, 4 channels per step -- the chain of DESIGN section 3.
+    // KC == 32: ONE staged item holds two 16-channel chain chunks; the steps still walk chunk 0 (all taps) and then
+    // chunk 1 (all taps), so the fmaf chain is unchanged -- only barriers, commits and the weight restaging per MFMA
+    // are halved (a 32 -> 32 layer becomes a single-item-per-tile layer whose weights are staged once per block).
     auto load_frag = [&](int st, float (&a)[NR], float (&b)[4]) {
-        const int tap = st / (KC / 4), s = st % (KC / 4);
+        constexpr int SPC = KS * KS * 4;                          // steps per 16-channel chain chunk
+        const int sub = KC > 16 ? st / SPC : 0, sr = KC > 16 ? st % SPC : st;
+        constexpr int Q = KC > 16 ? 4 : KC / 4;
+        const int tap = sr / Q, s = sr % Q;
         const int ky = tap / KS, kx = tap % KS;
+        const int ch = sub * 16 + s * 4;                          // first channel of the step inside the staged item
 #pragma unroll
-        for (int nb = 0; nb < NR; ++nb) a[nb] = wa_lds[(tap * KC + s * 4) * C::BNS + nb * 16];
+        for (int nb = 0; nb < NR; ++nb)                           // row parity = kk & 1 (tap * KC + ch is even)
+            a[nb] = wa_lds[(tap * KC + ch) * C::BNS + ((nb * 16) ^ ((kk & 1) ? C::WSWZ : 0))];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b[r] = xb_lds[((r + ky) * C::HALO_W + kx) * C::PS + s * 4];
+        for (int r = 0; r < 4; ++r) b[r] = xb_lds[((r + ky) * C::HALO_W + kx) * C::PS + ch];
     };
 
     // activation as two selects (no per-element scalar branches in the store tail):
@@ -634,6 +649,11 @@ int launch_v2(const float *x, const float *w, const float *bias, float *y, int N
     return sq_check_launch("sq_conv2d_nhwc_fwd_f32(v2)");
 }
 
+inline bool stage32() {                                         // SQ_CONV_STAGE32=0: A/B switch back to 16-channel items
+    static const bool v = [] { const char *e = getenv("SQ_CONV_STAGE32"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 template <int KS, int KC>
 int dispatch_bn(const float *x, const float *w, const float *bias, float *y, int N, int H, int W, int Cin,
                 int Cout, float wscale, int act, const SqConvEpi &epi, hipStream_t st) {
@@ -643,6 +663,11 @@ int dispatch_bn(const float *x, const float *w, const float *bias, float *y, int
     const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * N;
     int bn = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16);
     while (bn > 16 && (int64_t)ntiles * ((Cout + bn - 1) / bn) < 2 * 256) bn >>= 1;
+    // 32 -> 32 (and wider-input) 3x3 layers on 32-channel blocks: stage 32 input channels per item (same chain)
+    if constexpr (KS == 3 && KC == 16) {
+        if (bn == 32 && Cin % 32 == 0 && !epi.x2 && stage32())
+            return launch_v2<32, 3, 32, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
+    }
     if (bn == 64) return launch_v2<64, KS, KC, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
     if (bn == 32) return launch_v2<32, KS, KC, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
     return launch_v2<16, KS, KC, false>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
