@@ -11,12 +11,15 @@ namespace {
 // read flat.  Block = 64 rows x 64 input pixels, wave w owns rows 16w..16w+15 and four
 // 16-pixel column blocks; a lane ends up with 4 consecutive o of one output pixel, so the
 // bridge operand is one 16-B load and the result one 16-B store.
-constexpr int CT_PS = 18;  // 16-channel chunk + 2 pad floats: conflict-free ds_read_b32
-
+// KCH input channels are staged per barrier pair: 16 (any Cin % 16 == 0) or 32 when Cin % 32 == 0 (same chain, c
+// ascending).  Measured on the decoder's three launches (Cin 64 / 128 / 256): KCH 16: 124 us average, KCH 64: 149 us
+// (33.8 KB of LDS per block: half the resident blocks, and these launches live on occupancy).
+template <int KCH>
 __global__ __launch_bounds__(256) void convT2x2_mfma_f32_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
     const float *__restrict__ skip, float *__restrict__ y, int64_t P, int H, int W, int Cin,
     int Cout, int bridge) {
+    constexpr int CT_PS = KCH + 2;  // chunk + 2 pad floats: conflict-free ds_read_b32 (stride = 2 mod 32)
     __shared__ __attribute__((aligned(16))) float as[64 * CT_PS];
     __shared__ __attribute__((aligned(16))) float xs[64 * CT_PS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -28,27 +31,26 @@ __global__ __launch_bounds__(256) void convT2x2_mfma_f32_kernel(
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int srow = tid >> 2, sq = tid & 3;  // staging: 64 rows x 4 float4
-    for (int cc = 0; cc < Cin; cc += 16) {
-        {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int QPR = KCH / 4;              // float4 per staged row
+    for (int cc = 0; cc < Cin; cc += KCH) {
+#pragma unroll
+        for (int it = 0; it < QPR / 4; ++it) {    // staging: 64 rows x QPR float4 over 256 threads
+            const int idx = tid + it * 256, srow = idx / QPR, sq = idx % QPR;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), u = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r0 + srow < 4 * Cout)                           // ragged last row block (Cout % 16 != 0)
                 v = *reinterpret_cast<const float4 *>(w + (size_t)(r0 + srow) * Cin + cc + sq * 4);
+            if (p0 + srow < P)
+                u = *reinterpret_cast<const float4 *>(x + (size_t)(p0 + srow) * Cin + cc + sq * 4);
             float *d = as + srow * CT_PS + sq * 4;
             *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.y);
             *reinterpret_cast<float2 *>(d + 2) = make_float2(v.z, v.w);
-        }
-        {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p0 + srow < P)
-                v = *reinterpret_cast<const float4 *>(x + (size_t)(p0 + srow) * Cin + cc + sq * 4);
-            float *d = xs + srow * CT_PS + sq * 4;
-            *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.y);
-            *reinterpret_cast<float2 *>(d + 2) = make_float2(v.z, v.w);
+            float *e = xs + srow * CT_PS + sq * 4;
+            *reinterpret_cast<float2 *>(e) = make_float2(u.x, u.y);
+            *reinterpret_cast<float2 *>(e + 2) = make_float2(u.z, u.w);
         }
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
+#pragma unroll 4
+        for (int s = 0; s < QPR; ++s) {
             const float a = as[(16 * wv + li) * CT_PS + s * 4 + kk];
             float b[4];
 #pragma unroll
@@ -169,8 +171,12 @@ extern "C" int sq_convT2x2s2_nhwc_fwd_f32(const float *x, const float *w, const 
     if (skip) SQ_REQUIRE_ALIGNED(skip);
     const int64_t P = (int64_t)N * H * W;
     dim3 grid((unsigned)((P + 63) / 64), (unsigned)((4 * Cout + 63) / 64));
-    hipLaunchKernelGGL(convT2x2_mfma_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       x, w, bias, skip, y, P, H, W, Cin, Cout, bridge);
+    if (Cin % 32 == 0)
+        hipLaunchKernelGGL(convT2x2_mfma_f32_kernel<32>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           x, w, bias, skip, y, P, H, W, Cin, Cout, bridge);
+    else
+        hipLaunchKernelGGL(convT2x2_mfma_f32_kernel<16>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           x, w, bias, skip, y, P, H, W, Cin, Cout, bridge);
     return sq_check_launch("sq_convT2x2s2_nhwc_fwd_f32");
 }
 
