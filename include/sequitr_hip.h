@@ -436,6 +436,11 @@ int sq_conv2d_nhwc_dgrad_relu_bf16(const void *dy, const void *wp_t, const void 
 /* the same with a factor on what passes (backward of dropout(ReLU(.)) = `gate`): gate > 0 ? dgrad * gate_scale : 0 */
 int sq_conv2d_nhwc_dgrad_gate_bf16(const void *dy, const void *wp_t, const void *gate, float gate_scale, void *dx, int N,
                                    int H, int W, int Cin, int Cout, int K, void *stream);
+/* dgrad of a decoder block's first conv with the junction backward (merged = bridge(up, skip), unet.py:312-319) in
+ * its epilogue: writes g (N,H/2,W/2,4*Cout) = d_up in the space-to-depth layout and dskip (N,H,W,Cout); d(merged) is
+ * never stored.  Same bits as the dgrad followed by sq_bridge_bwd_s2d_bf16. */
+int sq_conv2d_nhwc_dgrad_junction_bf16(const void *dy, const void *wp_t, const void *up, const void *skip, void *g,
+                                       void *dskip, int N, int H, int W, int Cin, int Cout, int K, int bridge, void *stream);
 int sq_bridge_fwd_bf16(const void *a, const void *b, void *y, int64_t n, int bridge, void *stream);
 int sq_bridge_bwd_bf16(const void *dy, const void *a, const void *b, void *da, void *db, int64_t n, int bridge,
                        void *stream);

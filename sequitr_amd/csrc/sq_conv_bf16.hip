@@ -42,6 +42,13 @@ struct SqDropEpi {
     unsigned seed;
     const int *step;
     float gscale = 1.f;     // factor applied where the gate passes (1: plain ReLU backward; 1/(1-rate): dropout + ReLU)
+    // decoder-junction backward in the epilogue (j_g != NULL): the conv's output dM = d(merged) is not stored; with the
+    // forward operands of merged = bridge(up, skip) the epilogue writes d_up in the space-to-depth layout the
+    // transpose-conv gradients consume (j_g (N,H/2,W/2,4*Cout)) and d_skip (j_dskip (N,H,W,Cout)) -- what
+    // sq_bridge_bwd_s2d_bf16 does in a pass of its own, same roundings
+    const __bf16 *j_up = nullptr, *j_skip = nullptr;
+    __bf16 *j_g = nullptr, *j_dskip = nullptr;
+    int j_bridge = 0;
 };
 
 __device__ __forceinline__ unsigned conv_hash32(unsigned a, unsigned b) {       // = hash32 of sq_ops_bf16.hip
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
     }
 }
 
-template <int BN, int KS, int KC, typename TIO>
+template <int BN, int KS, int KC, typename TIO, bool JN = false>    // JN: decoder-junction epilogue (SqDropEpi::j_*)
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const TIO *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
     TIO *__restrict__ y, int N, int H, int W, int Cin, int Cout, int act, int tiles_x, int tiles_y,
@@ -287,6 +294,69 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     auto epilogue = [&](int tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int gx = tx * TW + li;
+        if constexpr (JN) {
+            // junction form (dgrad: no bias, no activation): every forward operand of the tile is requested before the
+            // first is used -- one exposed HBM round trip per tile, not one per store
+            const int jb = (int)((size_t)N * H * W * Cout * 2);
+            const bool mul = drop.j_bridge == SQ_BRIDGE_MUL;
+            const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(drop.j_up), 0, mul ? jb : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(drop.j_skip), 0, mul ? jb : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t dsrsrc = __builtin_amdgcn_make_buffer_rsrc(drop.j_dskip, 0, jb, 0x00020000);
+            const __amdgpu_buffer_rsrc_t g2rsrc = __builtin_amdgcn_make_buffer_rsrc(drop.j_g, 0, jb, 0x00020000);
+            unsigned offs[NR][4];
+            bf16x4 uv[NR][4], kv[NR][4];
+#pragma unroll
+            for (int nb = 0; nb < NR; ++nb) {
+                const int co = n0 + nb * 16 + 4 * kg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gy = ty * TH + 4 * wv + r;
+                    const bool ok = gy < H && gx < W && co < Cout;
+                    offs[nb][r] = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 2) : OOB;
+                }
+            }
+            if (mul) {
+#pragma unroll
+                for (int nb = 0; nb < NR; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        uv[nb][r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(ursrc, offs[nb][r], 0, 0));
+                        kv[nb][r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(krsrc, offs[nb][r], 0, 0));
+                    }
+                __builtin_amdgcn_s_waitcnt(0x0F70);             // inside the branch, as for the gate below
+            }
+#pragma unroll
+            for (int nb = 0; nb < NR; ++nb) {
+                const int co = n0 + nb * 16 + 4 * kg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gy = ty * TH + 4 * wv + r;
+                    bf16x4 o, da, db;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[r][nb][j];
+                    da = o, db = o;
+                    if (mul) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            da[j] = (__bf16)((float)o[j] * (float)kv[nb][r][j]);
+                            db[j] = (__bf16)((float)o[j] * (float)uv[nb][r][j]);
+                        }
+                    } else if (drop.j_bridge == SQ_BRIDGE_SUB) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) db[j] = (__bf16)(-(float)o[j]);
+                    }
+                    const unsigned off = offs[nb][r];
+                    const unsigned goff = off == OOB ? OOB :
+                        (unsigned)((((((n * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * 4 + ((gy & 1) * 2 + (gx & 1))) * Cout) + co) * 2);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
+                        __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, db), dsrsrc, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
+                        __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, da), g2rsrc, goff, 0, 0);
+                    acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int nb = 0; nb < NR; ++nb) {
             const int co = n0 + nb * 16 + 4 * kg;
@@ -443,13 +513,17 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
     }
 }
 
-template <int BN, int KS, int KC, typename TIO>
+template <int BN, int KS, int KC, typename TIO, bool JN = false>
 int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int H, int W, int Cin, int Cout,
            int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
+    if constexpr (!JN && KS == 3 && sizeof(TIO) == 2) {         // the junction form is its own instantiation, so
+        if (drop.j_g)                                           // that the plain kernels keep their register budget
+            return launch<BN, KS, KC, TIO, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    }
     using C = CfgB<BN, KS, KC>;
     static bool attr_set = false;
     static int occ = 2;                                         // resident blocks per CU (registers / LDS)
-    auto kern = conv_mfma_bf16_kernel<BN, KS, KC, TIO>;
+    auto kern = conv_mfma_bf16_kernel<BN, KS, KC, TIO, JN>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
@@ -638,6 +712,28 @@ extern "C" int sq_conv2d_nhwc_dgrad_gate_bf16(const void *dy, const void *wp_t, 
     SqDropEpi d{0u, 1.f, 0u, nullptr};
     d.gscale = gate_scale;
     return conv_fwd_bf16_impl(dy, wp_t, nullptr, dx, N, H, W, Cin, Cout, K, SQ_ACT_NONE, stream, gate, d);
+}
+
+// dgrad of the first conv of a decoder block, fused with the backward of the junction that produced its input
+// (merged = bridge(up, skip), unet.py:312-319): g (N,H/2,W/2,4*Cout) = d_up in space-to-depth layout, dskip (N,H,W,Cout);
+// dM itself is never written.  Bit-identical to sq_conv2d_nhwc_fwd_bf16 (dgrad pack) + sq_bridge_bwd_s2d_bf16.
+extern "C" int sq_conv2d_nhwc_dgrad_junction_bf16(const void *dy, const void *wp_t, const void *up, const void *skip, void *g,
+                                                  void *dskip, int N, int H, int W, int Cin, int Cout, int K, int bridge,
+                                                  void *stream) {
+    SQ_REQUIRE(g && dskip, "sq_conv2d_nhwc_dgrad_junction_bf16: null output");
+    SQ_REQUIRE(K == 3, "sq_conv2d_nhwc_dgrad_junction_bf16: K=%d (the junction epilogue exists for the 3x3 form)", K);
+    SQ_REQUIRE(bridge >= SQ_BRIDGE_ADD && bridge <= SQ_BRIDGE_SUB, "sq_conv2d_nhwc_dgrad_junction_bf16: bad bridge %d", bridge);
+    SQ_REQUIRE(bridge != SQ_BRIDGE_MUL || (up && skip), "sq_conv2d_nhwc_dgrad_junction_bf16: eltwise_mul needs both forward operands");
+    SQ_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cout % 4 == 0, "sq_conv2d_nhwc_dgrad_junction_bf16: even H, W; Cout %% 4 == 0");
+    SQ_REQUIRE_ALIGNED(g); SQ_REQUIRE_ALIGNED(dskip);
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    d.j_up = reinterpret_cast<const __bf16 *>(up);
+    d.j_skip = reinterpret_cast<const __bf16 *>(skip);
+    d.j_g = reinterpret_cast<__bf16 *>(g);
+    d.j_dskip = reinterpret_cast<__bf16 *>(dskip);
+    d.j_bridge = bridge;
+    return conv_fwd_bf16_impl(dy, wp_t, nullptr, dskip /* placeholder: never stored through */, N, H, W, Cin, Cout, K,
+                              SQ_ACT_NONE, stream, nullptr, d);
 }
 
 // first conv of down0 in the bf16 graph: f32 image (1..7 channels) in, bf16 activation out.

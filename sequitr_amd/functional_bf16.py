@@ -89,6 +89,32 @@ def _gate_of(t):
 
 
 FUSE_GATE = __import__("os").environ.get("SQ_FUSE_GATE", "1") != "0"    # A/B switch
+FUSE_JUNCTION = __import__("os").environ.get("SQ_FUSE_JUNCTION", "1") != "0"
+
+
+class JunctionHandoff(object):
+    """The decoder junction's backward as the epilogue of the kernel that produces its incoming gradient.
+    merged = bridge(up, skip) feeds exactly one op, conv1 of the block (unet.py:312-321); conv1's dgrad kernel can
+    therefore form d_up (in the space-to-depth layout the transpose-conv gradients take) and d_skip in its epilogue and
+    never write d(merged) (sq_conv2d_nhwc_dgrad_junction_bf16): one write and one read of a full-resolution tensor
+    less per decoder level than the stand-alone sq_bridge_bwd_s2d_bf16 pass, same roundings.  up_junction() hangs
+    one of these on `merged`; conv_block() passes it to its tape entry, whose backward leaves (g, dskip) in
+    `result` and hands autograd a zero-stride placeholder as the gradient of `merged`; _UpJunction.backward picks
+    the result up instead of reading that gradient."""
+
+    def __init__(self):
+        self.up = self.skip = self.kind = self.result = None
+
+
+_ZEROS = {}
+
+
+def _placeholder_grad(like):
+    key = (like.device, like.dtype)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros((), dtype=like.dtype, device=like.device)
+    return z.expand(like.shape)
 
 
 class _ConvBlock(torch.autograd.Function):
@@ -100,9 +126,9 @@ class _ConvBlock(torch.autograd.Function):
     x is the bf16 block input, or the f32 single-channel image for down0."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, rate, seed, mask, step_dev, gate):
+    def forward(ctx, x, w1, b1, w2, b2, rate, seed, mask, step_dev, gate, junction):
         first = x.dtype == torch.float32
-        ctx.gate = gate
+        ctx.gate, ctx.junction = gate, junction
         f = w1.shape[3]
         y1 = ob.conv3x3_first(x, w1, b1, act='relu') if first else ob.conv2d(x, ob.pack_weights(w1), b1, 3, f, act='relu')
         m = y2 = None
@@ -145,9 +171,16 @@ class _ConvBlock(torch.autograd.Function):
             dx = None
         else:
             dw1, db1 = ob.conv2d_wgrad(x, d1, 3, want_bias=True, dw_out=s1w, db_out=s1b)
-            dx = ob.conv2d(d1, ob.pack_weights(w1, transform=True), None, 3, x.shape[3]) if ctx.needs_input_grad[0] else None
+            dx = None
+            if ctx.needs_input_grad[0] and ctx.junction is not None:
+                j = ctx.junction                                # x = merged: the junction's backward rides in this dgrad
+                j.result = ob.conv2d_dgrad_junction(d1, ob.pack_weights(w1, transform=True), j.up, j.skip, j.kind, 3,
+                                                    x.shape[3])
+                dx = _placeholder_grad(x)
+            elif ctx.needs_input_grad[0]:
+                dx = ob.conv2d(d1, ob.pack_weights(w1, transform=True), None, 3, x.shape[3])
         return (dx, None if s1w is not None else dw1, None if s1b is not None else db1,
-                None if s2w is not None else dw2, None if s2b is not None else db2, None, None, None, None, None)
+                None if s2w is not None else dw2, None if s2b is not None else db2, None, None, None, None, None, None)
 
 
 def conv_block(x, w1, b1, w2, b2, rate=0.0, seed=0, mask=None, step_dev=None):
@@ -155,7 +188,10 @@ def conv_block(x, w1, b1, w2, b2, rate=0.0, seed=0, mask=None, step_dev=None):
     if FUSE_GATE and mask is None:                               # pinned masks keep the separate mask kernels
         rate = float(rate)
         gate = BlockGate(float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) if rate > 0.0 else 1.0)
-    out = _ConvBlock.apply(x, w1, b1, w2, b2, float(rate), int(seed), mask, step_dev, gate)
+    junction = getattr(x, '_sq_junction', None)
+    if not isinstance(junction, JunctionHandoff):
+        junction = None
+    out = _ConvBlock.apply(x, w1, b1, w2, b2, float(rate), int(seed), mask, step_dev, gate, junction)
     if gate is not None:
         out._sq_gate = gate
     return out
@@ -200,8 +236,8 @@ class _UpJunction(torch.autograd.Function):
     skip tensor's pool shares a `box`, hands d_skip to that pool's backward instead of to autograd."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, skip, kind, box, gate):
-        ctx.gate = gate
+    def forward(ctx, x, w, bias, skip, kind, box, gate, handoff):
+        ctx.gate, ctx.handoff = gate, handoff
         if kind == 'eltwise_mul' and _UPJ_BOTH:                 # `up` is needed by the backward: both from one pass
             up, merged = ob.convT2x2s2_bridge_both(x, ob.to_bf16(w), bias, skip, kind)
         elif kind == 'eltwise_mul':
@@ -210,6 +246,8 @@ class _UpJunction(torch.autograd.Function):
         else:                                                   # add / sub: the up-scaled tensor is not kept at all
             up, merged = None, ob.convT2x2s2(x, ob.to_bf16(w), bias, skip, kind)
         keep = kind == 'eltwise_mul'
+        if handoff is not None:
+            handoff.up, handoff.skip, handoff.kind = (up if keep else None), (skip if keep else None), kind
         ctx.save_for_backward(x, w, up if keep else None, skip if keep else None)
         ctx.kind, ctx.box, ctx.has_bias = kind, box, bias is not None
         ctx.sinks = (grad_sink(w), grad_sink(bias))
@@ -220,7 +258,11 @@ class _UpJunction(torch.autograd.Function):
     def backward(ctx, dm):
         x, w, up, skip = ctx.saved_tensors
         Cout, Cin = w.shape[2], w.shape[3]
-        g, dskip = ob.bridge_bwd_s2d(dm.contiguous(), up, skip, ctx.kind)
+        if ctx.handoff is not None and ctx.handoff.result is not None:
+            g, dskip = ctx.handoff.result                       # formed in conv1's dgrad epilogue (JunctionHandoff)
+            ctx.handoff.result = None
+        else:
+            g, dskip = ob.bridge_bwd_s2d(dm.contiguous(), up, skip, ctx.kind)
         dx = None
         if ctx.needs_input_grad[0]:
             packs = getattr(w, '_sq_packs', None) or {}
@@ -236,13 +278,19 @@ class _UpJunction(torch.autograd.Function):
         if ctx.box is not None and ctx.needs_input_grad[3]:
             ctx.box['dskip'] = dskip                            # picked up by the skip tensor's pool backward
             dskip = None
-        return dx, dw, db, dskip, None, None, None
+        return dx, dw, db, dskip, None, None, None, None
 
 
-def up_junction(x, w, bias, skip, kind, box=None, x_single_use=False):
+def up_junction(x, w, bias, skip, kind, box=None, x_single_use=False, merged_single_use=False):
     """x_single_use: the caller guarantees this junction is the only differentiable consumer of x (U-Net wiring:
-    net[-1] feeds the next up_layer and nothing else), which lets x's block gate ride in the dgrad epilogue."""
-    return _UpJunction.apply(x, w, bias, skip, kind, box, _gate_of(x) if x_single_use else None)
+    net[-1] feeds the next up_layer and nothing else), which lets x's block gate ride in the dgrad epilogue.
+    merged_single_use: the result feeds one conv_block and nothing else (unet.py:319-321): its backward may then be
+    formed in that block's dgrad epilogue (JunctionHandoff)."""
+    handoff = JunctionHandoff() if (merged_single_use and FUSE_JUNCTION) else None
+    merged = _UpJunction.apply(x, w, bias, skip, kind, box, _gate_of(x) if x_single_use else None, handoff)
+    if handoff is not None:
+        merged._sq_junction = handoff
+    return merged
 
 
 class _ConvT(torch.autograd.Function):

@@ -758,7 +758,8 @@ class UNet2DBf16(UNet2D):
             entry = self._skip_boxes.get(id(bridge))
             box = entry[1] if entry is not None and entry[0] is bridge else None
             # build() feeds net[-1] to this up_layer only (unet.py:248): its block gate can ride in the dgrad epilogue
-            merged = FB.up_junction(x, w, b, bridge, self.bridge_type, box, x_single_use=x is self._net[-1])
+            merged = FB.up_junction(x, w, b, bridge, self.bridge_type, box, x_single_use=x is self._net[-1],
+                                    merged_single_use=True)     # merged goes straight into the block below
             out = self.conv_block(merged, filters)
         return out
 

@@ -97,6 +97,24 @@ def conv2d_dgrad_relu(dy, wp_t, gate, K, scale=1.0):
     return dx
 
 
+def conv2d_dgrad_junction(dy, wp_t, up, skip, kind, K, Cout):
+    """dgrad conv (dy -> d merged, Cout channels) with the decoder junction's backward in the epilogue: returns
+    (g (N,H/2,W/2,4Cout) = d_up in space-to-depth layout, dskip (N,H,W,Cout)); d merged is never written."""
+    _chk(dy, "dy", ndim=4), _chk(wp_t, "wp_t")
+    N, H, W, Cin = dy.shape
+    if kind == 'eltwise_mul':
+        _chk(up, "up", ndim=4), _chk(skip, "skip", ndim=4)
+        if tuple(up.shape) != (N, H, W, Cout) or tuple(skip.shape) != (N, H, W, Cout):
+            raise ValueError("conv2d_dgrad_junction: up / skip must be %s" % ((N, H, W, Cout),))
+    g = torch.empty((N, H // 2, W // 2, 4 * Cout), dtype=BF16, device=dy.device)
+    dskip = torch.empty((N, H, W, Cout), dtype=BF16, device=dy.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_conv2d_nhwc_dgrad_junction_bf16(_ptr(dy), _ptr(wp_t), _ptr(up), _ptr(skip), _ptr(g), _ptr(dskip), N, H,
+                                                     W, Cin, Cout, K, BRIDGE[kind], _stream()),
+               "sq_conv2d_nhwc_dgrad_junction_bf16")
+    return g, dskip
+
+
 def conv3x3_first(x, w, bias, act="relu"):
     """f32 (N,H,W,Cin) image (Cin 1..7), f32 (3,3,Cin,Cout) filter -> bf16 activation."""
     _chk(x, "x", dtype=torch.float32, ndim=4), _chk(w, "w", dtype=torch.float32, ndim=4)

@@ -321,3 +321,44 @@ def test_convT_bridge_dual_output_equals_the_two_kernels(kind):
     merged_ref = ob.bridge(up_ref, dev(skip, torch.bfloat16), kind)
     up, merged = ob.convT2x2s2_bridge_both(dev(x, torch.bfloat16), wb, dev(b), dev(skip, torch.bfloat16), kind)
     assert torch.equal(up, up_ref) and torch.equal(merged, merged_ref)
+
+
+@pytest.mark.parametrize("kind", ["eltwise_mul", "eltwise_add", "eltwise_sub"])
+@pytest.mark.parametrize("shape", [(2, 24, 40, 32, 16), (1, 64, 64, 64, 32), (3, 16, 16, 128, 64), (1, 34, 30, 16, 16)])
+def test_dgrad_with_junction_epilogue_equals_dgrad_then_bridge_backward(kind, shape):
+    """sq_conv2d_nhwc_dgrad_junction_bf16: d_up (space-to-depth) and d_skip from the dgrad kernel's epilogue, bit for
+    bit what the dgrad conv followed by sq_bridge_bwd_s2d_bf16 writes (ragged tiles included)."""
+    N, H, W, Cd, Cm = shape                                     # dy has Cd channels, merged has Cm
+    dy = dev(tiles(41, N, H, W, Cd), torch.bfloat16)
+    up, skip = dev(tiles(42, N, H, W, Cm), torch.bfloat16), dev(tiles(43, N, H, W, Cm), torch.bfloat16)
+    w = dev(rand_weights(44, (3, 3, Cm, Cd), 0.1))              # forward filter merged -> block
+    wp_t = ob.pack_weights(w, transform=True)
+    dm = ob.conv2d(dy, wp_t, None, 3, Cm)
+    g_ref, ds_ref = ob.bridge_bwd_s2d(dm, up, skip, kind)
+    keep = kind == "eltwise_mul"
+    g, ds = ob.conv2d_dgrad_junction(dy, wp_t, up if keep else None, skip if keep else None, kind, 3, Cm)
+    assert torch.equal(g, g_ref) and torch.equal(ds, ds_ref)
+
+
+@pytest.mark.parametrize("bridge", ["eltwise_mul", "eltwise_add", "eltwise_sub"])
+def test_junction_handoff_gives_the_same_gradients_as_the_standalone_pass(bridge, monkeypatch):
+    """functional_bf16.JunctionHandoff on / off: same loss, same gradients, bit for bit."""
+    from sequitr_amd.train import UNetTrainer
+    from sequitr_amd import functional_bf16 as FB
+    base = {"shape": (64, 64), "dropout": 0.4, "device": "cuda:0", "seed": 5, "filters": (16, 32, 64), "dtype": "bf16",
+            "bridge": bridge}
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2, 64, 64, 1)).astype(np.float32)
+    lab = rng.random((2, 64, 64)) < 0.4
+    onehot = np.stack([~lab, lab], -1).astype(np.uint8)
+    wmap = (1 + rng.random((2, 64, 64, 1))).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to("cuda:0")
+    out = []
+    for fuse in (True, False):
+        monkeypatch.setattr(FB, "FUSE_JUNCTION", fuse)
+        t = UNetTrainer(dict(base))
+        loss = t.forward_backward(d(x), d(onehot), d(wmap))
+        out.append((loss.item(), t.grads()))
+    assert out[0][0] == out[1][0]
+    for k in out[1][1]:
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k
