@@ -274,28 +274,21 @@ __global__ __launch_bounds__(256) void head_finish_kernel(const float *__restric
     else if (db) db[i - nw] = s;
 }
 
-// counter-based dropout mask: keep iff hash(seed, element index) >= rate * 2^32
-__device__ __forceinline__ unsigned hash32(unsigned a, unsigned b) {
-    unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    h += b * 0x27D4EB2Fu; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-    return h;
-}
+// counter-based dropout mask: sq_dropout_keep4 (sq_common.h), one hash per quad of elements
 
 // 4 elements per thread (16 B of data, 4 B of mask); n % 4 == 0 is required by the entry points
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y,
                                                            uchar4 *__restrict__ mask, int64_t n4, float rate,
                                                            unsigned seed, int mask_given, const int *__restrict__ step) {
-    if (step) seed += (unsigned)step[0] * 0x9E3779B9u;          // a fresh mask on every replayed step
-    const unsigned thr = (unsigned)(rate * 4294967296.0);
+    const SqDropKey key = sq_dropout_key(seed, step);
+    const unsigned thr = sq_dropout_thr16(rate);
     const float inv = 1.0f / (1.0f - rate);
     SQ_GRID_STRIDE(i, n4) {
         uchar4 k;
         if (mask_given) k = mask[i];
         else {
-            const unsigned e = (unsigned)(i * 4);
-            k = make_uchar4(hash32(seed, e) >= thr, hash32(seed, e + 1) >= thr, hash32(seed, e + 2) >= thr,
-                            hash32(seed, e + 3) >= thr);
+            const unsigned b = sq_dropout_keep4(key, (unsigned)i, thr);
+            k = make_uchar4(b & 1u, (b >> 1) & 1u, (b >> 2) & 1u, (b >> 3) & 1u);
             mask[i] = k;
         }
         const float4 v = x[i];

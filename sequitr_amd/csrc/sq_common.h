@@ -51,6 +51,32 @@ __device__ __forceinline__ unsigned sq_xcd_remap(unsigned bid, unsigned nblk) {
     return base + k;
 }
 
+// Counter-based dropout mask (tf.nn.dropout's semantics, sequitr/networks/unet.py:274-276; the random stream is the
+// build's own): one 32-bit hash per QUAD of consecutive elements 4q .. 4q+3 yields two words = four 16-bit uniforms,
+// element kept iff its uniform >= thr16 = rate * 2^16.  v_mul_lo_u32 is quarter rate on CDNA, and the fused
+// conv + dropout epilogue is VALU-bound on it at the shallow levels: three multiplies per four elements here instead of
+// four per element.  The key carries (seed, step) into the mix at two places, so that two layers' (or steps') masks are
+// not shifted copies of each other.  Every dropout kernel of the library uses this one definition.
+struct SqDropKey { unsigned s1, s2; };
+__device__ __forceinline__ SqDropKey sq_dropout_key(unsigned seed, const int *__restrict__ step) {
+    if (step) seed += (unsigned)step[0] * 0x9E3779B9u;          // a fresh mask on every replayed step
+    SqDropKey k;
+    k.s1 = seed * 0x9E3779B1u + 0x7F4A7C15u;
+    k.s2 = (seed ^ 0x68E31DA4u) * 0x85EBCA6Bu;
+    k.s2 ^= k.s2 >> 13;
+    return k;
+}
+__device__ __forceinline__ unsigned sq_dropout_thr16(float rate) { return (unsigned)(rate * 65536.0f); }
+// bit j of the result: element 4q + j is kept
+__device__ __forceinline__ unsigned sq_dropout_keep4(SqDropKey k, unsigned q, unsigned thr16) {
+    unsigned h = q + k.s1;
+    h ^= h >> 16; h *= 0x7FEB352Du; h = h ^ (h >> 15) ^ k.s2; h *= 0x846CA68Bu; h ^= h >> 16;
+    unsigned g = (h ^ 0x5BD1E995u) * 0x2C1B3C6Du;
+    g ^= g >> 15;
+    return (unsigned)((h & 0xFFFFu) >= thr16) | ((unsigned)((h >> 16) >= thr16) << 1) |
+           ((unsigned)((g & 0xFFFFu) >= thr16) << 2) | ((unsigned)((g >> 16) >= thr16) << 3);
+}
+
 // Fixed-order reduction of `nblk` block partials per output by a group of G lanes (G a power of two
 // <= 64, the same for a given problem size, so results are run-to-run reproducible): lane g sums
 // partials g, g+G, ... in order, then an xor butterfly folds the group.

@@ -33,8 +33,8 @@ constexpr int TH = 16, TW = 16;
 __host__ __device__ constexpr int kp_for(int KS, int KC) { return ((KS * KS * KC + 31) / 32) * 32; }
 
 // dropout fused into the epilogue (training conv_block: relu(conv2) -> dropout, unet.py:265-277): the
-// element with flat NHWC index e is kept iff hash32(seed', e) >= thr -- the hash, the threshold and the two
-// roundings (bf16 activation, then * 1/(1-rate) -> bf16) are those of dropout_fwd_bf16_kernel, so the result
+// element with flat NHWC index e is kept iff bit e % 4 of sq_dropout_keep4(key, e / 4, thr) is set (sq_common.h; thr in
+// 16-bit units) -- the mask and the two roundings (bf16 activation, then * 1/(1-rate) -> bf16) are those of dropout_fwd_bf16_kernel, so the result
 // equals the separate kernels bit for bit.  thr == 0: no dropout.
 struct SqDropEpi {
     unsigned thr;
@@ -50,13 +50,6 @@ struct SqDropEpi {
     __bf16 *j_g = nullptr, *j_dskip = nullptr;
     int j_bridge = 0;
 };
-
-__device__ __forceinline__ unsigned conv_hash32(unsigned a, unsigned b) {       // = hash32 of sq_ops_bf16.hip
-    unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    h += b * 0x27D4EB2Fu; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-    return h;
-}
 
 template <int BN, int KS, int KC>
 struct CfgB {
@@ -273,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
 #pragma unroll
         for (int nb = 0; nb < NR; ++nb) acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const unsigned dseed = drop.seed + (drop.step ? (unsigned)drop.step[0] * 0x9E3779B9u : 0u);
+    const SqDropKey dkey = sq_dropout_key(drop.seed, drop.thr ? drop.step : nullptr);
     const float slope = act == SQ_ACT_LEAKY ? 0.2f : 1.0f;
     const bool is_relu = act == SQ_ACT_RELU;
     auto actf = [&](float v) {
@@ -406,10 +399,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                         o[j] = (float)gv[r][j] > 0.f ? (__bf16)((float)o[j] * drop.gscale) : (__bf16)0.f;
                 }
                 if (drop.thr) {
-                    const unsigned e0 = offs[r] >> 1;          // flat element index (offsets are in bytes)
+                    const unsigned k4 = sq_dropout_keep4(dkey, offs[r] >> 3, drop.thr);    // quad index (offsets are in bytes)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        o[j] = conv_hash32(dseed, e0 + j) >= drop.thr ? (__bf16)((float)o[j] * drop.inv) : (__bf16)0.f;
+                        o[j] = (k4 >> j) & 1u ? (__bf16)((float)o[j] * drop.inv) : (__bf16)0.f;
                 }
                 const unsigned off = offs[r];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
@@ -685,11 +678,11 @@ extern "C" int sq_conv2d_nhwc_fwd_dropout_bf16(const void *x, const void *wp, co
                                                const int32_t *step_dev, void *stream) {
     SQ_REQUIRE(rate > 0.f && rate < 1.f, "sq_conv2d_nhwc_fwd_dropout_bf16: rate must be in (0, 1)");
     SqDropEpi d;
-    d.thr = (unsigned)(rate * 4294967296.0);
+    d.thr = (unsigned)(rate * 65536.0f);                       // = sq_dropout_thr16
     d.inv = 1.0f / (1.0f - rate);
     d.seed = seed;
     d.step = step_dev;
-    SQ_REQUIRE(d.thr != 0u, "sq_conv2d_nhwc_fwd_dropout_bf16: rate too small for the 32-bit threshold");
+    SQ_REQUIRE(d.thr != 0u, "sq_conv2d_nhwc_fwd_dropout_bf16: rate too small for the 16-bit threshold");
     return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, K, act, stream, nullptr, d);
 }
 

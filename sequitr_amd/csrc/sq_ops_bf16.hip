@@ -221,29 +221,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_bf16_kernel(const bf16x8 
     }
 }
 
-__device__ __forceinline__ unsigned hash32(unsigned a, unsigned b) {          // same hash as the f32 dropout
-    unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    h += b * 0x27D4EB2Fu; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-    return h;
-}
-
-// 8 elements per thread (16 B of data, 8 B of mask); element e uses hash(seed, e) as the f32 kernel does
+// 8 elements per thread (16 B of data, 8 B of mask); the mask of sq_dropout_keep4 (sq_common.h), as the f32 kernel
 __global__ __launch_bounds__(256) void dropout_fwd_bf16_kernel(const bf16x8 *__restrict__ x, bf16x8 *__restrict__ y,
                                                                 uint2 *__restrict__ mask, int64_t n8, float rate,
                                                                 unsigned seed, int mask_given, const int *__restrict__ step) {
-    if (step) seed += (unsigned)step[0] * 0x9E3779B9u;
-    const unsigned thr = (unsigned)(rate * 4294967296.0);
+    const SqDropKey key = sq_dropout_key(seed, step);
+    const unsigned thr = sq_dropout_thr16(rate);
     const float inv = 1.0f / (1.0f - rate);
     SQ_GRID_STRIDE(i, n8) {
         uint2 m;
         if (mask_given) m = mask[i];
         else {
-            const unsigned e = (unsigned)(i * 8);
-            m.x = (hash32(seed, e) >= thr) | ((hash32(seed, e + 1) >= thr) << 8) | ((hash32(seed, e + 2) >= thr) << 16) |
-                  ((hash32(seed, e + 3) >= thr) << 24);
-            m.y = (hash32(seed, e + 4) >= thr) | ((hash32(seed, e + 5) >= thr) << 8) | ((hash32(seed, e + 6) >= thr) << 16) |
-                  ((hash32(seed, e + 7) >= thr) << 24);
+            const unsigned a = sq_dropout_keep4(key, (unsigned)(i * 2), thr), b = sq_dropout_keep4(key, (unsigned)(i * 2 + 1), thr);
+            m.x = (a & 1u) | ((a & 2u) << 7) | ((a & 4u) << 14) | ((a & 8u) << 21);
+            m.y = (b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21);
             mask[i] = m;
         }
         const bf16x8 v = x[i];
