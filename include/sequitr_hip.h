@@ -467,6 +467,17 @@ int sq_conv1x1_head_bwd_bf16(const void *x, const float *w, const float *dz, voi
 /* gate_scale > 0: x = dropout(ReLU(.)) of the last conv block; dx leaves through that gate (x > 0 ? dx * gate_scale : 0) */
 int sq_conv1x1_head_bwd_gate_bf16(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db,
                                   float *workspace, int64_t npix, int Cin, int Cout, float gate_scale, void *stream);
+/* to_image head + weighted softmax-CE of the training step as one forward and one backward kernel: the logits are never
+ * written (sequitr/networks/unet.py:252-253 followed by the loss of SURVEY.md A.3).  forward: loss = f32 device scalar,
+ * partials = sq_wsoftmax_ce_partials(npix) doubles; backward: dloss = f32 device scalar (gradient arriving at the loss),
+ * workspace = sq_conv1x1_head_bwd_workspace_bf16 bytes, gate_scale as above.  Bit-identical to
+ * sq_conv1x1_head_fwd_bf16 -> sq_wsoftmax_ce_fwd_bwd_f32 -> (* dloss) -> sq_conv1x1_head_bwd_gate_bf16. */
+int sq_conv1x1_head_wce_fwd_bf16(const void *x, const float *w, const float *bias, const uint8_t *onehot,
+                                 const float *weights, double *partials, float *loss, int64_t npix, int Cin, int Cout,
+                                 void *stream);
+int sq_conv1x1_head_wce_bwd_bf16(const void *x, const float *w, const float *bias, const uint8_t *onehot,
+                                 const float *weights, const float *dloss, void *dx, float *dw, float *db, float *workspace,
+                                 int64_t npix, int Cin, int Cout, float gate_scale, void *stream);
 
 /* weight gradient of the first (Cin -> Cout, Cin 1..7) 3x3 convolution from the f32 image and a bf16 dY:
  * dW (3,3,Cin,Cout) f32, db (Cout) f32 or NULL */

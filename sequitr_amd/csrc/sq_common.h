@@ -77,6 +77,34 @@ __device__ __forceinline__ unsigned sq_dropout_keep4(SqDropKey k, unsigned q, un
            ((unsigned)((g & 0xFFFFu) >= thr16) << 2) | ((unsigned)((g >> 16) >= thr16) << 3);
 }
 
+// Weighted softmax cross-entropy of ONE pixel: returns w * (lse(z) * sum(y) - <y, z>) and, when dz is
+// given, dz[c] = g * (softmax(z)[c] * sum(y) - y[c]).  One definition for sq_wsoftmax_ce_fwd_bwd_f32 and for the head +
+// loss kernels (sq_conv1x1_head_wce_*_bf16), contraction off, so that both evaluate the same roundings.
+template <int MAXC>
+__device__ __forceinline__ float sq_wce_pixel(const float (&zc)[MAXC], const float (&yc)[MAXC], int C, float wp, float g,
+                                              float *__restrict__ dz) {
+#pragma clang fp contract(off)
+    float m = -INFINITY, yt = 0.f, dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < C) {
+            m = zc[c] > m ? zc[c] : m;
+            yt += yc[c];
+            dot = __builtin_fmaf(yc[c], zc[c], dot);
+        }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < C) s += expf(zc[c] - m);
+    const float lse = m + logf(s);
+    if (dz) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) dz[c] = g * (expf(zc[c] - lse) * yt - yc[c]);
+    }
+    return wp * (lse * yt - dot);
+}
+
 // Fixed-order reduction of `nblk` block partials per output by a group of G lanes (G a power of two
 // <= 64, the same for a given problem size, so results are run-to-run reproducible): lane g sums
 // partials g, g+G, ... in order, then an xor butterfly folds the group.

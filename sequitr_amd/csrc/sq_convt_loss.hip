@@ -101,30 +101,21 @@ __global__ __launch_bounds__(256) void wsoftmax_ce_f32_kernel(
     __shared__ double red[256];
     double tsum = 0.0;
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
-        float zc[CE_MAXC], yc[CE_MAXC];
-        float m = -INFINITY, yt = 0.f, dot = 0.f;
+        float zc[CE_MAXC], yc[CE_MAXC], dzc[CE_MAXC];
 #pragma unroll
         for (int c = 0; c < CE_MAXC; ++c) {
+            zc[c] = yc[c] = 0.f;
             if (c < C) {
                 zc[c] = z[p * C + c];
                 yc[c] = (float)yoh[p * C + c];
-                m = zc[c] > m ? zc[c] : m;
-                yt += yc[c];
-                dot = __builtin_fmaf(yc[c], zc[c], dot);
             }
         }
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < CE_MAXC; ++c)
-            if (c < C) s += expf(zc[c] - m);
-        const float lse = m + logf(s);
         const float wp = wgt[p];
-        tsum += (double)(wp * (lse * yt - dot));
+        tsum += (double)sq_wce_pixel<CE_MAXC>(zc, yc, C, wp, wp * gscale, dz ? dzc : nullptr);
         if (dz) {
-            const float g = wp * gscale;
 #pragma unroll
             for (int c = 0; c < CE_MAXC; ++c)
-                if (c < C) dz[p * C + c] = g * (expf(zc[c] - lse) * yt - yc[c]);
+                if (c < C) dz[p * C + c] = dzc[c];
         }
     }
     red[threadIdx.x] = tsum;

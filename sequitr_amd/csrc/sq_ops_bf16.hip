@@ -394,11 +394,71 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// head backward: x bf16 (CIN ch), dz f32 (COUT ch) -> dx bf16, block partials of dW (CIN,COUT) and db
-template <int CIN, int COUT>
+// head + weighted softmax-CE, forward: the logits (head_fwd_bf16_kernel's fmaf chain) live in registers only; the loss
+// partials are those of wsoftmax_ce_f32_kernel on the same logits (same grid, same per-thread order, fp64)
+struct SqHeadCE {
+    const float *bias;
+    const uint8_t *yoh;
+    const float *wgt;
+    const float *dloss;         // device scalar: the gradient arriving at the loss (backward only)
+    float inv_npix;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256) void head_wce_fwd_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
+                                                                 SqHeadCE ce, double *__restrict__ partials, int64_t npix,
+                                                                 int Cin) {
+    __shared__ double red[256];
+    double tsum = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+        float acc[COUT], yc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+        for (int c8 = 0; c8 < Cin / 8; ++c8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + p * Cin + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) acc[o] = __builtin_fmaf(w[(c8 * 8 + j) * COUT + o], (float)v[j], acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            acc[o] = acc[o] + (ce.bias ? ce.bias[o] : 0.f);
+            yc[o] = (float)ce.yoh[p * COUT + o];
+        }
+        tsum += (double)sq_wce_pixel<COUT>(acc, yc, COUT, ce.wgt[p], 0.f, nullptr);
+    }
+    red[threadIdx.x] = tsum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void head_wce_finish_kernel(const double *__restrict__ partials, int n, double inv_npix,
+                                                              float *__restrict__ loss) {      // = ce_finish_kernel, f32 out
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * inv_npix);
+}
+
+// head backward: x bf16 (CIN ch), dz f32 (COUT ch) -> dx bf16, block partials of dW (CIN,COUT) and db.
+// CE: dz is not read but formed here, from the logits recomputed out of x: dz = (w_p / npix * (softmax * sum(y) - y))
+// * dloss, the two roundings of wsoftmax_ce_f32_kernel followed by the tape's multiplication with the incoming gradient
+template <int CIN, int COUT, bool CE = false>
 __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
                                                              const float *__restrict__ dz, __bf16 *__restrict__ dx,
-                                                             float *__restrict__ partials, int64_t npix, float gscale) {
+                                                             float *__restrict__ partials, int64_t npix, float gscale,
+                                                             SqHeadCE ce = SqHeadCE{}) {
     constexpr int NVAL = CIN * COUT + COUT;
     __shared__ float red[4][NVAL];
     float gw[CIN][COUT], gb[COUT];
@@ -413,11 +473,39 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const __bf16 *__rest
         const int64_t p = base + threadIdx.x;
         if (p < npix) {
             float g[COUT];
+            bf16x8 xv[CIN / 8];
 #pragma unroll
-            for (int o = 0; o < COUT; ++o) { g[o] = dz[p * COUT + o]; gb[o] += g[o]; }
+            for (int c8 = 0; c8 < CIN / 8; ++c8) xv[c8] = *reinterpret_cast<const bf16x8 *>(x + p * CIN + c8 * 8);
+            if constexpr (CE) {
+                float acc[COUT], yc[COUT];
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+#pragma unroll
+                for (int c8 = 0; c8 < CIN / 8; ++c8)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int o = 0; o < COUT; ++o)
+                            acc[o] = __builtin_fmaf(w[(c8 * 8 + j) * COUT + o], (float)xv[c8][j], acc[o]);
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) {
+                    acc[o] = acc[o] + (ce.bias ? ce.bias[o] : 0.f);
+                    yc[o] = (float)ce.yoh[p * COUT + o];
+                }
+                const float wp = ce.wgt[p];
+                sq_wce_pixel<COUT>(acc, yc, COUT, wp, wp * ce.inv_npix, g);
+                const float up = ce.dloss[0];
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) g[o] = g[o] * up;
+            } else {
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) g[o] = dz[p * COUT + o];
+            }
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) gb[o] += g[o];
 #pragma unroll
             for (int c8 = 0; c8 < CIN / 8; ++c8) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + p * CIN + c8 * 8);
+                const bf16x8 v = xv[c8];
                 bf16x8 r;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -661,15 +749,15 @@ extern "C" int sq_conv1x1_head_bwd_bf16(const void *x, const float *w, const flo
                                         float *workspace, int64_t npix, int Cin, int Cout, void *stream) {
     return sq_conv1x1_head_bwd_gate_bf16(x, w, dz, dx, dw, db, workspace, npix, Cin, Cout, 0.f, stream);
 }
-extern "C" int sq_conv1x1_head_bwd_gate_bf16(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db,
-                                             float *workspace, int64_t npix, int Cin, int Cout, float gate_scale,
-                                             void *stream) {
-    SQ_REQUIRE(x && w && dz && dw && workspace && npix > 0, "sq_conv1x1_head_bwd_bf16: null pointer");
+template <bool CE>
+static int head_bwd_impl(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db, float *workspace,
+                         int64_t npix, int Cin, int Cout, float gate_scale, void *stream, const SqHeadCE &ce) {
+    SQ_REQUIRE(x && w && (CE || dz) && dw && workspace && npix > 0, "sq_conv1x1_head_bwd_bf16: null pointer");
     SQ_REQUIRE(gate_scale >= 0.f, "sq_conv1x1_head_bwd_gate_bf16: gate_scale must be >= 0 (0 = no gate)");
     SQ_REQUIRE((Cin == 16 || Cin == 32) && Cout >= 1 && Cout <= 5, "sq_conv1x1_head_bwd_bf16: Cin=%d (16|32), Cout=%d (1..5)", Cin, Cout);
     const int nb = head_blocks(npix);
     hipStream_t st = SQ_ST(stream);
-#define SQ_HEAD_BWD(CI, CO) hipLaunchKernelGGL((head_bwd_bf16_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix, gate_scale)
+#define SQ_HEAD_BWD(CI, CO) hipLaunchKernelGGL((head_bwd_bf16_kernel<CI, CO, CE>), dim3(nb), dim3(256), 0, st, BF(x), w, dz, BFM(dx), workspace, npix, gate_scale, ce)
     if (Cin == 16) {
         switch (Cout) {
         case 1: SQ_HEAD_BWD(16, 1); break;
@@ -693,4 +781,47 @@ extern "C" int sq_conv1x1_head_bwd_gate_bf16(const void *x, const float *w, cons
     const int nw = Cin * Cout;
     { const int G = sq_group_size(nb); hipLaunchKernelGGL(head_finish2_kernel, dim3(((nw + Cout) * G + 255) / 256), dim3(256), 0, st, workspace, dw, db, nb, nw, Cout, G); }
     return sq_check_launch("sq_conv1x1_head_bwd_bf16(finish)");
+}
+
+extern "C" int sq_conv1x1_head_bwd_gate_bf16(const void *x, const float *w, const float *dz, void *dx, float *dw, float *db,
+                                             float *workspace, int64_t npix, int Cin, int Cout, float gate_scale,
+                                             void *stream) {
+    return head_bwd_impl<false>(x, w, dz, dx, dw, db, workspace, npix, Cin, Cout, gate_scale, stream, SqHeadCE{});
+}
+
+// ---- to_image head + weighted softmax-CE without the logits round trip (training) -----------------------------------
+// forward: loss (f32 device scalar) = mean over pixels of w * CE(softmax(head(x)), y); partials: sq_wsoftmax_ce_partials(npix)
+// doubles.  Same logits as sq_conv1x1_head_fwd_bf16 and same loss as sq_wsoftmax_ce_fwd_bwd_f32 on them, bit for bit.
+extern "C" int sq_conv1x1_head_wce_fwd_bf16(const void *x, const float *w, const float *bias, const uint8_t *onehot,
+                                            const float *weights, double *partials, float *loss, int64_t npix, int Cin,
+                                            int Cout, void *stream) {
+    SQ_REQUIRE(x && w && onehot && weights && partials && loss && npix > 0, "sq_conv1x1_head_wce_fwd_bf16: null pointer");
+    SQ_REQUIRE(Cin > 0 && Cin % 8 == 0 && Cout >= 1 && Cout <= 5, "sq_conv1x1_head_wce_fwd_bf16: Cin=%d (%% 8), Cout=%d (1..5)", Cin, Cout);
+    SQ_REQUIRE_ALIGNED(x);
+    const int64_t nb64 = sq_wsoftmax_ce_partials(npix);
+    const unsigned nb = (unsigned)nb64;
+    hipStream_t st = SQ_ST(stream);
+    const SqHeadCE ce{bias, onehot, weights, nullptr, 0.f};
+    switch (Cout) {
+    case 1: hipLaunchKernelGGL(head_wce_fwd_bf16_kernel<1>, dim3(nb), dim3(256), 0, st, BF(x), w, ce, partials, npix, Cin); break;
+    case 2: hipLaunchKernelGGL(head_wce_fwd_bf16_kernel<2>, dim3(nb), dim3(256), 0, st, BF(x), w, ce, partials, npix, Cin); break;
+    case 3: hipLaunchKernelGGL(head_wce_fwd_bf16_kernel<3>, dim3(nb), dim3(256), 0, st, BF(x), w, ce, partials, npix, Cin); break;
+    case 4: hipLaunchKernelGGL(head_wce_fwd_bf16_kernel<4>, dim3(nb), dim3(256), 0, st, BF(x), w, ce, partials, npix, Cin); break;
+    default: hipLaunchKernelGGL(head_wce_fwd_bf16_kernel<5>, dim3(nb), dim3(256), 0, st, BF(x), w, ce, partials, npix, Cin); break;
+    }
+    int rc = sq_check_launch("sq_conv1x1_head_wce_fwd_bf16");
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_wce_finish_kernel, dim3(1), dim3(256), 0, st, partials, (int)nb, 1.0 / (double)npix, loss);
+    return sq_check_launch("sq_conv1x1_head_wce_fwd_bf16(finish)");
+}
+
+// backward of the pair above: dloss = the gradient arriving at the loss (f32 device scalar); dx / dW / db as
+// sq_conv1x1_head_bwd_gate_bf16 fed with sq_wsoftmax_ce_fwd_bwd_f32's dlogits * dloss, bit for bit
+extern "C" int sq_conv1x1_head_wce_bwd_bf16(const void *x, const float *w, const float *bias, const uint8_t *onehot,
+                                            const float *weights, const float *dloss, void *dx, float *dw, float *db,
+                                            float *workspace, int64_t npix, int Cin, int Cout, float gate_scale,
+                                            void *stream) {
+    SQ_REQUIRE(onehot && weights && dloss, "sq_conv1x1_head_wce_bwd_bf16: null pointer");
+    const SqHeadCE ce{bias, onehot, weights, dloss, 1.0f / (float)npix};
+    return head_bwd_impl<true>(x, w, nullptr, dx, dw, db, workspace, npix, Cin, Cout, gate_scale, stream, ce);
 }

@@ -722,10 +722,39 @@ class UNet2DBf16(UNet2D):
         w, b = self._kernel((1, 1, x.shape[-1], filters)), self._bias(filters)
         if self.training:
             # build() hands the last block's output to the head and to nothing else (unet.py:252-253)
+            labels = getattr(self, '_loss_inputs', None)
+            if labels is not None and x.shape[-1] in (16, 32) and filters <= 5:
+                self._loss = FB.conv1x1_head_loss(x, w, b, labels[0], labels[1], x_single_use=x is self._net[-1])
+                self._head_wb = (w, b)
+                return self._loss                               # build_loss(): the loss stands in for the logits
             return FB.conv1x1_head(x, w, b, x_single_use=x is self._net[-1])
         from .. import ops_bf16 as ob
         logits, self._mask = ob.head_fwd(x, w, b)
         return logits
+
+    def logits(self):
+        """unet.py:220-222.  After build_loss() the logits were never stored: they are evaluated here, on demand,
+        from the last block's output (inspection / tests; not part of the training step)."""
+        if getattr(self, '_loss', None) is not None and self._net[-1] is self._loss:
+            from .. import ops_bf16 as ob
+            with torch.no_grad():
+                return ob.head_fwd(self._net[-2].detach(), self._head_wb[0].detach(),
+                                   None if self._head_wb[1] is None else self._head_wb[1].detach(), want_mask=False)[0]
+        return self._net[-1]
+
+    def build_loss(self, features, onehot, weights):
+        """Training graph ending in the weighted softmax cross-entropy instead of the logits: the
+        head and the loss run as one tape entry (FB.conv1x1_head_loss) and the logits are never stored.  Falls back
+        to build() + the stand-alone loss where that entry does not apply (an overridden head, > 5 classes)."""
+        from .. import functional as F32
+        self._loss_inputs, self._loss = (onehot, weights), None
+        try:
+            out = self.build(features)
+        finally:
+            self._loss_inputs = None
+        if self._loss is not None and out is self._loss:
+            return out
+        return F32.weighted_softmax_cross_entropy(out, onehot, weights)
 
     def conv_transpose_layer(self, x, filters):
         return FB.convT2x2s2(x, self._kernel((2, 2, filters, x.shape[-1])), self._bias(filters))

@@ -396,6 +396,42 @@ def head_bwd(x, w, dz, want_dx=True, dw_out=None, db_out=None, gate_scale=0.0):
     return dx, dw, db
 
 
+def _head_wce_check(x, w, onehot, weights):
+    _chk(x, "x", ndim=4), _chk(w, "w", dtype=torch.float32, ndim=4)
+    _chk(onehot, "onehot", dtype=torch.uint8), _chk(weights, "weights", dtype=torch.float32)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    if tuple(onehot.shape) != (N, H, W, Cout) or weights.numel() != N * H * W:
+        raise ValueError("label / weight shapes do not match the head's output")
+    return N * H * W, Cin, Cout
+
+
+def head_wce_fwd(x, w, bias, onehot, weights):
+    """to_image head + weighted softmax-CE, forward: 0-d f32 loss; the logits stay in registers."""
+    npix, Cin, Cout = _head_wce_check(x, w, onehot, weights)
+    lib = _lib.load()
+    parts = torch.empty(lib.sq_wsoftmax_ce_partials(npix), dtype=torch.float64, device=x.device)
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    _lib.check(lib.sq_conv1x1_head_wce_fwd_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(onehot), _ptr(weights), _ptr(parts),
+                                               _ptr(loss), npix, Cin, Cout, _stream()), "sq_conv1x1_head_wce_fwd_bf16")
+    return loss
+
+
+def head_wce_bwd(x, w, bias, onehot, weights, dloss, want_dx=True, dw_out=None, db_out=None, gate_scale=0.0):
+    """backward of head_wce_fwd from the 0-d f32 gradient arriving at the loss: (dx, dW, db)."""
+    npix, Cin, Cout = _head_wce_check(x, w, onehot, weights)
+    _chk(dloss, "dloss", dtype=torch.float32)
+    lib = _lib.load()
+    ws = _workspace(lib.sq_conv1x1_head_bwd_workspace_bf16(npix, Cin, Cout), x.device)
+    dx = torch.empty_like(x) if want_dx else None
+    dw = _grad_out(dw_out, (1, 1, Cin, Cout), x.device)
+    db = _grad_out(db_out, (Cout,), x.device)
+    _lib.check(lib.sq_conv1x1_head_wce_bwd_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(onehot), _ptr(weights), _ptr(dloss),
+                                               _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), npix, Cin, Cout, float(gate_scale),
+                                               _stream()), "sq_conv1x1_head_wce_bwd_bf16")
+    return dx, dw, db
+
+
 def conv3x3_first_wgrad(x, dy, dw_out=None, db_out=None):
     """x f32 (N,H,W,Cin), dy bf16 (N,H,W,Cout) -> (dW (3,3,Cin,Cout) f32, db f32)."""
     _chk(x, "x", dtype=torch.float32, ndim=4), _chk(dy, "dy", ndim=4)

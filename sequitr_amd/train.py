@@ -22,6 +22,7 @@ class UNetTrainer(object):
         if net_cls is None:
             net_cls = UNet2DBf16 if str(params.get('dtype', 'f32')).lower() in ('bf16', 'bfloat16') else UNet2D
         self.net = net_cls(params, TRAIN)
+        self.fuse_head_loss = bool(params.get('fuse_head_loss', True))      # A/B switch (tests compare both tapes)
         self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
         self.group = group
         self.step_count = 0
@@ -86,8 +87,10 @@ class UNetTrainer(object):
         self.gbucket.flat.zero_()
         if self.pack_plan is not None:
             self.pack_plan.run()                                # every bf16 filter pack of the step, one launch
-        logits = self.net.build(x)
-        loss = F.weighted_softmax_cross_entropy(logits, onehot, weights)
+        if self.fuse_head_loss and hasattr(self.net, 'build_loss'):
+            loss = self.net.build_loss(x, onehot, weights)      # bf16 graph: head + loss as one tape entry
+        else:
+            loss = F.weighted_softmax_cross_entropy(self.net.build(x), onehot, weights)
         loss.backward()
         self.last_loss = loss.detach()
         return self.last_loss

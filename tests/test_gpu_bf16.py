@@ -362,3 +362,41 @@ def test_junction_handoff_gives_the_same_gradients_as_the_standalone_pass(bridge
     assert out[0][0] == out[1][0]
     for k in out[1][1]:
         assert np.array_equal(out[0][1][k], out[1][1][k]), k
+
+
+@pytest.mark.parametrize("cfg", [{"filters": (16, 32, 64)}, {"filters": (32, 64), "num_outputs": 3},
+                                 {"filters": (16, 32), "dropout": 0.0}])
+def test_head_plus_loss_tape_entry_equals_head_then_loss(cfg):
+    """sq_conv1x1_head_wce_{fwd,bwd}_bf16 (logits never stored) against head -> weighted softmax-CE -> head backward:
+    same loss bits, same gradient bits, and the same after scaling the loss (a non-unit gradient arriving at it)."""
+    from sequitr_amd.train import UNetTrainer
+    base = dict({"shape": (64, 64), "dropout": 0.4, "device": "cuda:0", "seed": 5, "dtype": "bf16"}, **cfg)
+    C = base.get("num_outputs", 2)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 64, 64, 1)).astype(np.float32)
+    lab = rng.integers(0, C, (2, 64, 64))
+    onehot = (lab[..., None] == np.arange(C)).astype(np.uint8)
+    wmap = (1 + 4 * rng.random((2, 64, 64, 1))).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to("cuda:0")
+    a, b = UNetTrainer(dict(base, fuse_head_loss=True)), UNetTrainer(dict(base, fuse_head_loss=False))
+    la, lb = a.forward_backward(d(x), d(onehot), d(wmap)), b.forward_backward(d(x), d(onehot), d(wmap))
+    assert la.item() == lb.item()
+    ga, gb = a.grads(), b.grads()
+    for k in gb:
+        assert np.array_equal(ga[k], gb[k]), k
+    # a scaled loss: the incoming gradient is a device scalar in both tapes
+    from sequitr_amd import functional as F
+    outs = []
+    for t in (a, b):
+        t.gbucket.flat.zero_()
+        if t.pack_plan is not None:
+            t.pack_plan.run()
+        t.net.dropout_masks = None
+        if t.fuse_head_loss:
+            loss = t.net.build_loss(d(x), d(onehot), d(wmap))
+        else:
+            loss = F.weighted_softmax_cross_entropy(t.net.build(d(x)), d(onehot), d(wmap))
+        (loss * 0.37).backward()
+        outs.append(t.grads())
+    for k in outs[1]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
