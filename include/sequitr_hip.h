@@ -395,6 +395,10 @@ int sq_conv3x3_first_fwd_bf16(const float *x, const float *w, const float *bias,
 int64_t sq_conv2d_nhwc_wgrad_workspace_bf16(int N, int H, int W, int Cin, int Cout, int K);
 int sq_conv2d_nhwc_wgrad_bf16(const void *x, const void *dy, float *dw, float *db, float *workspace, int N,
                               int H, int W, int Cin, int Cout, int K, void *stream);
+/* parameter gradients of the 2x2/s2 transpose conv from x (N,H,W,Cin) bf16 and the output gradient in space-to-depth
+ * form g (N,H,W,4*Cout) bf16: dW (2,2,Cout,Cin) f32, db (Cout) f32 or NULL; workspace as for the 1x1 wgrad Cin -> 4*Cout */
+int sq_convT2x2s2_wgrad_bf16(const void *x, const void *g, float *dw, float *db, float *workspace, int N, int H, int W,
+                             int Cin, int Cout, void *stream);
 
 /* bf16 <-> f32 casts (RNE), n % 4 == 0 */
 int sq_cast_f32_to_bf16(const float *x, void *y, int64_t n, void *stream);

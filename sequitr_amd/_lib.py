@@ -109,6 +109,7 @@ SIGNATURES = {
     "sq_conv3x3_first_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "sq_conv2d_nhwc_wgrad_workspace_bf16": (c_int64, [c_int] * 6),
     "sq_conv2d_nhwc_wgrad_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "sq_convT2x2s2_wgrad_bf16": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "sq_cast_f32_to_bf16": (c_int, [c_void_p] * 2 + [c_int64, c_void_p]),
     "sq_cast_bf16_to_f32": (c_int, [c_void_p] * 2 + [c_int64, c_void_p]),
     "sq_maxpool2x2_fwd_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),

@@ -238,11 +238,15 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
 
 // factor the finish kernel applies to dW (not db): set by the *_scaled_* entry points around their dispatch, 1 otherwise
 thread_local float t_dw_scale = 1.0f;
+// > 0: the launch is the 1x1 wgrad of a 2x2/s2 transpose conv in space-to-depth form (Cout = 4 * t_convT_cout); the
+// finish kernel then writes the transpose conv's own parameter layouts (sq_convT2x2s2_wgrad_bf16)
+thread_local int t_convT_cout = 0;
 
 template <int KS, int NI, int NO>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float *__restrict__ partials,
                                                                       float *__restrict__ dw, float *__restrict__ db,
-                                                                      int nblk, int Cin, int Cout, int G, float dw_scale) {
+                                                                      int nblk, int Cin, int Cout, int G, float dw_scale,
+                                                                      int ct) {
     using C = WB<KS, NI, NO>;
     const int nco = Cout / C::CO, npairs = (Cin / C::CI) * nco;
     const int total = C::NTAP * Cin * Cout;
@@ -254,7 +258,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float
         const size_t off = (size_t)((ci / C::CI) * nco + co / C::CO) * C::RED_FLOATS +
                            (tap * C::CI + ci % C::CI) * C::CO + co % C::CO;
         const float s = sq_group_reduce(partials + off, stride, nblk, g, G);
-        if (g == 0) dw[i] = dw_scale == 1.0f ? s : s * dw_scale;      // the equalised-LR factor of gan.py:79, one f32 multiply
+        // ct: dW of the transpose conv, (2,2,ct,Cin), from column q * ct + c of its space-to-depth form
+        const size_t o = ct ? (size_t)co * Cin + ci : (size_t)i;
+        if (g == 0) dw[o] = dw_scale == 1.0f ? s : s * dw_scale;      // the equalised-LR factor of gan.py:79, one f32 multiply
+    } else if (ct) {                                            // db[c] = ((q0 + q1) + q2) + q3 of the four sub-pixel columns
+        const int c = i - total;
+        if (c < ct) {
+            float s = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const int co = q * ct + c;
+                const size_t off = (size_t)(co / C::CO) * C::RED_FLOATS + (C::NTAP * C::CI) * C::CO + co % C::CO;
+                const float sq = sq_group_reduce(partials + off, stride, nblk, g, G);
+                s = q ? s + sq : sq;
+            }
+            if (g == 0 && db) db[c] = s;
+        }
     } else if (i < total + Cout) {
         const int co = i - total;
         const size_t off = (size_t)(co / C::CO) * C::RED_FLOATS + (C::NTAP * C::CI) * C::CO + co % C::CO;
@@ -307,7 +325,7 @@ int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, 
     const int G = sq_group_size(gx);
     const int64_t total = ((int64_t)KS * KS * Cin * Cout + Cout) * G;
     hipLaunchKernelGGL((conv_wgrad_bf16_finish_kernel<KS, NI, NO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       ws, dw, db, gx, Cin, Cout, G, t_dw_scale);
+                       ws, dw, db, gx, Cin, Cout, G, t_dw_scale, KS == 1 ? t_convT_cout : 0);
     return sq_check_launch("sq_conv2d_nhwc_wgrad_bf16(finish)");
 }
 
@@ -435,6 +453,19 @@ extern "C" int sq_conv2d_nhwc_wgrad_mixed_f32(const float *x, const float *dy, f
                Cout, K);
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(workspace);
     return launch_any_mixed(x, dy, dw, db, workspace, N, H, W, Cin, Cout, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+// parameter gradients of conv_transpose_layer (2x2, stride 2; unet.py:312-318) from its input x (N,H,W,Cin) and the
+// gradient of its output in space-to-depth form g (N,H,W,4*Cout): dW (2,2,Cout,Cin) f32 and db (Cout) f32 or NULL.
+// The 1x1 weight-gradient kernel of sq_conv2d_nhwc_wgrad_bf16 with a finish kernel that writes these layouts (the
+// permutation and the 4-way bias sum were two framework kernels per level).  Workspace: that of the 1x1 wgrad Cin -> 4*Cout.
+extern "C" int sq_convT2x2s2_wgrad_bf16(const void *x, const void *g, float *dw, float *db, float *workspace, int N, int H,
+                                        int W, int Cin, int Cout, void *stream) {
+    SQ_REQUIRE(Cout > 0 && Cout % 4 == 0, "sq_convT2x2s2_wgrad_bf16: Cout=%d", Cout);
+    t_convT_cout = Cout;
+    const int rc = sq_conv2d_nhwc_wgrad_bf16(x, g, dw, db, workspace, N, H, W, Cin, 4 * Cout, 1, stream);
+    t_convT_cout = 0;
+    return rc;
 }
 
 // dW additionally multiplied by dw_scale in the finish kernel (db is not): the gradient of a weighted_conv2d kernel is

@@ -7,7 +7,7 @@ from torch.autograd.function import once_differentiable
 
 from . import ops
 from . import ops_bf16 as ob
-from .functional import grad_sink, convT_param_grads
+from .functional import grad_sink
 
 
 class _Conv2d(torch.autograd.Function):
@@ -273,8 +273,9 @@ class _UpJunction(torch.autograd.Function):
                 dx = ob.conv2d_dgrad_relu(g, wp, x, 1, scale=ctx.gate.take())
             else:
                 dx = ob.conv2d(g, wp, None, 1, Cin)
-        dwp, dbp = ob.conv2d_wgrad(x, g, 1, want_bias=ctx.has_bias)
-        dw, db = convT_param_grads(dwp, dbp if ctx.has_bias else None, Cin, Cout, ctx.sinks)
+        sw, sb = ctx.sinks
+        dw, db = ob.convT_wgrad(x, g, Cout, want_bias=ctx.has_bias, dw_out=sw, db_out=sb if ctx.has_bias else None)
+        dw, db = (None if sw is not None else dw), (None if (sb is not None or not ctx.has_bias) else db)
         if ctx.box is not None and ctx.needs_input_grad[3]:
             ctx.box['dskip'] = dskip                            # picked up by the skip tensor's pool backward
             dskip = None
@@ -314,8 +315,9 @@ class _ConvT(torch.autograd.Function):
             if wp is None:
                 wp = ob.pack_weights(w.reshape(1, 1, 4 * Cout, Cin))          # 1x1 conv 4Cout -> Cin
             dx = ob.conv2d(g, wp, None, 1, Cin)
-        dwp, dbp = ob.conv2d_wgrad(x, g, 1, want_bias=ctx.has_bias)           # (1,1,Cin,4Cout)
-        dw, db = convT_param_grads(dwp, dbp if ctx.has_bias else None, Cin, Cout, ctx.sinks)
+        sw, sb = ctx.sinks
+        dw, db = ob.convT_wgrad(x, g, Cout, want_bias=ctx.has_bias, dw_out=sw, db_out=sb if ctx.has_bias else None)
+        dw, db = (None if sw is not None else dw), (None if (sb is not None or not ctx.has_bias) else db)
         return dx, dw, db
 
 

@@ -146,6 +146,25 @@ def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None):
     return dw, db
 
 
+def convT_wgrad(x, g, Cout, want_bias=True, dw_out=None, db_out=None):
+    """(dW (2,2,Cout,Cin) f32, db (Cout) f32 or None) of the 2x2/s2 transpose conv from its bf16 input x and its
+    output gradient in space-to-depth form g (N,H,W,4*Cout)."""
+    _chk(x, "x", ndim=4), _chk(g, "g", ndim=4)
+    N, H, W, Cin = x.shape
+    if tuple(g.shape) != (N, H, W, 4 * Cout):
+        raise ValueError("convT_wgrad: g must be %s" % ((N, H, W, 4 * Cout),))
+    lib = _lib.load()
+    nbytes = lib.sq_conv2d_nhwc_wgrad_workspace_bf16(N, H, W, Cin, 4 * Cout, 1)
+    if nbytes < 0:
+        raise _lib.SequitrHipError("convT_wgrad(bf16): unsupported Cin=%d Cout=%d" % (Cin, Cout))
+    ws = _workspace(nbytes, x.device)
+    dw = _grad_out(dw_out, (2, 2, Cout, Cin), x.device)
+    db = _grad_out(db_out, (Cout,), x.device) if want_bias else None
+    _lib.check(lib.sq_convT2x2s2_wgrad_bf16(_ptr(x), _ptr(g), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout, _stream()),
+               "sq_convT2x2s2_wgrad_bf16")
+    return dw, db
+
+
 class PackPlan(object):
     """All bf16 filter packs of one training step as ONE launch (sq_conv_pack_weights_multi_bf16).
     `flat` is the flat fp32 parameter buffer, `leaves` {name: (leaf tensor, float offset)}; every 3x3 / 1x1

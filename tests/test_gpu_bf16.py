@@ -400,3 +400,20 @@ def test_head_plus_loss_tape_entry_equals_head_then_loss(cfg):
         outs.append(t.grads())
     for k in outs[1]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 20, 64, 32), (1, 16, 16, 32, 16), (1, 8, 8, 256, 128)])
+def test_convT_wgrad_writes_the_transpose_conv_layouts(shape):
+    """sq_convT2x2s2_wgrad_bf16 = the 1x1 wgrad of the space-to-depth form, with dW permuted to (2,2,Cout,Cin) and db
+    summed over the four sub-pixel columns ((q0 + q1) + q2) + q3 by the finish kernel."""
+    N, H, W, Cin, Cout = shape
+    x, g = dev(tiles(51, N, H, W, Cin), torch.bfloat16), dev(tiles(52, N, H, W, 4 * Cout), torch.bfloat16)
+    dwp, dbp = ob.conv2d_wgrad(x, g, 1)
+    dw_ref = dwp.reshape(Cin, 2, 2, Cout).permute(1, 2, 3, 0).contiguous()
+    b4 = dbp.reshape(4, Cout)
+    db_ref = ((b4[0] + b4[1]) + b4[2]) + b4[3]
+    dw, db = ob.convT_wgrad(x, g, Cout)
+    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    sink = torch.zeros(2 * 2 * Cout * Cin, device="cuda")
+    dw2, db2 = ob.convT_wgrad(x, g, Cout, want_bias=False, dw_out=sink)
+    assert db2 is None and torch.equal(sink.view(2, 2, Cout, Cin), dw_ref)
