@@ -301,12 +301,14 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_bf16_kernel(const bf16x8 
 // D[rho][p] = sum_c Wt[rho][c] X[p][c], rho = (2a+b)*Cout + o; Wt = the (2,2,Cout,Cin) kernel read flat (k = c is
 // contiguous for both operands: 16-byte fragment reads).  Block = 64 rows x 64 input pixels, 32-channel chunks.
 constexpr int CT_ROWB = 96;                                   // 64 B of data + pad: conflict-free b128 reads
+constexpr int CT_STGB = 144;                                  // output staging: 64 rows x (128 B + pad)
 __global__ __launch_bounds__(256) void convT_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
                                                           const float *__restrict__ bias, const __bf16 *__restrict__ skip,
                                                           __bf16 *__restrict__ y, int64_t P, int H, int W, int Cin, int Cout,
                                                           int bridge, __bf16 *__restrict__ up_out) {
-    __shared__ __attribute__((aligned(16))) unsigned char as[64 * CT_ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char xs[64 * CT_ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 64 * CT_ROWB];
+    unsigned char *as = lds, *xs = lds + 64 * CT_ROWB;
+    static_assert(64 * CT_STGB <= 2 * 64 * CT_ROWB, "the output staging tile reuses the operand tiles");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
@@ -330,33 +332,47 @@ __global__ __launch_bounds__(256) void convT_bf16_kernel(const __bf16 *__restric
         }
         __syncthreads();
     }
-    const int rho = r0 + 16 * wv + 4 * kg;
-    const int ab = rho / Cout, o = rho % Cout;
-    const int a2 = ab >> 1, b2 = ab & 1;
+    // epilogue through LDS: the accumulator layout gives a lane 4 channels (8 B) of one sub-pixel, 16 lanes 16 output
+    // pixels a stride apart -- scattered 8-byte accesses for the skip read and both stores.  Staged as [pixel][rho]
+    // (up-scaled value, already rounded to bf16) and read back in OUTPUT order, the block's results are runs of whole
+    // output-row segments: 16 bytes per lane, consecutive lanes consecutive addresses.
+    const int rho = 16 * wv + 4 * kg;                          // block-local row
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) bv = *reinterpret_cast<const float4 *>(bias + o);
+    if (bias) bv = *reinterpret_cast<const float4 *>(bias + (r0 + rho) % Cout);
+    unsigned char *stg = lds;                                  // the operand tiles are dead (loop ended on a barrier)
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const int64_t p = p0 + cb * 16 + li;
-        if (p >= P) continue;
-        const int j = (int)(p % W);
-        const int64_t t = p / W;
-        const int i = (int)(t % H);
+    for (int cb = 0; cb < 4; ++cb)
+        *reinterpret_cast<bf16x4 *>(stg + (cb * 16 + li) * CT_STGB + rho * 2) =
+            (bf16x4){(__bf16)(acc[cb][0] + bv.x), (__bf16)(acc[cb][1] + bv.y), (__bf16)(acc[cb][2] + bv.z),
+                     (__bf16)(acc[cb][3] + bv.w)};
+    __syncthreads();
+    // rows (2a+b)*Cout + o: for one a, (b, o) is contiguous in the output over min(64, 2*Cout) rows of this block
+    const int RB = 2 * Cout < 64 ? 2 * Cout : 64, R8 = RB >> 3;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * 256;                         // 512 sixteen-byte pieces
+        const int ai = idx / (64 * R8), rem = idx % (64 * R8);
+        const int pl = rem / R8, rl = ai * RB + (rem % R8) * 8;
+        const int64_t pp = p0 + pl;
+        if (pp >= P) continue;
+        const int rg = r0 + rl, ab = rg / Cout, o = rg % Cout;
+        const int jx = (int)(pp % W);
+        const int64_t t = pp / W;
+        const int iy = (int)(t % H);
         const int64_t n = t / H;
-        const size_t off = ((size_t)(n * 2 * H + 2 * i + a2) * (2 * W) + 2 * j + b2) * Cout + o;
-        float v[4] = {acc[cb][0] + bv.x, acc[cb][1] + bv.y, acc[cb][2] + bv.z, acc[cb][3] + bv.w};
-        if (up_out)                                               // training keeps the up-scaled tensor for the bridge backward
-            *reinterpret_cast<bf16x4 *>(up_out + off) = (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        const size_t off = ((size_t)(n * 2 * H + 2 * iy + (ab >> 1)) * (2 * W) + 2 * jx + (ab & 1)) * Cout + o;
+        bf16x8 u = *reinterpret_cast<const bf16x8 *>(stg + pl * CT_STGB + rl * 2);
+        if (up_out) *reinterpret_cast<bf16x8 *>(up_out + off) = u;    // training keeps the up-scaled tensor for the bridge backward
         if (bridge != SQ_BRIDGE_NONE) {
-            const bf16x4 k = *reinterpret_cast<const bf16x4 *>(skip + off);
+            const bf16x8 k = *reinterpret_cast<const bf16x8 *>(skip + off);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // the up-scaled value is rounded to bf16 first: bit-identical to the unfused convT -> bridge pair
-                const float u = (float)(__bf16)v[e], s = (float)k[e];
-                v[e] = bridge == SQ_BRIDGE_ADD ? u + s : (bridge == SQ_BRIDGE_MUL ? u * s : u - s);
+            for (int e = 0; e < 8; ++e) {
+                // the up-scaled value was rounded to bf16 first: bit-identical to the unfused convT -> bridge pair
+                const float uu = (float)u[e], sk = (float)k[e];
+                u[e] = (__bf16)(bridge == SQ_BRIDGE_ADD ? uu + sk : (bridge == SQ_BRIDGE_MUL ? uu * sk : uu - sk));
             }
         }
-        *reinterpret_cast<bf16x4 *>(y + off) = (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *reinterpret_cast<bf16x8 *>(y + off) = u;
     }
 }
 
