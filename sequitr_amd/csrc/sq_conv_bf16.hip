@@ -296,56 +296,63 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
             const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(drop.j_skip), 0, mul ? jb : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t dsrsrc = __builtin_amdgcn_make_buffer_rsrc(drop.j_dskip, 0, jb, 0x00020000);
             const __amdgpu_buffer_rsrc_t g2rsrc = __builtin_amdgcn_make_buffer_rsrc(drop.j_g, 0, jb, 0x00020000);
-            unsigned offs[NR][4];
-            bf16x4 uv[NR][4], kv[NR][4];
+            // NG channel blocks at a time: the operands of the whole 64-channel tile would not fit beside the
+            // accumulators (BN = 64: 64 more registers -> scratch)
+            constexpr int NG = NR > 2 ? 2 : NR;
 #pragma unroll
-            for (int nb = 0; nb < NR; ++nb) {
-                const int co = n0 + nb * 16 + 4 * kg;
+            for (int nb0 = 0; nb0 < NR; nb0 += NG) {
+                unsigned offs[NG][4];
+                bf16x4 uv[NG][4], kv[NG][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gy = ty * TH + 4 * wv + r;
-                    const bool ok = gy < H && gx < W && co < Cout;
-                    offs[nb][r] = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 2) : OOB;
-                }
-            }
-            if (mul) {
-#pragma unroll
-                for (int nb = 0; nb < NR; ++nb)
+                for (int g = 0; g < NG; ++g) {
+                    const int co = n0 + (nb0 + g) * 16 + 4 * kg;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        uv[nb][r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(ursrc, offs[nb][r], 0, 0));
-                        kv[nb][r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(krsrc, offs[nb][r], 0, 0));
+                        const int gy = ty * TH + 4 * wv + r;
+                        const bool ok = gy < H && gx < W && co < Cout;
+                        offs[g][r] = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 2) : OOB;
                     }
-                __builtin_amdgcn_s_waitcnt(0x0F70);             // inside the branch, as for the gate below
-            }
+                }
+                if (mul) {
 #pragma unroll
-            for (int nb = 0; nb < NR; ++nb) {
-                const int co = n0 + nb * 16 + 4 * kg;
+                    for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gy = ty * TH + 4 * wv + r;
-                    bf16x4 o, da, db;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[r][nb][j];
-                    da = o, db = o;
-                    if (mul) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            da[j] = (__bf16)((float)o[j] * (float)kv[nb][r][j]);
-                            db[j] = (__bf16)((float)o[j] * (float)uv[nb][r][j]);
+                        for (int r = 0; r < 4; ++r) {
+                            uv[g][r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(ursrc, offs[g][r], 0, 0));
+                            kv[g][r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(krsrc, offs[g][r], 0, 0));
                         }
-                    } else if (drop.j_bridge == SQ_BRIDGE_SUB) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);         // inside the branch, as for the gate below
+                }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) db[j] = (__bf16)(-(float)o[j]);
+                for (int g = 0; g < NG; ++g) {
+                    const int nb = nb0 + g;
+                    const int co = n0 + nb * 16 + 4 * kg;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gy = ty * TH + 4 * wv + r;
+                        bf16x4 o, da, db;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[r][nb][j];
+                        da = o, db = o;
+                        if (mul) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                da[j] = (__bf16)((float)o[j] * (float)kv[g][r][j]);
+                                db[j] = (__bf16)((float)o[j] * (float)uv[g][r][j]);
+                            }
+                        } else if (drop.j_bridge == SQ_BRIDGE_SUB) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) db[j] = (__bf16)(-(float)o[j]);
+                        }
+                        const unsigned off = offs[g][r];
+                        const unsigned goff = off == OOB ? OOB :
+                            (unsigned)((((((n * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * 4 + ((gy & 1) * 2 + (gx & 1))) * Cout) + co) * 2);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
+                            __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, db), dsrsrc, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
+                            __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, da), g2rsrc, goff, 0, 0);
+                        acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
-                    const unsigned off = offs[nb][r];
-                    const unsigned goff = off == OOB ? OOB :
-                        (unsigned)((((((n * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * 4 + ((gy & 1) * 2 + (gx & 1))) * Cout) + co) * 2);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
-                        __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, db), dsrsrc, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
-                        __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, da), g2rsrc, goff, 0, 0);
-                    acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
             return;

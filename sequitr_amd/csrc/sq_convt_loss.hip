@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const double *__restrict
 
 inline int64_t ce_blocks(int64_t npix) {
     int64_t b = (npix + 255) / 256;
-    return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+    return b > 2048 ? 2048 : (b < 1 ? 1 : b);
 }
 
 }  // namespace

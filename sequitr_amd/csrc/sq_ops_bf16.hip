@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void head_finish2_kernel(const float *__restri
 
 inline int head_blocks(int64_t npix) {
     int64_t b = (npix + 255) / 256;
-    return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
 }
 
 }  // namespace
