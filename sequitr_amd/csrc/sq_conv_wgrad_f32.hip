@@ -321,31 +321,60 @@ __global__ __launch_bounds__(256) void conv_wgrad_cin1_f32_kernel(
 #pragma unroll
     for (int c = 0; c < CIN; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    // register double buffer: the next tile's loads are in flight while this one is multiplied (the kernel used to
+    // load, wait, compute, and hid the HBM latency only through resident blocks)
+    constexpr int XSL = (HW * HW * CIN + 255) / 256;            // halo items (one float) per thread
+    constexpr int YV = sizeof(TY) == 4 ? 4 : 2;                 // 16-byte pieces of dY per thread: 256 px x 16 ch
+    float xr[XSL];
+    uint4 yr[YV];
+    auto fetch = [&](int tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW, y0 = ty * TH;
-        for (int idx = tid; idx < HW * HW * CIN; idx += 256) {
+#pragma unroll
+        for (int sl = 0; sl < XSL; ++sl) {
+            const int idx = tid + sl * 256;
             const int pix = idx / CIN, c = idx % CIN;
             const int gy = y0 - 1 + pix / HW, gx = x0 - 1 + pix % HW;
-            xs[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[(((size_t)n * H + gy) * W + gx) * CIN + c] : 0.f;
+            xr[sl] = (idx < HW * HW * CIN && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                         ? x[(((size_t)n * H + gy) * W + gx) * CIN + c] : 0.f;
         }
-        for (int idx = tid; idx < TH * TW * 4; idx += 256) {
-            const int pix = idx >> 2, q = idx & 3;
+#pragma unroll
+        for (int v = 0; v < YV; ++v) {
+            constexpr int PER = 16 / (16 / (int)sizeof(TY));   // 16-byte pieces per pixel: 4 (f32), 2 (bf16)
+            constexpr int EL = 16 / (int)sizeof(TY);           // channels per piece
+            const int idx = tid + v * 256, pix = idx / PER, q = idx % PER;
             const int gy = y0 + pix / TW, gx = x0 + pix % TW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < H && gx < W && co0 + q * 4 < Cout) {
-                const TY *src = dy + (((size_t)n * H + gy) * W + gx) * Cout + co0 + q * 4;
-                if constexpr (sizeof(TY) == 4) {
-                    v = *reinterpret_cast<const float4 *>(src);
-                } else {                                          // bf16 dY: 4 values = 8 bytes
-                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-                    const bf16x4_t h = *reinterpret_cast<const bf16x4_t *>(src);
-                    v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-                }
-            }
-            *reinterpret_cast<float4 *>(ys + pix * 16 + q * 4) = v;
+            yr[v] = make_uint4(0, 0, 0, 0);
+            if (gy < H && gx < W && co0 + q * EL < Cout)        // Cout % 4 == 0; a partial last group (bf16: Cout % 8 == 4)
+                yr[v] = (co0 + q * EL + EL <= Cout)             // is read 8 bytes wide
+                            ? *reinterpret_cast<const uint4 *>(dy + (((size_t)n * H + gy) * W + gx) * Cout + co0 + q * EL)
+                            : make_uint4(reinterpret_cast<const uint2 *>(dy + (((size_t)n * H + gy) * W + gx) * Cout + co0 + q * EL)->x,
+                                         reinterpret_cast<const uint2 *>(dy + (((size_t)n * H + gy) * W + gx) * Cout + co0 + q * EL)->y, 0, 0);
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int sl = 0; sl < XSL; ++sl)
+            if (tid + sl * 256 < HW * HW * CIN) xs[tid + sl * 256] = xr[sl];
+#pragma unroll
+        for (int v = 0; v < YV; ++v) {
+            const int idx = tid + v * 256;
+            if constexpr (sizeof(TY) == 4) {
+                *reinterpret_cast<uint4 *>(ys + (idx >> 2) * 16 + (idx & 3) * 4) = yr[v];
+            } else {
+                typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+                const bf16x8_t h = __builtin_bit_cast(bf16x8_t, yr[v]);
+                float *dst = ys + (idx >> 1) * 16 + (idx & 1) * 8;
+                *reinterpret_cast<float4 *>(dst) = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                *reinterpret_cast<float4 *>(dst + 4) = make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
+            }
+        }
+    };
+    if (t_begin < t_end) fetch(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        commit();
         __syncthreads();
+        if (tile + 1 < t_end) fetch(tile + 1);
 #pragma unroll 4
         for (int ks = 0; ks < 16; ++ks) {
             const int r = 4 * wv + (ks >> 2), g = ks & 3;
