@@ -33,7 +33,9 @@ struct WB {
     static constexpr int HP = HALO_W * (TH + KS - 1);
     static constexpr int NTAP = KS * KS;
     static constexpr int CI = 16 * NI, CO = 16 * NO;          // channels of X / dY one block contracts
-    static constexpr int XPLANE = HP * PSB, YPLANE = TH * TW * PSB;   // one 16-channel plane of the tile in LDS
+    // one 16-channel plane of the tile in LDS; the X planes are 64 B out of phase so that the 16-byte commit writes of
+    // one pixel's two planes (consecutive lanes) land in different banks
+    static constexpr int XPLANE = HP * PSB + (NI > 1 ? 64 : 0), YPLANE = TH * TW * PSB;
     static constexpr int XS_BYTES = XPLANE * NI;
     static constexpr int YS_BYTES = YPLANE * NO;
     static constexpr int ROWS = NTAP * CI + 1;
@@ -92,6 +94,17 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
     // PF register sets: the loads of tile t+PF are issued while tile t is computed, i.e. PF-1 whole
     // iterations before they are committed to LDS -- one iteration is far shorter than an HBM round trip
     uint4 xr[PF][C::XSLOTS][XV], yr[PF][C::YSLOTS][XV];
+    // halo geometry of this thread's X items, fixed for the whole run (the divisions by the halo width are not
+    // redone per tile): position in the halo (py | px << 16; py = 0x7FFF, never in range, for a slot past the tile) and the byte offset
+    // relative to the halo's first pixel
+    int xpos[C::XSLOTS], xrel[C::XSLOTS];
+#pragma unroll
+    for (int sl = 0; sl < C::XSLOTS; ++sl) {
+        const int idx = tid + sl * 256, pix = idx / (2 * NI), rem = idx % (2 * NI);
+        const int py = pix / C::HALO_W, px = pix % C::HALO_W;
+        xpos[sl] = idx < C::XITEMS ? (py | (px << 16)) : 0x7FFF;
+        xrel[sl] = ((py * W + px) * Cin + rem * 8) * ES;
+    }
     auto issue = [&](int tile, uint4 (&xr)[C::XSLOTS][XV], uint4 (&yr)[C::YSLOTS][XV]) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW, y0 = ty * TH;
@@ -99,11 +112,9 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
         const int ybase = (((n * H + y0) * W + x0) * Cout + co0) * ES;
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
-            const int idx = tid + sl * 256, pix = idx / (2 * NI), rem = idx % (2 * NI);
-            const int py = pix / C::HALO_W, px = pix % C::HALO_W;
-            const bool inb = idx < C::XITEMS && (unsigned)(y0 - PAD + py) < (unsigned)H &&
-                             (unsigned)(x0 - PAD + px) < (unsigned)W;
-            const unsigned off = inb ? (unsigned)(xbase + ((py * W + px) * Cin + rem * 8) * ES) : OOB;
+            const int py = xpos[sl] & 0xFFFF, px = xpos[sl] >> 16;
+            const bool inb = (unsigned)(y0 - PAD + py) < (unsigned)H && (unsigned)(x0 - PAD + px) < (unsigned)W;
+            const unsigned off = inb ? (unsigned)(xbase + xrel[sl]) : OOB;
 #pragma unroll
             for (int h = 0; h < XV; ++h) {
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? off + 16 * h : OOB, 0, 0);
@@ -131,7 +142,8 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
             const int idx = tid + sl * 256, pix = idx / (2 * NI), rem = idx % (2 * NI);
-            if (idx < C::XITEMS) *reinterpret_cast<uint4 *>(xs + (rem >> 1) * C::XPLANE + pix * PSB + (rem & 1) * 16) = item(xr[sl]);
+            if (idx < C::XITEMS)
+                *reinterpret_cast<uint4 *>(xs + (rem >> 1) * C::XPLANE + pix * PSB + (rem & 1) * 16) = item(xr[sl]);
         }
 #pragma unroll
         for (int sl = 0; sl < C::YSLOTS; ++sl) {
@@ -147,9 +159,12 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int o = 0; o < NO; ++o) acc[t][i][o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bsum[NO];
+    f32x4 bacc[NO];                                             // every row = sum over pixels of dY[.][co = li]
 #pragma unroll
-    for (int o = 0; o < NO; ++o) bsum[o] = 0.f;
+    for (int o = 0; o < NO; ++o) bacc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
     // this lane's tr-read address inside a k-step: pixel (row kg>>1, x 4*(kg&1) + q), 8-byte piece p;
     // the second read of a fragment is 8 pixels further along the row
@@ -179,8 +194,8 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
 #pragma unroll
                 for (int o = 0; o < NO; ++o) {
                     b[o] = tr_frag(yk + o * C::YPLANE, yk + o * C::YPLANE + 8 * PSB);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bsum[o] += (float)b[o][e];
+                    // db on the matrix pipe: a row of ones times the dY fragment (16 conversions + adds on the VALU before)
+                    bacc[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[o], bacc[o], 0, 0, 0);
                 }
 #pragma unroll
                 for (int t = 0; t < C::NTAP; ++t) {
@@ -196,6 +211,8 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
             }
             __syncthreads();
             if (tile + 1 < t_end) {
+                // (a second LDS buffer with one barrier per tile was measured: slower on the 16-channel and 1x1 shapes,
+                // within 3 % on the deep 3x3 ones -- the barriers are not what this loop waits for)
                 commit(xr[(u + 1) % PF], yr[(u + 1) % PF]);
                 __syncthreads();
             }
@@ -204,11 +221,9 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
 
     // cross-wave reduction in wave order, then one partial per block: red[(tap*CI + ci)*CO + co], bias row last
     float *red = reinterpret_cast<float *>(smem);
+    float bsum[NO];
 #pragma unroll
-    for (int o = 0; o < NO; ++o) {
-        bsum[o] += __shfl_xor(bsum[o], 16);
-        bsum[o] += __shfl_xor(bsum[o], 32);
-    }
+    for (int o = 0; o < NO; ++o) bsum[o] = bacc[o][0];          // row 4 * kg: identical in every row
     for (int w = 0; w < 4; ++w) {
         if (wv == w) {
 #pragma unroll
@@ -349,6 +364,12 @@ inline void max_shape(int *ni, int *no) {
     *no = mo;
 }
 
+// SQ_WGRAD_BF16_K3="ni,no": force the 3x3 block shape where the channel counts allow it (tuning experiments)
+inline int k3_shape() {
+    static const int v = [] { const char *e = getenv("SQ_WGRAD_BF16_K3"); return (e && e[0] && e[1] == ',' && e[2]) ? (e[0] - '0') * 10 + (e[2] - '0') : 0; }();
+    return v;
+}
+
 // channel-block shape per layer, from the measured sweep (tools/wgrad_bf16_bench.py under rocprofv3): every
 // launch is bound by the re-read traffic X * Cout/(16 NO) + dY * Cin/(16 NI) at ~4-5 TB/s; 3x3: 32 x 16 channels
 // (32 x 32 needs 36 accumulator blocks = the whole register file at one block per CU, and is slower);
@@ -361,6 +382,10 @@ inline void max_shape(int *ni, int *no) {
         const bool i2 = wide && mi_ >= 2 && Cin % 32 == 0, o2 = wide && mo_ >= 2 && Cout % 32 == 0,  \
                    o4 = wide && mo_ >= 4 && Cout % 64 == 0;                                          \
         if (K == 3) {                                                                                \
+            const int k3_ = k3_shape();                                                              \
+            if (k3_ == 14 && Cout % 64 == 0) return FN<3, 1, 4>(__VA_ARGS__);                        \
+            if (k3_ == 22 && Cin % 32 == 0 && Cout % 32 == 0) return FN<3, 2, 2>(__VA_ARGS__);       \
+            if (k3_ == 12 && Cout % 32 == 0) return FN<3, 1, 2>(__VA_ARGS__);                        \
             if (i2) return FN<3, 2, 1>(__VA_ARGS__);                                                 \
             if (o2) return FN<3, 1, 2>(__VA_ARGS__);                                                 \
             return FN<3, 1, 1>(__VA_ARGS__);                                                         \
@@ -382,6 +407,10 @@ int64_t plan_floats(int N, int H, int W, int Cin, int Cout, int K) {
     const bool i2 = wide && mi_ >= 2 && Cin % 32 == 0, o2 = wide && mo_ >= 2 && Cout % 32 == 0,
                o4 = wide && mo_ >= 4 && Cout % 64 == 0;
     if (K == 3) {
+        const int k3_ = k3_shape();
+        if (k3_ == 14 && Cout % 64 == 0) return SQ_PLAN_CALL(3, 1, 4);
+        if (k3_ == 22 && Cin % 32 == 0 && Cout % 32 == 0) return SQ_PLAN_CALL(3, 2, 2);
+        if (k3_ == 12 && Cout % 32 == 0) return SQ_PLAN_CALL(3, 1, 2);
         if (i2) return SQ_PLAN_CALL(3, 2, 1);
         if (o2) return SQ_PLAN_CALL(3, 1, 2);
         return SQ_PLAN_CALL(3, 1, 1);
