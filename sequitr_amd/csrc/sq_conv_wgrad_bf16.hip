@@ -257,42 +257,71 @@ thread_local float t_dw_scale = 1.0f;
 // finish kernel then writes the transpose conv's own parameter layouts (sq_convT2x2s2_wgrad_bf16)
 thread_local int t_convT_cout = 0;
 
+// Finish: dW / db = sum over the K-split blocks of their partials, in a fixed order.  Threads walk the PARTIAL layout
+// ([pair][row][co], the order the blocks wrote): 256 / G consecutive elements x G lanes-groups per block, group g adds
+// blocks g, g + G, ... in order, then a fixed LDS tree folds the groups -- every load is a full run of consecutive
+// floats (the earlier version walked dW order with the group along the lanes: 4 useful bytes per 128-byte line).
 template <int KS, int NI, int NO>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float *__restrict__ partials,
                                                                       float *__restrict__ dw, float *__restrict__ db,
                                                                       int nblk, int Cin, int Cout, int G, float dw_scale,
                                                                       int ct) {
     using C = WB<KS, NI, NO>;
+    __shared__ float red[4][256];
     const int nco = Cout / C::CO, npairs = (Cin / C::CI) * nco;
-    const int total = C::NTAP * Cin * Cout;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int i = t / G, g = t % G;
+    const int total = npairs * C::RED_FLOATS;
+    const int OUT = 256 / G;
+    const int ol = threadIdx.x % OUT, g = threadIdx.x / OUT;
+    const int j = blockIdx.x * OUT + ol;
     const size_t stride = (size_t)npairs * C::RED_FLOATS;
-    if (i < total) {
-        const int co = i % Cout, ci = (i / Cout) % Cin, tap = i / (Cout * Cin);
-        const size_t off = (size_t)((ci / C::CI) * nco + co / C::CO) * C::RED_FLOATS +
-                           (tap * C::CI + ci % C::CI) * C::CO + co % C::CO;
-        const float s = sq_group_reduce(partials + off, stride, nblk, g, G);
-        // ct: dW of the transpose conv, (2,2,ct,Cin), from column q * ct + c of its space-to-depth form
-        const size_t o = ct ? (size_t)co * Cin + ci : (size_t)i;
-        if (g == 0) dw[o] = dw_scale == 1.0f ? s : s * dw_scale;      // the equalised-LR factor of gan.py:79, one f32 multiply
-    } else if (ct) {                                            // db[c] = ((q0 + q1) + q2) + q3 of the four sub-pixel columns
-        const int c = i - total;
-        if (c < ct) {
-            float s = 0.f;
-            for (int q = 0; q < 4; ++q) {
-                const int co = q * ct + c;
-                const size_t off = (size_t)(co / C::CO) * C::RED_FLOATS + (C::NTAP * C::CI) * C::CO + co % C::CO;
-                const float sq = sq_group_reduce(partials + off, stride, nblk, g, G);
-                s = q ? s + sq : sq;
-            }
-            if (g == 0 && db) db[c] = s;
+    auto column = [&](int jj) {                                 // this group's share of element jj, in block order
+        float s = 0.f;
+        const float *p = partials + jj;
+        int b = g;
+        for (; b + 3 * G < nblk; b += 4 * G) {                  // four loads in flight
+            const float v0 = p[(size_t)b * stride], v1 = p[(size_t)(b + G) * stride], v2 = p[(size_t)(b + 2 * G) * stride],
+                        v3 = p[(size_t)(b + 3 * G) * stride];
+            s = (((s + v0) + v1) + v2) + v3;
         }
-    } else if (i < total + Cout) {
-        const int co = i - total;
-        const size_t off = (size_t)(co / C::CO) * C::RED_FLOATS + (C::NTAP * C::CI) * C::CO + co % C::CO;
-        const float s = sq_group_reduce(partials + off, stride, nblk, g, G);
-        if (g == 0 && db) db[co] = s;
+        for (; b < nblk; b += G) s += p[(size_t)b * stride];
+        return s;
+    };
+    const bool live = j < total;
+    const int pair = live ? j / C::RED_FLOATS : 0, r = live ? j % C::RED_FLOATS : 0, row = r / C::CO, col = r % C::CO;
+    const int co = (pair % nco) * C::CO + col;
+    const bool bias_row = row == C::NTAP * C::CI;
+    // transpose conv (ct > 0): db[c] = ((q0 + q1) + q2) + q3 over the sub-pixel columns q * ct + c; the lanes of
+    // column c (q = 0) reduce the other three columns as well
+    const bool fold = ct > 0 && live && bias_row && pair / nco == 0 && co < ct;
+    red[0][threadIdx.x] = live ? column(j) : 0.f;
+    if (ct > 0) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const int cq = co + q * ct;
+            red[q][threadIdx.x] = fold ? column((cq / C::CO) * C::RED_FLOATS + (C::NTAP * C::CI) * C::CO + cq % C::CO) : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int m = G >> 1; m > 0; m >>= 1) {
+        if (g < m) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + m * OUT];
+            if (ct > 0) {
+#pragma unroll
+                for (int q = 1; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + m * OUT];
+            }
+        }
+        __syncthreads();
+    }
+    if (g != 0 || !live) return;
+    const float s = red[0][threadIdx.x];
+    if (!bias_row) {
+        const int tap = row / C::CI, ci = (pair / nco) * C::CI + row % C::CI;
+        // ct: dW of the transpose conv, (2,2,ct,Cin), from column q * ct + c of its space-to-depth form
+        const size_t o = ct ? (size_t)co * Cin + ci : ((size_t)tap * Cin + ci) * Cout + co;
+        dw[o] = dw_scale == 1.0f ? s : s * dw_scale;            // the equalised-LR factor of gan.py:79, one f32 multiply
+    } else if (db && pair / nco == 0) {                         // the bias row is taken from the ci-block 0 pairs
+        if (!ct) db[co] = s;
+        else if (fold) db[co] = ((s + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
     }
 }
 
@@ -337,9 +366,11 @@ int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, 
                        tiles_y, tiles_x * tiles_y * N, tpb);
     int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_bf16");
     if (rc) return rc;
-    const int G = sq_group_size(gx);
-    const int64_t total = ((int64_t)KS * KS * Cin * Cout + Cout) * G;
-    hipLaunchKernelGGL((conv_wgrad_bf16_finish_kernel<KS, NI, NO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+    int G = sq_group_size(gx);
+    if (G > 16) G = 16;                                         // >= 16 consecutive floats (64 B) per load of a group
+    const int64_t total = (int64_t)npairs * C::RED_FLOATS;
+    const int OUT = 256 / G;
+    hipLaunchKernelGGL((conv_wgrad_bf16_finish_kernel<KS, NI, NO>), dim3((unsigned)((total + OUT - 1) / OUT)), dim3(256), 0, st,
                        ws, dw, db, gx, Cin, Cout, G, t_dw_scale, KS == 1 ? t_convT_cout : 0);
     return sq_check_launch("sq_conv2d_nhwc_wgrad_bf16(finish)");
 }
