@@ -17,33 +17,37 @@ inline unsigned grid_for(int64_t items) {
 #define SQ_GRID_STRIDE(i, n) \
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n); i += (int64_t)gridDim.x * 256)
 
-__device__ __forceinline__ float group16_sum(float v) {
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+template <int GL>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < GL; m <<= 1) v += __shfl_xor(v, m);
     return v;
 }
 
-// pixel_norm: y = x r, r = rsqrt(mean_c x^2 + eps).  One 16-lane group per pixel.
+// pixel_norm: y = x r, r = rsqrt(mean_c x^2 + eps).  One GL-lane group per pixel, GL = power of two >= C / 4, <= 16
+// (as pixelnorm_f32_kernel: the wide, few-channel layers keep every lane busy).
 //   MODE 1 (backward):      dx = r g - r^3 s x,                       s = mean_c(g x)
 //   MODE 2 (2nd backward):  given v = dL/d(dx):
 //        dg = r v - r^3 t x,                                          t = mean_c(v x)
 //        dx2 = -r^3 u x + 3 r^5 s t x - r^3 t g - r^3 s v,            u = mean_c(v g)
-template <int MODE>
+template <int MODE, int GL>
 __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                                              const float *__restrict__ v, float *__restrict__ out1,
                                                              float *__restrict__ out2, int64_t npix, int C, float eps,
                                                              float gate_slope) {
     // gate_slope (MODE 1 only): 1 = plain; otherwise x is the output of an activation (leaky 0.2 / ReLU 0) and dx leaves
     // already through that activation's backward, x > 0 ? dx : dx * slope -- the act_bwd pass that would follow
-    const int lane = threadIdx.x & 63, l16 = lane & 15, sub = lane >> 4;
+    constexpr int PPW = 64 / GL;
+    const int lane = threadIdx.x & 63, l16 = lane & (GL - 1), sub = lane / GL;
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
     const float invC = 1.0f / (float)C;
-    for (int64_t pb = wave * 4; pb < npix; pb += nwaves * 4) {
+    for (int64_t pb = wave * PPW; pb < npix; pb += nwaves * PPW) {
         const int64_t p = pb + sub;
         const bool live = p < npix;
         float sxx = 0.f, sgx = 0.f, svx = 0.f, svg = 0.f;
         if (live)
-            for (int c = 4 * l16; c < C; c += 64) {
+            for (int c = 4 * l16; c < C; c += 4 * GL) {
                 const float4 xv = *reinterpret_cast<const float4 *>(x + p * C + c);
                 const float4 gv = *reinterpret_cast<const float4 *>(g + p * C + c);
                 sxx += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
@@ -54,12 +58,12 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float *__restr
                     svg += vv.x * gv.x + vv.y * gv.y + vv.z * gv.z + vv.w * gv.w;
                 }
             }
-        sxx = group16_sum(sxx); sgx = group16_sum(sgx);
-        if (MODE == 2) { svx = group16_sum(svx); svg = group16_sum(svg); }
+        sxx = group_sum<GL>(sxx); sgx = group_sum<GL>(sgx);
+        if (MODE == 2) { svx = group_sum<GL>(svx); svg = group_sum<GL>(svg); }
         const float r = 1.0f / __builtin_sqrtf(sxx * invC + eps);
         const float r3 = r * r * r, s = sgx * invC, t = svx * invC, u = svg * invC;
         if (live)
-            for (int c = 4 * l16; c < C; c += 64) {
+            for (int c = 4 * l16; c < C; c += 4 * GL) {
                 const float4 xv = *reinterpret_cast<const float4 *>(x + p * C + c);
                 const float4 gv = *reinterpret_cast<const float4 *>(g + p * C + c);
                 if (MODE == 1) {
@@ -305,8 +309,11 @@ extern "C" int sq_pixelnorm_bwd_f32(const float *x, const float *dy, float *dx, 
                                     void *stream) {
     SQ_REQUIRE(x && dy && dx && npix > 0 && C > 0 && C % 4 == 0, "sq_pixelnorm_bwd_f32: bad arguments (C %% 4 == 0)");
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(dx);
-    hipLaunchKernelGGL(pixelnorm_bwd_kernel<1>, dim3(grid_for(npix * 16)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr,
-                       dx, nullptr, npix, C, eps, 1.0f);
+    if (C <= 4) hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 1>), dim3(grid_for(npix)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr, dx, nullptr, npix, C, eps, 1.0f);
+    else if (C <= 8) hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 2>), dim3(grid_for(npix * 2)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr, dx, nullptr, npix, C, eps, 1.0f);
+    else if (C <= 16) hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 4>), dim3(grid_for(npix * 4)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr, dx, nullptr, npix, C, eps, 1.0f);
+    else if (C <= 32) hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 8>), dim3(grid_for(npix * 8)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr, dx, nullptr, npix, C, eps, 1.0f);
+    else hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 16>), dim3(grid_for(npix * 16)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr, dx, nullptr, npix, C, eps, 1.0f);
     return sq_check_launch("sq_pixelnorm_bwd_f32");
 }
 
@@ -318,8 +325,11 @@ extern "C" int sq_pixelnorm_bwd_act_f32(const float *x, const float *dy, float *
     SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_pixelnorm_bwd_act_f32: bad activation %d", act);
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(dx);
     const float slope = act == SQ_ACT_LEAKY ? 0.2f : (act == SQ_ACT_RELU ? 0.0f : 1.0f);
-    hipLaunchKernelGGL(pixelnorm_bwd_kernel<1>, dim3(grid_for(npix * 16)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr,
-                       dx, nullptr, npix, C, eps, slope);
+    if (C <= 4) hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 1>), dim3(grid_for(npix)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr, dx, nullptr, npix, C, eps, slope);
+    else if (C <= 8) hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 2>), dim3(grid_for(npix * 2)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr, dx, nullptr, npix, C, eps, slope);
+    else if (C <= 16) hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 4>), dim3(grid_for(npix * 4)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr, dx, nullptr, npix, C, eps, slope);
+    else if (C <= 32) hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 8>), dim3(grid_for(npix * 8)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr, dx, nullptr, npix, C, eps, slope);
+    else hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 16>), dim3(grid_for(npix * 16)), dim3(256), 0, SQ_ST(stream), x, dy, nullptr, dx, nullptr, npix, C, eps, slope);
     return sq_check_launch("sq_pixelnorm_bwd_act_f32");
 }
 
@@ -328,8 +338,11 @@ extern "C" int sq_pixelnorm_bwd2_f32(const float *x, const float *g, const float
     SQ_REQUIRE(x && g && v && dg && dx2 && npix > 0 && C > 0 && C % 4 == 0,
                "sq_pixelnorm_bwd2_f32: bad arguments (C %% 4 == 0)");
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(g); SQ_REQUIRE_ALIGNED(v); SQ_REQUIRE_ALIGNED(dg); SQ_REQUIRE_ALIGNED(dx2);
-    hipLaunchKernelGGL(pixelnorm_bwd_kernel<2>, dim3(grid_for(npix * 16)), dim3(256), 0, SQ_ST(stream), x, g, v, dg,
-                       dx2, npix, C, eps, 1.0f);
+    if (C <= 4) hipLaunchKernelGGL((pixelnorm_bwd_kernel<2, 1>), dim3(grid_for(npix)), dim3(256), 0, SQ_ST(stream), x, g, v, dg, dx2, npix, C, eps, 1.0f);
+    else if (C <= 8) hipLaunchKernelGGL((pixelnorm_bwd_kernel<2, 2>), dim3(grid_for(npix * 2)), dim3(256), 0, SQ_ST(stream), x, g, v, dg, dx2, npix, C, eps, 1.0f);
+    else if (C <= 16) hipLaunchKernelGGL((pixelnorm_bwd_kernel<2, 4>), dim3(grid_for(npix * 4)), dim3(256), 0, SQ_ST(stream), x, g, v, dg, dx2, npix, C, eps, 1.0f);
+    else if (C <= 32) hipLaunchKernelGGL((pixelnorm_bwd_kernel<2, 8>), dim3(grid_for(npix * 8)), dim3(256), 0, SQ_ST(stream), x, g, v, dg, dx2, npix, C, eps, 1.0f);
+    else hipLaunchKernelGGL((pixelnorm_bwd_kernel<2, 16>), dim3(grid_for(npix * 16)), dim3(256), 0, SQ_ST(stream), x, g, v, dg, dx2, npix, C, eps, 1.0f);
     return sq_check_launch("sq_pixelnorm_bwd2_f32");
 }
 

@@ -87,31 +87,37 @@ __global__ __launch_bounds__(256) void argmax_u8_kernel(const float *__restrict_
     }
 }
 
-// pixel_norm: one 16-lane group per pixel (4 pixels per wave); sequential-in-c f32 sum is
+// pixel_norm: one GL-lane group per pixel, GL = the power of two >= C / 4, at most 16 (64 / GL pixels per wave: with
+// 16 lanes per pixel the 8- and 16-channel layers of the GAN, its largest tensors, ran on 2 or 4 lanes in 16);
+// sequential-in-c f32 sum is
 // NOT reproduced lane-parallel, so the sum order is fixed as: each lane sums its own
-// channels c = 4*(lane16) + 64*k + {0..3} in order, then a 4-step xor butterfly.
+// channels c = 4*(lane in group) + 4*GL*k + {0..3} in order, then an xor butterfly over the group (the same value
+// whatever GL: lanes without channels contribute zeros).
 // The oracle comparison for this op is therefore a tolerance (1e-6 rel), not bit-exact.
+template <int GL>
 __global__ __launch_bounds__(256) void pixelnorm_f32_kernel(const float *__restrict__ x,
                                                              float *__restrict__ y, int64_t npix,
                                                              int C, float eps) {
-    const int lane = threadIdx.x & 63, l16 = lane & 15, sub = lane >> 4;
+    constexpr int PPW = 64 / GL;
+    const int lane = threadIdx.x & 63, l16 = lane & (GL - 1), sub = lane / GL;
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
     // wave-uniform trip count: the shuffles below always see a full wave
-    for (int64_t pb = wave * 4; pb < npix; pb += nwaves * 4) {
+    for (int64_t pb = wave * PPW; pb < npix; pb += nwaves * PPW) {
         const int64_t p = pb + sub;
         const bool live = p < npix;
         float s = 0.f;
         if (live)
-            for (int c = 4 * l16; c < C; c += 64) {
+            for (int c = 4 * l16; c < C; c += 4 * GL) {
                 const float4 v = *reinterpret_cast<const float4 *>(x + p * C + c);
                 s = __builtin_fmaf(v.x, v.x, s); s = __builtin_fmaf(v.y, v.y, s);
                 s = __builtin_fmaf(v.z, v.z, s); s = __builtin_fmaf(v.w, v.w, s);
             }
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+#pragma unroll
+        for (int m = 1; m < GL; m <<= 1) s += __shfl_xor(s, m);
         const float r = 1.0f / __builtin_sqrtf(s / (float)C + eps);
         if (live)
-            for (int c = 4 * l16; c < C; c += 64) {
+            for (int c = 4 * l16; c < C; c += 4 * GL) {
                 float4 v = *reinterpret_cast<const float4 *>(x + p * C + c);
                 v.x *= r; v.y *= r; v.z *= r; v.w *= r;
                 *reinterpret_cast<float4 *>(y + p * C + c) = v;
@@ -184,8 +190,12 @@ extern "C" int sq_pixelnorm_fwd_f32(const float *x, float *y, int64_t npix, int 
     SQ_REQUIRE(x && y, "sq_pixelnorm_fwd_f32: null tensor pointer");
     SQ_REQUIRE(npix > 0 && C > 0 && C % 4 == 0, "sq_pixelnorm_fwd_f32: C=%d must be a multiple of 4", C);
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(y);
-    hipLaunchKernelGGL(pixelnorm_f32_kernel, dim3(grid_for(npix * 16)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), x, y, npix, C, eps);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (C <= 4) hipLaunchKernelGGL(pixelnorm_f32_kernel<1>, dim3(grid_for(npix)), dim3(256), 0, st, x, y, npix, C, eps);
+    else if (C <= 8) hipLaunchKernelGGL(pixelnorm_f32_kernel<2>, dim3(grid_for(npix * 2)), dim3(256), 0, st, x, y, npix, C, eps);
+    else if (C <= 16) hipLaunchKernelGGL(pixelnorm_f32_kernel<4>, dim3(grid_for(npix * 4)), dim3(256), 0, st, x, y, npix, C, eps);
+    else if (C <= 32) hipLaunchKernelGGL(pixelnorm_f32_kernel<8>, dim3(grid_for(npix * 8)), dim3(256), 0, st, x, y, npix, C, eps);
+    else hipLaunchKernelGGL(pixelnorm_f32_kernel<16>, dim3(grid_for(npix * 16)), dim3(256), 0, st, x, y, npix, C, eps);
     return sq_check_launch("sq_pixelnorm_fwd_f32");
 }
 
