@@ -38,7 +38,7 @@ def test_host_side_validation_needs_no_gpu():
     assert rc == -1 and b"even" in lib.sq_last_error()
     rc = lib.sq_convT2x2s2_nhwc_fwd_f32(16, 16, None, None, 16, 1, 4, 4, 12, 16, 0, None)
     assert rc == -1 and b"multiple of 16" in lib.sq_last_error()
-    assert lib.sq_wsoftmax_ce_partials(10 ** 9) == 1024 and lib.sq_wsoftmax_ce_partials(100) == 1
+    assert lib.sq_wsoftmax_ce_partials(10 ** 9) == 2048 and lib.sq_wsoftmax_ce_partials(100) == 1
 
 
 def test_no_cpu_fallback():
