@@ -89,125 +89,94 @@ def divisible_by_two_n_times(x, n):
     return x % 1 == 0
 
 
+# the validated fields of the configuration surface (utils.py:281-330): accepted type(s), what a value must satisfy, the
+# error raised for each, and how the value is stored.  Everything else is a plain attribute (utils.py:262-278).
+_RULES = {
+    'name': (str, 'Name is not a string.', lambda v: v in MODELS, 'Net name is not recognized.', None),
+    'dropout': (float, 'Dropout is not a float.', lambda v: 0 <= v <= 1, 'Dropout should be in the (0-1) range.', None),
+    'shape': ((tuple, list), 'Shape is not a tuple.', None, None, tuple),
+    'warm_start': (bool, 'Warm start is not a boolean.', None, None, None),
+}
+# insertion order = the key order of net.config (the reference writes its members in assignment order)
+_DEFAULTS = (('name', 'UNet2D_test'), ('dropout', 0.5), ('warm_start', False), ('shape', (64, 64)), ('num_inputs', 1),
+             ('num_outputs', 2), ('num_epochs', 1000), ('learning_rate', 0.01), ('augment', True), ('path', None),
+             ('training_data', 'train.tfrecord'), ('test_data', 'test.tfrecord'), ('image_dict', None))
+
+
 class NetConfiguration(object):
-    """Generic network configuration (utils.py:247-421)."""
+    """Generic network configuration (utils.py:247-421): a bag of named settings, four of them validated on
+    assignment, written to / read from ``net.config`` as ``{class name: {setting: value}}``.  Schema-driven here
+    (_RULES / _DEFAULTS) instead of one property pair per field; the surface -- attribute names, accepted values,
+    exception types and texts, JSON layout -- is the reference's."""
 
     def __init__(self):
-        self.name = 'UNet2D_test'
-        self.dropout = 0.5
-        self.warm_start = False
-        self.shape = (64, 64)
-        self.num_inputs = 1
-        self.num_outputs = 2
-        self.num_epochs = 1000
-        self.learning_rate = 0.01
-        self.augment = True
-        self.path = None
-        self.training_data = 'train.tfrecord'
-        self.test_data = 'test.tfrecord'
-        self.image_dict = {}
+        for key, value in _DEFAULTS:
+            setattr(self, key, {} if key == 'image_dict' else value)
 
-    @property
-    def name(self):
-        return self._name
+    def __setattr__(self, key, value):
+        rule = _RULES.get(key)
+        if rule is not None:
+            kinds, not_kind, accept, not_accepted, store = rule
+            if not isinstance(value, kinds) or (kinds is float and isinstance(value, bool)):
+                raise TypeError(not_kind)
+            if accept is not None and not accept(value):
+                raise ValueError(not_accepted)
+            if store is not None:
+                value = store(value)
+        object.__setattr__(self, key, value)
 
-    @name.setter
-    def name(self, name):
-        if not isinstance(name, str):
-            raise TypeError('Name is not a string.')
-        if name not in MODELS:
-            raise ValueError('Net name is not recognized.')
-        self._name = name
-
-    @property
-    def dropout(self):
-        return self._dropout
-
-    @dropout.setter
-    def dropout(self, dropout):
-        if not isinstance(dropout, float):
-            raise TypeError('Dropout is not a float.')
-        if dropout < 0 or dropout > 1:
-            raise ValueError('Dropout should be in the (0-1) range.')
-        self._dropout = dropout
-
-    @property
-    def shape(self):
-        return self._shape
-
-    @shape.setter
-    def shape(self, shape):
-        if not isinstance(shape, (tuple, list)):
-            raise TypeError('Shape is not a tuple.')
-        self._shape = tuple(shape)
-
-    @property
-    def warm_start(self):
-        return self._warm_start
-
-    @warm_start.setter
-    def warm_start(self, warm_start):
-        if not isinstance(warm_start, bool):
-            raise TypeError('Warm start is not a boolean.')
-        self._warm_start = warm_start
-
+    # -- locations ---------------------------------------------------------------------------------
     @property
     def export_dir_base(self):
         return os.path.join(core.TensorflowConfiguration.MODELDIR, self.name)
 
-    def warm_start_from(self, model_num=None):
-        if not self.warm_start:
-            return None
-        return get_latest_model_dir(self.export_dir_base)
-
     def get_latest_model_dir(self):
         return get_latest_model_dir(self.export_dir_base)
 
-    @property
-    def training_data_file(self):
-        if isinstance(self.training_data, list):
-            return [os.path.join(self.path, f) for f in self.training_data]
-        return os.path.join(self.path, self.training_data)
+    def warm_start_from(self, model_num=None):
+        return self.get_latest_model_dir() if self.warm_start else None
 
-    @property
-    def testing_data_file(self):
-        if isinstance(self.test_data, list):
-            return [os.path.join(self.path, f) for f in self.test_data]
-        return os.path.join(self.path, self.test_data)
+    def _in_path(self, names):
+        if isinstance(names, list):
+            return [os.path.join(self.path, n) for n in names]
+        return os.path.join(self.path, names)
+
+    training_data_file = property(lambda self: self._in_path(self.training_data))
+    testing_data_file = property(lambda self: self._in_path(self.test_data))
+
+    # -- dict / file round trip (utils.py:362-421) ---------------------------------------------------
+    def update(self, params):
+        for key, value in params.items():
+            setattr(self, key, value)
+        return self
 
     @classmethod
     def from_params(cls, params, preload_model=False):
-        """Instantiate from a parameter dict; preload_model first reads the latest saved
-        net.config, then the dict overrides it (utils.py:362-388)."""
+        """preload_model: the latest saved net.config of params['name'] is read first, then params override it."""
         if not isinstance(params, dict):
             raise TypeError('Parameters are not specified in dictionary.')
         config = cls()
         if preload_model:
             config.name = params['name']
             config.load()
-        for p in params:
-            setattr(config, p, params[p])
-        return config
+        return config.update(params)
 
     def to_params(self):
-        """ {member name without leading underscore: value} (utils.py:390-395) """
-        return {m.lstrip('_'): getattr(self, m.lstrip('_')) for m in self.__dict__.keys()}
+        return dict(vars(self))
 
     def save(self, filename):
-        export = {str(self.__class__.__name__): self.to_params()}
         with open(filename, 'w') as f:
-            f.write(json.dumps(export, indent=2, separators=(',', ': ')))
+            json.dump({type(self).__name__: self.to_params()}, f, indent=2, separators=(',', ': '))
 
     def load(self, filename='net.config'):
         model_dir = self.get_latest_model_dir()
-        model_fn = os.path.join(model_dir or '', filename)
-        if model_dir is None or not os.path.exists(model_fn):
-            raise IOError('Cannot preload config: {0:s}'.format(model_fn))
-        with open(model_fn, 'r') as f:
-            params = json.load(f)[str(self.__class__.__name__)]
-        logger.info('Loading model parameters from: {0:s}'.format(model_fn))
-        for p in params:
-            setattr(self, p, params[p])
+        source = os.path.join(model_dir or '', filename)
+        if model_dir is None or not os.path.exists(source):
+            raise IOError('Cannot preload config: {0:s}'.format(source))
+        with open(source, 'r') as f:
+            stored = json.load(f)[type(self).__name__]
+        logger.info('Loading model parameters from: {0:s}'.format(source))
+        self.update(stored)
 
 
 WEIGHTS_FILE = 'weights.npz'
