@@ -16,62 +16,48 @@ __version__ = '0.1.7'                                          # reference versi
 DEFAULT_LOGGER_PROCESSES = ('server_process', 'worker_process')
 
 
-class ServerConfiguration:
-    """ A server config (core.py:34-46) """
-    VERSION = __version__
-    LOGDIR = ''
-    JOBDIR = ''
-    OUTDIR = ''
-    SERVER_IP = ''
-    DEFAULT_GPUS = [0, 1, 2, 3, 4, 5, 6, 7]
-    MAX_PROCESSES = 8
-    DELAY = 60
-    LOCAL = True
-    VERBOSE_LOG = True
-    CORES = 0
-    CPUS = []
-    GPUS = []
+def _settings(name, doc, **defaults):
+    """A namespace class of upper-case settings: read as ``Name.SETTING`` everywhere, overwritten by _configure()."""
+    return type(name, (object,), dict(defaults, __doc__=doc))
 
 
-class TensorflowConfiguration:
-    """ Back-end config; name kept for job/config-file compatibility (core.py:48-54) """
-    TF_LOG_LEVEL = '3'
-    LOGDIR = ''
-    MODELDIR = ''
-    LOG_DEVICE_PLACEMENT = True
-    ALLOW_GROWTH = True
+# the settings and their defaults (core.py:34-54); DEFAULT_GPUS / MAX_PROCESSES sized for one 8-GPU MI355X node
+ServerConfiguration = _settings(
+    'ServerConfiguration', 'server side: folders, address, worker slots (core.py:34-46)',
+    VERSION=__version__, LOGDIR='', JOBDIR='', OUTDIR='', SERVER_IP='', DEFAULT_GPUS=list(range(8)), MAX_PROCESSES=8,
+    DELAY=60, LOCAL=True, VERBOSE_LOG=True, CORES=0, CPUS=[], GPUS=[])
+TensorflowConfiguration = _settings(
+    'TensorflowConfiguration', 'back end; the name is kept for job / config-file compatibility (core.py:48-54)',
+    TF_LOG_LEVEL='3', LOGDIR='', MODELDIR='', LOG_DEVICE_PLACEMENT=True, ALLOW_GROWTH=True)
+
+_SECTIONS = {'config': ServerConfiguration, 'tensorflow': TensorflowConfiguration}
 
 
-BOOL_OPTS = ('LOCAL', 'VERBOSE_LOG', 'LOG_DEVICE_PLACEMENT', 'ALLOW_GROWTH')
-INT_OPTS = ('MAX_PROCESSES', 'DELAY', 'CORES')
-LIST_OPTS = ('DEFAULT_GPUS',)
-
-
-def _get_config_opt_correct_type(config, section, opt):
-    """ Return correctly typed configuration info (core.py:90-106) """
-    if opt.upper() in BOOL_OPTS:
-        return config.getboolean(section, opt)
-    if opt.upper() in INT_OPTS:
-        return config.getint(section, opt)
-    if opt.upper() in LIST_OPTS:
-        return literal_eval(config.get(section, opt))
-    return config.get(section, opt)
+def _typed(parser, section, option, default):
+    """The option parsed as the type of the setting's default (the reference keeps name lists per type,
+    core.py:90-106: same result for every setting it lists); unknown settings stay strings."""
+    if isinstance(default, bool):
+        return parser.getboolean(section, option)
+    if isinstance(default, int):
+        return parser.getint(section, option)
+    if isinstance(default, (list, tuple)):
+        return literal_eval(parser.get(section, option))
+    return parser.get(section, option)
 
 
 def _configure(config_file='server.config'):
-    """ Configure the package from a config file; returns the version, or None if absent """
+    """Apply an INI file to the settings above (core.py:57-87); returns the version, or None when there is no file."""
     if not os.path.exists(config_file):
         return None
-    config = configparser.ConfigParser()
-    config.read(config_file)
-    for section, target in (('config', ServerConfiguration), ('tensorflow', TensorflowConfiguration)):
-        if config.has_section(section):
-            for opt in config.options(section):
-                setattr(target, opt.upper(), _get_config_opt_correct_type(config, section, opt))
-    ServerConfiguration.CPUS = [config.get('cpu', c) for c in config.options('cpu')] \
-        if config.has_section('cpu') else []
-    ServerConfiguration.GPUS = [config.get('gpu', g) for g in config.options('gpu')] \
-        if config.has_section('gpu') else []
+    parser = configparser.ConfigParser()
+    parser.read(config_file)
+    for section, target in _SECTIONS.items():
+        for option in (parser.options(section) if parser.has_section(section) else ()):
+            key = option.upper()
+            setattr(target, key, _typed(parser, section, option, getattr(target, key, '')))
+    for section, key in (('cpu', 'CPUS'), ('gpu', 'GPUS')):     # device lists: one entry per line of the section
+        names = parser.options(section) if parser.has_section(section) else ()
+        setattr(ServerConfiguration, key, [parser.get(section, n) for n in names])
     return ServerConfiguration.VERSION
 
 
