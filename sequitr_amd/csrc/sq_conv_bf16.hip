@@ -284,6 +284,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
             bvr[nb] = (bias && co < Cout) ? *reinterpret_cast<const float4 *>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    // 1x1 form with a gate (the transpose conv's dgrad): the tile's gate values are requested BEFORE its last chunk is
+    // multiplied and have landed by the vmcnt(0) that precedes the commit -- the epilogue used to request them itself
+    // and wait, a third exposed HBM round trip per tile of a kernel whose tiles are two short chunks
+    constexpr bool GATE_EARLY = KS == 1 && !F32IO && !JN;
+    bf16x4 gpre[GATE_EARLY ? NR : 1][4];
+    auto gate_fetch = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int gx = tx * TW + li;
+#pragma unroll
+        for (int nb = 0; nb < NR; ++nb) {
+            const int co = n0 + nb * 16 + 4 * kg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gy = ty * TH + 4 * wv + r;
+                const bool ok = gy < H && gx < W && co < Cout;
+                gpre[nb][r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(
+                    grsrc, ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 2) : OOB, 0, 0));
+            }
+        }
+    };
     auto epilogue = [&](int tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int gx = tx * TW + li;
@@ -385,7 +405,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                 }
                 continue;
             }
-            if (gate) {
+            if constexpr (GATE_EARLY) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[r] = gpre[nb][r];
+            } else if (gate) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     gv[r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(grsrc, offs[r], 0, 0));
@@ -429,6 +452,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         if (nchk == nchunk) { nchk = 0; ntile = tile + 1; }
         const bool has_next = it + 1 < nitems;
         if (has_next) issue(ntile, nchk, restage_w);
+        if constexpr (GATE_EARLY) {
+            if (gate && chunk == nchunk - 1) gate_fetch(tile);
+        }
         __builtin_amdgcn_s_setprio(0);                          // see sq_conv_f32_v2.hip: low priority while only feeding MFMA
 #pragma unroll
         for (int s = 0; s < C::NSTEP; ++s) {
