@@ -187,6 +187,12 @@ int sq_adam_step_dev_f32(float *p, const float *g, float *m, float *v, int64_t n
 int sq_adam_advance_dev(int32_t *state, float lr, float beta1, float beta2, void *stream);
 int sq_adam_apply_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float beta1, float beta2,
                           float eps, const int32_t *state, float grad_scale, void *stream);
+/* the same apply over a list of tensors in ONE launch: table (device memory, 8-byte aligned) = n_entries x
+ * {p, g, m, v, element count, first chunk} as 64-bit words, chunks of sq_adam_multi_chunk() elements numbered across
+ * the entries, total_chunks of them; element for element the update of sq_adam_apply_dev_f32 */
+int sq_adam_multi_chunk(void);
+int sq_adam_apply_multi_dev_f32(const void *table, int n_entries, int64_t total_chunks, float beta1, float beta2, float eps,
+                                const int32_t *state, float grad_scale, void *stream);
 
 /* conv_transpose_layer with a 3x3 kernel (SURVEY.md A.1 `up_kernel` = (3,3); hook at
  * sequitr/networks/unet.py:336-338): TF's conv2d_transpose(k=3, s=2, SAME) equals a SAME 3x3

@@ -318,18 +318,48 @@ __global__ void adam_prepare_kernel(int *__restrict__ state, float lr, float b1,
     }
 }
 
+__device__ __forceinline__ void adam_update(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                            float *__restrict__ v, int64_t i, float lr_t, float b1, float b2, float eps,
+                                            float gscale) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (__builtin_sqrtf(vi) + eps);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                     float *__restrict__ m, float *__restrict__ v, int64_t n,
                                                     float lr_t_host, const int *__restrict__ state, float b1, float b2,
                                                     float eps, float gscale) {
     const float lr_t = state ? reinterpret_cast<const float *>(state)[1] : lr_t_host;
-    SQ_GRID_STRIDE(i, n) {
-        const float gi = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] = p[i] - lr_t * mi / (__builtin_sqrtf(vi) + eps);
+    SQ_GRID_STRIDE(i, n) adam_update(p, g, m, v, i, lr_t, b1, b2, eps, gscale);
+}
+
+// the same update over a LIST of tensors in one launch (the GAN's per-variable optimiser: ~30 tensors per solver, most of
+// them a few thousand elements, a few of them millions): table = n_entries x {p, g, m, v, count, first chunk} as 64-bit
+// words in device memory; the work is cut into chunks of ADAM_CHUNK elements numbered across the entries, one block
+// per chunk, the block finds its entry by bisection on the first-chunk column
+constexpr int ADAM_CHUNK = 2048;
+__global__ __launch_bounds__(256) void adam_multi_kernel(const int64_t *__restrict__ table, int n_entries,
+                                                          const int *__restrict__ state, float b1, float b2, float eps,
+                                                          float gscale) {
+    int lo = 0, hi = n_entries - 1;                            // last entry whose first chunk <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(size_t)mid * 6 + 5] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t *e = table + (size_t)lo * 6;
+    float *p = reinterpret_cast<float *>(e[0]);
+    const float *g = reinterpret_cast<const float *>(e[1]);
+    float *m = reinterpret_cast<float *>(e[2]), *v = reinterpret_cast<float *>(e[3]);
+    const int64_t n = e[4], base = ((int64_t)blockIdx.x - e[5]) * ADAM_CHUNK;
+    const float lr_t = reinterpret_cast<const float *>(state)[1];
+#pragma unroll
+    for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i < n) adam_update(p, g, m, v, i, lr_t, b1, b2, eps, gscale);
     }
 }
 
@@ -555,6 +585,21 @@ extern "C" int sq_adam_apply_dev_f32(float *p, const float *g, float *m, float *
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), p, g, m, v, n, 0.f, state, beta1,
                        beta2, eps, grad_scale);
     return sq_check_launch("sq_adam_apply_dev_f32");
+}
+
+extern "C" int sq_adam_multi_chunk(void) { return ADAM_CHUNK; }
+
+// one launch for a list of tensors: table (device memory) = n_entries x {p, g, m, v, element count, first chunk}, six 64-bit
+// words each; first chunk = sum over the earlier entries of ceil(count / sq_adam_multi_chunk()); total_chunks = that sum
+// over all entries
+extern "C" int sq_adam_apply_multi_dev_f32(const void *table, int n_entries, int64_t total_chunks, float beta1, float beta2,
+                                           float eps, const int32_t *state, float grad_scale, void *stream) {
+    SQ_REQUIRE(table && state && n_entries > 0 && total_chunks > 0 && total_chunks < ((int64_t)1 << 31),
+               "sq_adam_apply_multi_dev_f32: bad arguments");
+    SQ_REQUIRE((((uintptr_t)table) & 7u) == 0, "sq_adam_apply_multi_dev_f32: table must be 8-byte aligned");
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, SQ_ST(stream),
+                       reinterpret_cast<const int64_t *>(table), n_entries, state, beta1, beta2, eps, grad_scale);
+    return sq_check_launch("sq_adam_apply_multi_dev_f32");
 }
 
 extern "C" int sq_adam_step_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,

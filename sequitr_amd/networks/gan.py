@@ -192,17 +192,35 @@ class _Adam(object):
         self.state = None           # int32[2] {step, lr_t bits} on the device: a captured step replays correctly
         self.slots = {}
 
-    def apply(self, named_vars, grads, grad_scale=1.0):
+    def _live(self, named_vars, grads):
         live = [(name, v, g) for (name, v), g in zip(named_vars, grads) if g is not None]
+        for name, v, _ in live:
+            if name not in self.slots:
+                self.slots[name] = (torch.zeros_like(v), torch.zeros_like(v))
+        if live and self.state is None:
+            self.state = torch.zeros(2, dtype=torch.int32, device=live[0][1].device)
+        return live
+
+    def table(self, named_vars, grads):
+        """Pointer table for apply(..., table=): every live variable's {weights, gradient, slots} in device memory, so
+        that a minimize() is two launches (advance + one update over the list).  The gradients must be the static
+        tensors of a captured gradient graph (the table holds their addresses); None if one is not contiguous."""
+        live = self._live(named_vars, grads)
+        if not live or not all(g.is_contiguous() and v.is_contiguous() for _, v, g in live):
+            return None
+        return ops.adam_table([v.detach().view(-1) for _, v, _ in live], [g.view(-1) for _, _, g in live],
+                              [self.slots[n][0].view(-1) for n, _, _ in live], [self.slots[n][1].view(-1) for n, _, _ in live])
+
+    def apply(self, named_vars, grads, grad_scale=1.0, table=None):
+        live = self._live(named_vars, grads)
         if not live:
             return
         self.t += 1
-        if self.state is None:
-            self.state = torch.zeros(2, dtype=torch.int32, device=live[0][1].device)
         ops.adam_advance_dev(self.state, self.lr, self.b1, self.b2)       # ONE shared beta-power step per minimize()
+        if table is not None:
+            ops.adam_apply_multi_dev(table, self.b1, self.b2, self.eps, self.state, grad_scale=grad_scale)
+            return
         for name, v, g in live:
-            if name not in self.slots:
-                self.slots[name] = (torch.zeros_like(v), torch.zeros_like(v))
             m, s = self.slots[name]
             ops.adam_apply_dev(v.detach().view(-1), g.contiguous().view(-1), m.view(-1), s.view(-1), self.b1, self.b2,
                                self.eps, self.state, grad_scale=grad_scale)
@@ -520,11 +538,13 @@ class GenerativeAdverserialNetwork(object):
             with torch.cuda.graph(g_grad, stream=self._capture_stream):
                 named, grads, losses = self._d_grads(sx, sz, sa, sr) if kind == 'd' else self._g_grads(sx, sz, sa)
             t_host = opt.t
+            table = opt.table(named, grads)                     # addresses of the static gradients: one update launch
+            torch.cuda.synchronize(self.device)
             with torch.cuda.graph(g_adam, stream=self._capture_stream):
-                opt.apply(named, grads, grad_scale=1.0 / self._world())
+                opt.apply(named, grads, grad_scale=1.0 / self._world(), table=table)
             opt.t = t_host                                      # the capture executed nothing
-            entry = self._graphs[key] = (g_grad, g_adam, sx, sz, sa, sr, grads, losses)
-        g_grad, g_adam, sx, sz, sa, sr, grads, losses = entry
+            entry = self._graphs[key] = (g_grad, g_adam, sx, sz, sa, sr, grads, losses, table)
+        g_grad, g_adam, sx, sz, sa, sr, grads, losses = entry[:8]     # entry[8]: the Adam table the graph reads
         sx.copy_(X), sz.copy_(Z), sa.fill_(float(alpha))
         if sr is not None:
             sr.copy_(self._mixing_r(X.shape[0]))

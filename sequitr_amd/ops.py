@@ -941,6 +941,31 @@ def adam_apply_dev(p, g, m, v, beta1, beta2, eps, state, grad_scale=1.0):
     invalidate_packs()
 
 
+def adam_table(params, grads, ms, vs):
+    """Device table for adam_apply_multi_dev: one row {p, g, m, v, count, first chunk} per tensor.  Built on the host and
+    uploaded (a synchronous copy: call it outside any stream capture); the tensors must stay where they are."""
+    rows, chunk, first = [], _lib.load().sq_adam_multi_chunk(), 0
+    for p, g, m, v in zip(params, grads, ms, vs):
+        for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+            _chk(t, n)
+        if not (p.numel() == g.numel() == m.numel() == v.numel()):
+            raise ValueError("adam_table: tensor sizes differ")
+        rows.append([p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), first])
+        first += (p.numel() + chunk - 1) // chunk
+    table = torch.tensor(rows, dtype=torch.int64).to(params[0].device)
+    table._sq_chunks = first
+    return table
+
+
+def adam_apply_multi_dev(table, beta1, beta2, eps, state, grad_scale=1.0):
+    """adam_apply_dev over every row of an adam_table() in one launch."""
+    _chk(table, "table", dtype=torch.int64), _chk(state, "state", dtype=torch.int32)
+    _lib.check(_lib.load().sq_adam_apply_multi_dev_f32(_ptr(table), int(table.shape[0]), int(table._sq_chunks), float(beta1),
+                                                      float(beta2), float(eps), _ptr(state), float(grad_scale), _stream()),
+               "sq_adam_apply_multi_dev_f32")
+    invalidate_packs()
+
+
 # ----------------------------------------------------------------------------------------------
 # batch normalisation (include/sequitr_hip.h "Batch normalisation"; SURVEY.md A.1 `batch_norm`)
 # ----------------------------------------------------------------------------------------------

@@ -249,6 +249,31 @@ def test_adam_dev_matches_host_step():
     assert int(st[0].item()) == 5 and torch.equal(pa, pb)
 
 
+def test_adam_over_a_tensor_list_equals_one_launch_per_tensor():
+    """sq_adam_apply_multi_dev_f32 (pointer table, one launch) == sq_adam_apply_dev_f32 per tensor, bit for bit."""
+    from sequitr_amd import ops
+    rng = np.random.default_rng(1)
+    sizes = [7, 4096, 12, 100003, 512]
+    ps = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+    gs = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+    pa, pb = [dev(a) for a in ps], [dev(a) for a in ps]
+    ga = [dev(a) for a in gs]
+    sa = [(torch.zeros(n, device="cuda:0"), torch.zeros(n, device="cuda:0")) for n in sizes]
+    sb = [(torch.zeros(n, device="cuda:0"), torch.zeros(n, device="cuda:0")) for n in sizes]
+    sta, stb = torch.zeros(2, dtype=torch.int32, device="cuda:0"), torch.zeros(2, dtype=torch.int32, device="cuda:0")
+    table = ops.adam_table(pb, ga, [m for m, _ in sb], [v for _, v in sb])
+    for _ in range(3):
+        ops.adam_advance_dev(sta, 1e-3, 0.0, 0.99)
+        for p, g, (m, v) in zip(pa, ga, sa):
+            ops.adam_apply_dev(p, g, m, v, 0.0, 0.99, 1e-8, sta, grad_scale=0.5)
+        ops.adam_advance_dev(stb, 1e-3, 0.0, 0.99)
+        ops.adam_apply_multi_dev(table, 0.0, 0.99, 1e-8, stb, grad_scale=0.5)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    for (ma, va), (mb, vb) in zip(sa, sb):
+        assert torch.equal(ma, mb) and torch.equal(va, vb)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_direct_gradient_sinks_equal_autograd_accumulation(dtype):
     """UNetTrainer(direct_grads=True): the gradient kernels write the flat bucket themselves (no
