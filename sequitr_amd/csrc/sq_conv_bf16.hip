@@ -110,7 +110,13 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
     __shared__ int tb[128 * 8];
     for (int i = threadIdx.x; i < n_entries * 8; i += 256) tb[i] = table[i];
     __syncthreads();
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    // a thread makes 8 consecutive packed elements (one 16-byte store; entries start and end on multiples of 8: KP is a
+    // multiple of 32, channel counts of 8).  Which of (k-group, co) runs along the lanes follows the SOURCE layout:
+    // forward packs read (tap, c, co) with co contiguous -> co along the lanes (each of the 8 loads is a coalesced row);
+    // dgrad packs read (tap, co, c) with c contiguous -> the k-group along the lanes (32 contiguous source bytes each).
+    // With one element per thread and k along the lanes, a forward pack read one float per 128-byte line.
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < total / 8; u += gridDim.x * 256) {
+        const int i = u * 8;
         int lo = 0, hi = n_entries - 1;                        // last entry whose first item <= i
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -120,24 +126,38 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
         const float *w = base + e[0];
         __bf16 *wp = out + e[1];
         const int K = e[2], Cin = e[3], Cout = e[4], transform = e[5], j = i - e[6];
+        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+        bf16x8_t o;
         if (e[7] == 1) {
-            wp[j] = (__bf16)w[j];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] = (__bf16)w[j + t];
+            *reinterpret_cast<bf16x8_t *>(wp + j) = o;
             continue;
         }
-        const int KC = Cin % 32 == 0 ? 32 : (Cin % 16 == 0 ? 16 : 8), KP = kp_for(K, KC);
-        const int k = j % KP, co = (j / KP) % Cout, chunk = j / (KP * Cout);
-        float v = 0.f;
-        if (k < K * K * KC) {
-            const int tap = k / KC, c = chunk * KC + k % KC;
-            if (!transform) {
-                v = w[((size_t)tap * Cin + c) * Cout + co];
-            } else {
-                const int ky = tap / K, kx = tap % K;
-                v = w[((size_t)((K - 1 - ky) * K + (K - 1 - kx)) * Cout + co) * Cin + c];
+        const int KC = Cin % 32 == 0 ? 32 : (Cin % 16 == 0 ? 16 : 8), KP = kp_for(K, KC), KG = KP / 8;
+        const int q = j / 8;
+        int kg, co;
+        if (transform) { kg = q % KG; co = (q / KG) % Cout; }
+        else { co = q % Cout; kg = (q / Cout) % KG; }
+        const int chunk = q / (KG * Cout), k0 = kg * 8;
+        const float sc = scales ? scales[lo] : 1.0f;           // the equalised-LR factor, as pack_weights_bf16_kernel
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int k = k0 + t;
+            float v = 0.f;
+            if (k < K * K * KC) {
+                const int tap = k / KC, c = chunk * KC + k % KC;
+                if (!transform) {
+                    v = w[((size_t)tap * Cin + c) * Cout + co];
+                } else {
+                    const int ky = tap / K, kx = tap % K;
+                    v = w[((size_t)((K - 1 - ky) * K + (K - 1 - kx)) * Cout + co) * Cin + c];
+                }
             }
+            if (scales) v *= sc;
+            o[t] = (__bf16)v;
         }
-        if (scales) v *= scales[lo];                           // the equalised-LR factor, as pack_weights_bf16_kernel
-        wp[j] = (__bf16)v;
+        *reinterpret_cast<bf16x8_t *>(wp + ((size_t)chunk * Cout + co) * KP + k0) = o;
     }
 }
 
@@ -638,7 +658,9 @@ extern "C" int sq_conv_pack_weights_multi_bf16(const float *base, void *out, con
                                                int total_items, void *stream) {
     SQ_REQUIRE(base && out && table && n_entries > 0 && n_entries <= 128 && total_items > 0,
                "sq_conv_pack_weights_multi_bf16: bad arguments (at most 128 entries)");
-    int nb = (total_items + 255) / 256;
+    SQ_REQUIRE(total_items % 8 == 0 && (((uintptr_t)out) & 15u) == 0,
+               "sq_conv_pack_weights_multi_bf16: every entry must hold a multiple of 8 elements, out 16-byte aligned");
+    int nb = (total_items / 8 + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(pack_weights_multi_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        base, reinterpret_cast<__bf16 *>(out), table, n_entries, total_items, (const float *)nullptr);
@@ -651,7 +673,9 @@ extern "C" int sq_conv_pack_weights_multi_scaled_bf16(const float *base, void *o
                                                       const float *scales, int n_entries, int total_items, void *stream) {
     SQ_REQUIRE(base && out && table && scales && n_entries > 0 && n_entries <= 128 && total_items > 0,
                "sq_conv_pack_weights_multi_scaled_bf16: bad arguments (at most 128 entries)");
-    int nb = (total_items + 255) / 256;
+    SQ_REQUIRE(total_items % 8 == 0 && (((uintptr_t)out) & 15u) == 0,
+               "sq_conv_pack_weights_multi_scaled_bf16: every entry must hold a multiple of 8 elements, out 16-byte aligned");
+    int nb = (total_items / 8 + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(pack_weights_multi_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        base, reinterpret_cast<__bf16 *>(out), table, n_entries, total_items, scales);

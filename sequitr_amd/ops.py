@@ -151,6 +151,8 @@ class FilterPackPlan(object):
                 n = lib.sq_conv_packed_weights_elems_bf16(K, ci, co)
                 if n <= 0:
                     continue
+                if n % 8:                                       # the pack kernel writes 8 elements (16 bytes) per thread
+                    raise _lib.SequitrHipError("FilterPackPlan: %d elements in a pack (multiple of 8 needed)" % n)
                 rows.append([off, dst, K, ci, co, transform, item, 0])
                 scales.append(float(wscale))
                 self.views[(id(leaf), bool(transform))] = (dst, n, float(wscale), K, ci, co)

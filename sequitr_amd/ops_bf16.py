@@ -178,6 +178,8 @@ class PackPlan(object):
 
         def add(src, K, ci, co, transform, kind, count):
             nonlocal dst, item
+            if count % 8:                                       # the pack kernel writes 8 elements (16 bytes) per thread
+                raise _lib.SequitrHipError("PackPlan: %d elements in a pack (multiple of 8 needed)" % count)
             rows.append([src, dst, K, ci, co, transform, item, kind])
             view = (dst, count)
             dst += (count + 7) // 8 * 8                         # keep every pack 16-byte aligned
