@@ -19,6 +19,16 @@
 #include "sq_common.h"
 #include <stdlib.h>
 
+#ifndef SQ_WGRAD_OCC1_ABOVE
+#define SQ_WGRAD_OCC1_ABOVE 18      // accumulator blocks above which a shape is built for one block per CU
+#endif
+#ifndef SQ_WG_ABLATE
+#define SQ_WG_ABLATE 0              // experiments only: 1 = no MFMA (reads kept), 2 = no LDS reads (MFMA kept), 3 = no commit writes
+#endif
+#ifndef SQ_WGRAD_BUDGET2
+#define SQ_WGRAD_BUDGET2 200        // register budget (2 blocks per CU) the prefetch depth is sized for
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -57,7 +67,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char *p0, const unsigne
 // kernel; the accumulators (NTAP x NI x NO MFMA blocks) are what limits NI, NO.
 // blocks per CU the register budget is sized for: the 36-accumulator-block shapes take the whole file
 template <int KS, int NI, int NO>
-constexpr int wgrad_occ() { return KS * KS * NI * NO > 18 ? 1 : 2; }
+constexpr int wgrad_occ() { return KS * KS * NI * NO > SQ_WGRAD_OCC1_ABOVE ? 1 : 2; }
 
 __device__ __forceinline__ uint4 f32x8_to_bf16x8(const uint4 &a, const uint4 &b) {
     const float4 lo = __builtin_bit_cast(float4, a), hi = __builtin_bit_cast(float4, b);
@@ -142,7 +152,11 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
             const int idx = tid + sl * 256, pix = idx / (2 * NI), rem = idx % (2 * NI);
+#if SQ_WG_ABLATE == 3
+            if (idx < C::XITEMS && xr[sl][0].x == 0x12345678u)
+#else
             if (idx < C::XITEMS)
+#endif
                 *reinterpret_cast<uint4 *>(xs + (rem >> 1) * C::XPLANE + pix * PSB + (rem & 1) * 16) = item(xr[sl]);
         }
 #pragma unroll
@@ -193,7 +207,11 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
                 bf16x8 b[NO];
 #pragma unroll
                 for (int o = 0; o < NO; ++o) {
+#if SQ_WG_ABLATE == 2
+                    b[o] = ones;
+#else
                     b[o] = tr_frag(yk + o * C::YPLANE, yk + o * C::YPLANE + 8 * PSB);
+#endif
                     // db on the matrix pipe: a row of ones times the dY fragment (16 conversions + adds on the VALU before)
                     bacc[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[o], bacc[o], 0, 0, 0);
                 }
@@ -202,10 +220,20 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
                     const unsigned char *xk = xa + ((2 * ks + t / KS) * C::HALO_W + t % KS) * PSB;
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
+#if SQ_WG_ABLATE == 2
+                        const bf16x8 a = ones;
+                        (void)xk;
+#else
                         const bf16x8 a = tr_frag(xk + i * C::XPLANE, xk + i * C::XPLANE + 8 * PSB);
+#endif
 #pragma unroll
-                        for (int o = 0; o < NO; ++o)
+                        for (int o = 0; o < NO; ++o) {
+#if SQ_WG_ABLATE == 1
+                            acc[t][i][o][0] += (float)a[0] + (float)a[7] + (float)b[o][3];
+#else
                             acc[t][i][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[o], acc[t][i][o], 0, 0, 0);
+#endif
+                        }
                     }
                 }
             }
@@ -346,7 +374,7 @@ int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, 
     static bool attr_set = false;
     // prefetch depth: as deep as the accumulators leave registers for (f32 tensors: twice the registers per set)
     constexpr int acc_regs = C::NTAP * NI * NO * 4, set_regs = (C::XSLOTS + C::YSLOTS) * 4 * (int)(sizeof(TIO) / 2);
-    constexpr int budget = (wgrad_occ<KS, NI, NO>() == 1 ? 300 : 200) - acc_regs - 40;
+    constexpr int budget = (wgrad_occ<KS, NI, NO>() == 1 ? 300 : SQ_WGRAD_BUDGET2) - acc_regs - 40;
     constexpr int PF = budget / set_regs >= 4 ? 4 : (budget / set_regs >= 3 ? 3 : (budget / set_regs >= 2 ? 2 : 1));
     auto kern = conv_wgrad_bf16_kernel<KS, NI, NO, PF, TIO>;
     if (!attr_set) {
