@@ -438,6 +438,11 @@ int sq_act_dropout_bwd_bf16(const void *dy, const uint8_t *mask, const void *y, 
 int sq_conv2d_nhwc_fwd_dropout_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H, int W,
                                     int Cin, int Cout, int K, int act, float rate, uint32_t seed,
                                     const int32_t *step_dev, void *stream);
+/* ... and the 2x2/s2 max pool of the result beside it (ypool (N,H/2,W/2,Cout); K = 3, H and W even; rate 0 = no dropout):
+ * conv_block -> max_pool of an encoder level (unet.py:241-243, 265-277) in one kernel; ypool = sq_maxpool2x2_fwd_bf16(y) */
+int sq_conv2d_nhwc_fwd_dropout_pool_bf16(const void *x, const void *wp, const float *bias, void *y, void *ypool, int N, int H,
+                                         int W, int Cin, int Cout, int K, int act, float rate, uint32_t seed,
+                                         const int32_t *step_dev, void *stream);
 int sq_relu_scale_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, float scale, void *stream);
 /* dX of a convolution whose input was the ReLU output `gate` (same shape as dx): sq_conv2d_nhwc_fwd_bf16 of dy
  * with the transposed packed filter, passed only where gate > 0 (the upstream ReLU backward fused in) */

@@ -49,6 +49,9 @@ struct SqDropEpi {
     const __bf16 *j_up = nullptr, *j_skip = nullptr;
     __bf16 *j_g = nullptr, *j_dskip = nullptr;
     int j_bridge = 0;
+    // 2x2/s2 max pool of the block output in the same epilogue (pool != NULL; H, W even): the pooled tensor
+    // (N,H/2,W/2,Cout) the next encoder level reads is written beside y, what sq_maxpool2x2_fwd_bf16 computes from y
+    __bf16 *pool = nullptr;
 };
 
 template <int BN, int KS, int KC>
@@ -161,7 +164,8 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
     }
 }
 
-template <int BN, int KS, int KC, typename TIO, bool JN = false>    // JN: decoder-junction epilogue (SqDropEpi::j_*)
+// JN: decoder-junction epilogue (SqDropEpi::j_*); PL: max-pooled copy of the output (SqDropEpi::pool)
+template <int BN, int KS, int KC, typename TIO, bool JN = false, bool PL = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const TIO *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
     TIO *__restrict__ y, int N, int H, int W, int Cin, int Cout, int act, int tiles_x, int tiles_y,
@@ -195,6 +199,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16 *>(gate), 0, gate ? (int)((size_t)N * H * W * Cout * 2) : 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+        drop.pool, 0, (PL && drop.pool) ? (int)((size_t)N * (H >> 1) * (W >> 1) * Cout * 2) : 0, 0x00020000);
 
     uint4 xr[C::XSLOTS][XV], wr[C::WSLOTS];
     int xrel[C::XSLOTS], xpy[C::XSLOTS], xpx[C::XSLOTS];
@@ -405,6 +411,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
             else if (bias && co < Cout) bv = *reinterpret_cast<const float4 *>(bias + co);
             unsigned offs[4];
             bf16x4 gv[4];
+            bf16x4 pprev = {};
+            (void)pprev;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gy = ty * TH + 4 * wv + r;
@@ -457,6 +465,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                 const unsigned off = offs[r];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
                     __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, o), yrsrc, off, 0, 0);
+                if constexpr (PL) {
+                    // rows 4 wv + {0,1} and {2,3} are the two pool rows of this wave; the horizontal partner is the
+                    // neighbouring lane (li ^ 1).  Every lane runs the exchange; even lanes of valid pixels store.
+                    if ((r & 1) == 0) {
+                        pprev = o;
+                    } else {
+                        bf16x4 m;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) m[j] = (float)pprev[j] > (float)o[j] ? pprev[j] : o[j];
+                        const uint2 mv = __builtin_bit_cast(uint2, m);
+                        uint2 pv;
+                        pv.x = (unsigned)__shfl_xor((int)mv.x, 1);
+                        pv.y = (unsigned)__shfl_xor((int)mv.y, 1);
+                        const bf16x4 pp = __builtin_bit_cast(bf16x4, pv);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) m[j] = (float)pp[j] > (float)m[j] ? pp[j] : m[j];
+                        const int gy = ty * TH + 4 * wv + r;
+                        const unsigned poff = (off != OOB && !(li & 1))
+                            ? (unsigned)((((n * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * Cout + co) * 2) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
+                            __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, m), prsrc, poff, 0, 0);
+                    }
+                }
                 acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -559,17 +590,19 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
     }
 }
 
-template <int BN, int KS, int KC, typename TIO, bool JN = false>
+template <int BN, int KS, int KC, typename TIO, bool JN = false, bool PL = false>
 int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int H, int W, int Cin, int Cout,
            int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
-    if constexpr (!JN && KS == 3 && sizeof(TIO) == 2) {         // the junction form is its own instantiation, so
-        if (drop.j_g)                                           // that the plain kernels keep their register budget
-            return launch<BN, KS, KC, TIO, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    if constexpr (!JN && !PL && KS == 3 && sizeof(TIO) == 2) {  // the junction / pool forms are their own instantiations,
+        if (drop.j_g)                                           // so that the plain kernels keep their register budget
+            return launch<BN, KS, KC, TIO, true, false>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+        if (drop.pool)
+            return launch<BN, KS, KC, TIO, false, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
     }
     using C = CfgB<BN, KS, KC>;
     static bool attr_set = false;
     static int occ = 2;                                         // resident blocks per CU (registers / LDS)
-    auto kern = conv_mfma_bf16_kernel<BN, KS, KC, TIO, JN>;
+    auto kern = conv_mfma_bf16_kernel<BN, KS, KC, TIO, JN, PL>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
@@ -740,6 +773,26 @@ extern "C" int sq_conv2d_nhwc_fwd_dropout_bf16(const void *x, const void *wp, co
     d.seed = seed;
     d.step = step_dev;
     SQ_REQUIRE(d.thr != 0u, "sq_conv2d_nhwc_fwd_dropout_bf16: rate too small for the 16-bit threshold");
+    return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, K, act, stream, nullptr, d);
+}
+
+// the same, with the 2x2/s2 max pool of the result written beside it (ypool (N,H/2,W/2,Cout); H, W even; K = 3): the
+// encoder's conv_block -> max_pool pair (unet.py:241-243) in one kernel.  rate == 0: no dropout (plain conv + act).
+extern "C" int sq_conv2d_nhwc_fwd_dropout_pool_bf16(const void *x, const void *wp, const float *bias, void *y, void *ypool,
+                                                    int N, int H, int W, int Cin, int Cout, int K, int act, float rate,
+                                                    uint32_t seed, const int32_t *step_dev, void *stream) {
+    SQ_REQUIRE(rate >= 0.f && rate < 1.f, "sq_conv2d_nhwc_fwd_dropout_pool_bf16: rate must be in [0, 1)");
+    SQ_REQUIRE(ypool && K == 3 && H % 2 == 0 && W % 2 == 0, "sq_conv2d_nhwc_fwd_dropout_pool_bf16: K = 3, even H and W, ypool");
+    SQ_REQUIRE_ALIGNED(ypool);
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    if (rate > 0.f) {
+        d.thr = (unsigned)(rate * 65536.0f);
+        d.inv = 1.0f / (1.0f - rate);
+        d.seed = seed;
+        d.step = step_dev;
+        SQ_REQUIRE(d.thr != 0u, "sq_conv2d_nhwc_fwd_dropout_pool_bf16: rate too small for the 16-bit threshold");
+    }
+    d.pool = reinterpret_cast<__bf16 *>(ypool);
     return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, K, act, stream, nullptr, d);
 }
 

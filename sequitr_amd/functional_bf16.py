@@ -126,13 +126,20 @@ class _ConvBlock(torch.autograd.Function):
     x is the bf16 block input, or the f32 single-channel image for down0."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, rate, seed, mask, step_dev, gate, junction):
+    def forward(ctx, x, w1, b1, w2, b2, rate, seed, mask, step_dev, gate, junction, poolbox):
         first = x.dtype == torch.float32
         ctx.gate, ctx.junction = gate, junction
         f = w1.shape[3]
         y1 = ob.conv3x3_first(x, w1, b1, act='relu') if first else ob.conv2d(x, ob.pack_weights(w1), b1, 3, f, act='relu')
         m = y2 = None
-        if rate > 0.0 and mask is None:
+        if poolbox is not None and mask is None and y1.shape[1] % 2 == 0 and y1.shape[2] % 2 == 0:
+            # an encoder level: the max-pooled copy the next level reads leaves conv2's epilogue with the block output
+            # (poolbox: a one-slot list the pool layer looks into -- a side channel, not a second autograd output)
+            out, pooled = ob.conv2d_dropout_pool(y1, ob.pack_weights(w2), b2, 3, f, 'relu', rate, seed=seed, step_dev=step_dev)
+            poolbox.append(pooled)
+            if rate <= 0.0:
+                y2 = out
+        elif rate > 0.0 and mask is None:
             # conv2 + ReLU + dropout in ONE kernel; neither y2 nor a mask is stored: out > 0 <=> kept and active
             out = ob.conv2d_dropout(y1, ob.pack_weights(w2), b2, 3, f, 'relu', rate, seed=seed, step_dev=step_dev)
         else:
@@ -180,10 +187,13 @@ class _ConvBlock(torch.autograd.Function):
             elif ctx.needs_input_grad[0]:
                 dx = ob.conv2d(d1, ob.pack_weights(w1, transform=True), None, 3, x.shape[3])
         return (dx, None if s1w is not None else dw1, None if s1b is not None else db1,
-                None if s2w is not None else dw2, None if s2b is not None else db2, None, None, None, None, None, None)
+                None if s2w is not None else dw2, None if s2b is not None else db2, None, None, None, None, None, None, None)
 
 
-def conv_block(x, w1, b1, w2, b2, rate=0.0, seed=0, mask=None, step_dev=None):
+FUSE_POOL = __import__("os").environ.get("SQ_FUSE_POOL", "1") != "0"
+
+
+def conv_block(x, w1, b1, w2, b2, rate=0.0, seed=0, mask=None, step_dev=None, pool_follows=False):
     gate = None
     if FUSE_GATE and mask is None:                               # pinned masks keep the separate mask kernels
         rate = float(rate)
@@ -191,9 +201,12 @@ def conv_block(x, w1, b1, w2, b2, rate=0.0, seed=0, mask=None, step_dev=None):
     junction = getattr(x, '_sq_junction', None)
     if not isinstance(junction, JunctionHandoff):
         junction = None
-    out = _ConvBlock.apply(x, w1, b1, w2, b2, float(rate), int(seed), mask, step_dev, gate, junction)
+    poolbox = [] if (pool_follows and FUSE_POOL) else None
+    out = _ConvBlock.apply(x, w1, b1, w2, b2, float(rate), int(seed), mask, step_dev, gate, junction, poolbox)
     if gate is not None:
         out._sq_gate = gate
+    if poolbox:
+        out._sq_pooled = poolbox                                # maxpool2x2(out) returns it instead of running the pool kernel
     return out
 
 
@@ -204,9 +217,11 @@ class _MaxPool(torch.autograd.Function):
     instead of two that autograd would have to sum in an extra kernel."""
 
     @staticmethod
-    def forward(ctx, x, box, gate):
+    def forward(ctx, x, box, gate, pooled):
         ctx.save_for_backward(x)
         ctx.box, ctx.gate = box, gate
+        if pooled:                                              # written by the conv block's epilogue (conv_block(pool_follows=True))
+            return pooled.pop()
         return ob.maxpool2x2(x)
 
     @staticmethod
@@ -218,12 +233,12 @@ class _MaxPool(torch.autograd.Function):
             # x has exactly two differentiable uses, this pool and the junction whose gradient is `other`: the sum is
             # the whole gradient of x, so the block gate of x (if it is a conv block's output) is applied here too
             gs = ctx.gate.take() if ctx.gate is not None else 0.0
-            return ob.maxpool2x2_bwd_add(x, dy.contiguous(), other, gate_scale=gs), None, None
-        return ob.maxpool2x2_bwd(x, dy.contiguous()), None, None
+            return ob.maxpool2x2_bwd_add(x, dy.contiguous(), other, gate_scale=gs), None, None, None
+        return ob.maxpool2x2_bwd(x, dy.contiguous()), None, None, None
 
 
 def maxpool2x2(x, box=None):
-    return _MaxPool.apply(x, box, _gate_of(x) if box is not None else None)
+    return _MaxPool.apply(x, box, _gate_of(x) if box is not None else None, getattr(x, '_sq_pooled', None))
 
 
 _UPJ_BOTH = __import__("os").environ.get("SQ_UPJ_BOTH", "1") != "0"   # A/B: dual-output convT+bridge kernel

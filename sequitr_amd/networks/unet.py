@@ -716,7 +716,18 @@ class UNet2DBf16(UNet2D):
             mask = self.dropout_masks.pop(0) if getattr(self, 'dropout_masks', None) else None
             step_dev = None if mask is not None else getattr(self, '_step_dev', None)
             seed = self._dropout_seed(step_dev)
-        return FB.conv_block(x, w1, b1, w2, b2, rate, seed, mask, step_dev)
+        pool_follows, self._pool_next = getattr(self, '_pool_next', False), False
+        return FB.conv_block(x, w1, b1, w2, b2, rate, seed, mask, step_dev, pool_follows=pool_follows)
+
+    def down_layer(self, x, filters, name=None):
+        """unet.py:282-296.  Every encoder level but the last is followed by the max pool (unet.py:241-243): its block
+        then writes the pooled tensor from conv2's epilogue (FB.conv_block(pool_follows=True)) and pool_layer picks it up."""
+        self._pool_next = (self.training and self.fuse_block and isinstance(name, int) and name < len(self.filters) - 1
+                           and type(self).pool_layer is UNet2DBf16.pool_layer)
+        try:
+            return UNet.down_layer(self, x, filters, name=name)
+        finally:
+            self._pool_next = False
 
     def conv_layer_1x1(self, x, filters):
         w, b = self._kernel((1, 1, x.shape[-1], filters)), self._bias(filters)

@@ -68,6 +68,22 @@ def conv2d_dropout(x, wp, bias, K, Cout, act, rate, seed=0, step_dev=None):
     return y
 
 
+def conv2d_dropout_pool(x, wp, bias, K, Cout, act, rate, seed=0, step_dev=None):
+    """(y, maxpool2x2(y)) with y = dropout(act(conv(x))) (rate 0: no dropout), one kernel: the pooled tensor is written from
+    the conv's epilogue instead of being re-read from y by a pooling pass."""
+    _chk(x, "x", ndim=4), _chk(wp, "wp")
+    N, H, W, Cin = x.shape
+    if bias is not None:
+        _chk(bias, "bias", dtype=torch.float32)
+    y = torch.empty((N, H, W, Cout), dtype=BF16, device=x.device)
+    yp = torch.empty((N, H // 2, W // 2, Cout), dtype=BF16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.sq_conv2d_nhwc_fwd_dropout_pool_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(yp), N, H, W, Cin, Cout,
+                                                       K, ACT[act], float(rate), int(seed) & 0xFFFFFFFF, _ptr(step_dev),
+                                                       _stream()), "sq_conv2d_nhwc_fwd_dropout_pool_bf16")
+    return y, yp
+
+
 def relu_scale_bwd(dy, y, scale):
     """dx = y > 0 ? dy * scale : 0 -- backward of dropout(relu(.)) from its output alone."""
     _chk(dy, "dy"), _chk(y, "y")

@@ -417,3 +417,41 @@ def test_convT_wgrad_writes_the_transpose_conv_layouts(shape):
     sink = torch.zeros(2 * 2 * Cout * Cin, device="cuda")
     dw2, db2 = ob.convT_wgrad(x, g, Cout, want_bias=False, dw_out=sink)
     assert db2 is None and torch.equal(sink.view(2, 2, Cout, Cin), dw_ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 48, 16, 16), (1, 64, 64, 32, 32), (1, 32, 32, 64, 64), (2, 16, 16, 128, 128),
+                                   (1, 36, 20, 16, 32)])
+@pytest.mark.parametrize("rate", [0.0, 0.4])
+def test_conv_with_pooled_copy_equals_conv_then_maxpool(shape, rate):
+    """sq_conv2d_nhwc_fwd_dropout_pool_bf16: y as the conv (+ dropout) kernel writes it, ypool = maxpool2x2(y), bit for bit
+    (ragged tiles included)."""
+    N, H, W, Cin, Cout = shape
+    x = dev(tiles(61, N, H, W, Cin), torch.bfloat16)
+    w, b = dev(rand_weights(62, (3, 3, Cin, Cout), 0.1)), dev(rand_weights(63, (Cout,), 0.1))
+    wp = ob.pack_weights(w)
+    y_ref = ob.conv2d_dropout(x, wp, b, 3, Cout, "relu", rate, seed=7) if rate > 0 else ob.conv2d(x, wp, b, 3, Cout, act="relu")
+    y, yp = ob.conv2d_dropout_pool(x, wp, b, 3, Cout, "relu", rate, seed=7)
+    assert torch.equal(y, y_ref) and torch.equal(yp, ob.maxpool2x2(y_ref))
+
+
+@pytest.mark.parametrize("dropout", [0.4, 0.0])
+def test_pool_from_the_block_epilogue_gives_the_same_step(dropout, monkeypatch):
+    """FB.FUSE_POOL on / off: same loss, same gradients, bit for bit."""
+    from sequitr_amd.train import UNetTrainer
+    from sequitr_amd import functional_bf16 as FB
+    base = {"shape": (64, 64), "dropout": dropout, "device": "cuda:0", "seed": 5, "filters": (16, 32, 64), "dtype": "bf16"}
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 64, 64, 1)).astype(np.float32)
+    lab = rng.random((2, 64, 64)) < 0.4
+    onehot = np.stack([~lab, lab], -1).astype(np.uint8)
+    wmap = (1 + rng.random((2, 64, 64, 1))).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to("cuda:0")
+    out = []
+    for fuse in (True, False):
+        monkeypatch.setattr(FB, "FUSE_POOL", fuse)
+        t = UNetTrainer(dict(base))
+        loss = t.forward_backward(d(x), d(onehot), d(wmap))
+        out.append((loss.item(), t.grads()))
+    assert out[0][0] == out[1][0]
+    for k in out[1][1]:
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k
