@@ -395,6 +395,16 @@ int sq_conv2d_nhwc_wgrad_scaled_f32(const float *x, const float *dy, float *dw, 
  * weights (`num_inputs`, unet.py:131). */
 int sq_conv3x3_first_fwd_bf16(const float *x, const float *w, const float *bias, void *y, int N, int H, int W,
                               int Cin, int Cout, int act, void *stream);
+/* Sign masks of ReLU outputs: one bit per element in NHWC order (bit c & 7 of byte (pixel * Cout + c) >> 3, Cout % 16 == 0,
+ * N*H*W*Cout/8 bytes).  The forward convs of a conv_block's conv1 (unet.py:265-270) write the mask beside their output;
+ * the dgrad of conv2, which lets gradient through where conv1's ReLU was active, reads the mask instead of the tensor
+ * (1/16 of the bytes).  sq_conv2d_nhwc_dgrad_maskgate_bf16 == sq_conv2d_nhwc_dgrad_gate_bf16 on the tensor, bit for bit. */
+int sq_conv3x3_first_fwd_mask_bf16(const float *x, const float *w, const float *bias, void *y, void *mask, int N, int H,
+                                   int W, int Cin, int Cout, int act, void *stream);
+int sq_conv2d_nhwc_fwd_mask_bf16(const void *x, const void *wp, const float *bias, void *y, void *mask, int N, int H, int W,
+                                 int Cin, int Cout, int K, int act, void *stream);
+int sq_conv2d_nhwc_dgrad_maskgate_bf16(const void *dy, const void *wp_t, const void *mask, float scale, void *dx, int N,
+                                       int H, int W, int Cin, int Cout, int K, void *stream);
 
 /* dW (K,K,Cin,Cout) f32 and db (Cout, may be NULL) f32 from bf16 X (N,H,W,Cin) and bf16 dY (N,H,W,Cout);
  * Cin % 16 == 0, Cout % 16 == 0.  Transposing LDS reads (ds_read_b64_tr_b16) feed the MFMA. */

@@ -52,6 +52,10 @@ struct SqDropEpi {
     // 2x2/s2 max pool of the block output in the same epilogue (pool != NULL; H, W even): the pooled tensor
     // (N,H/2,W/2,Cout) the next encoder level reads is written beside y, what sq_maxpool2x2_fwd_bf16 computes from y
     __bf16 *pool = nullptr;
+    // sign mask of a ReLU output, one bit per element in NHWC order (bit c & 7 of byte (pixel * C + c) >> 3; C % 16 == 0):
+    // written by the forward conv beside y (FORM_MK), read by the dgrad that gates on that output (FORM_MG) in place
+    // of the tensor itself -- 1/16 of its bytes
+    unsigned char *mask = nullptr;
 };
 
 template <int BN, int KS, int KC>
@@ -164,14 +168,18 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
     }
 }
 
-// JN: decoder-junction epilogue (SqDropEpi::j_*); PL: max-pooled copy of the output (SqDropEpi::pool)
-template <int BN, int KS, int KC, typename TIO, bool JN = false, bool PL = false>
+// FORM: epilogue variants, each its own instantiation so that the plain kernel keeps its register budget
+//   1 JN: decoder-junction backward (SqDropEpi::j_*)        2 PL: max-pooled copy of the output (SqDropEpi::pool)
+//   3 MK: sign mask of the output written beside it (mask)  4 MG: gate read from such a mask instead of a tensor
+enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4 };
+template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const TIO *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
     TIO *__restrict__ y, int N, int H, int W, int Cin, int Cout, int act, int tiles_x, int tiles_y,
     int ntiles, int tiles_per_block, const __bf16 *__restrict__ gate, SqDropEpi drop) {
     using C = CfgB<BN, KS, KC>;
     constexpr int NR = BN / 16, PAD = KS / 2;
+    constexpr bool JN = FORM == FORM_JN, PL = FORM == FORM_PL, MK = FORM == FORM_MK, MG = FORM == FORM_MG;
     constexpr bool F32IO = sizeof(TIO) == 4;                    // f32 activations in HBM, bf16 in LDS
     constexpr int ES = (int)sizeof(TIO), XV = F32IO ? 2 : 1;    // 16-byte loads per 8-channel LDS item
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -199,6 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16 *>(gate), 0, gate ? (int)((size_t)N * H * W * Cout * 2) : 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        drop.mask, 0, ((MK || MG) && drop.mask) ? (int)((size_t)N * H * W * Cout / 8) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
         drop.pool, 0, (PL && drop.pool) ? (int)((size_t)N * (H >> 1) * (W >> 1) * Cout * 2) : 0, 0x00020000);
 
@@ -433,7 +443,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                 }
                 continue;
             }
-            if constexpr (GATE_EARLY) {
+            unsigned mbits[4];
+            (void)mbits;
+            if constexpr (MG) {
+                // 16 channels of a pixel = one 16-bit word of the mask; the four kg lanes of a pixel read the same word
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    mbits[r] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(mrsrc, offs[r] == OOB ? OOB : ((offs[r] >> 4) & ~1u), 0, 0);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mbits[r] = (mbits[r] >> (4 * kg)) & 0xFu;
+            } else if constexpr (GATE_EARLY) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gv[r] = gpre[nb][r];
             } else if (gate) {
@@ -451,7 +471,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                 o[1] = (__bf16)actf(acc[r][nb][1] + bv.y);
                 o[2] = (__bf16)actf(acc[r][nb][2] + bv.z);
                 o[3] = (__bf16)actf(acc[r][nb][3] + bv.w);
-                if (gate) {
+                if constexpr (MG) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (mbits[r] >> j) & 1u ? (__bf16)((float)o[j] * drop.gscale) : (__bf16)0.f;
+                } else if (gate) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)         // bf16(o * 1.0f) == o: the plain ReLU gate costs no rounding
                         o[j] = (float)gv[r][j] > 0.f ? (__bf16)((float)o[j] * drop.gscale) : (__bf16)0.f;
@@ -465,6 +488,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                 const unsigned off = offs[r];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
                     __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, o), yrsrc, off, 0, 0);
+                if constexpr (MK) {
+                    unsigned nib = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nib |= ((float)o[j] > 0.f ? 1u : 0u) << j;
+                    unsigned v16 = nib << (4 * kg);             // fold the four kg lanes of the pixel: 16 channels, 16 bits
+                    v16 |= (unsigned)__shfl_xor((int)v16, 16);
+                    v16 |= (unsigned)__shfl_xor((int)v16, 32);
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v16, mrsrc, (off != OOB && kg == 0) ? (off >> 4) : OOB, 0, 0);
+                }
                 if constexpr (PL) {
                     // rows 4 wv + {0,1} and {2,3} are the two pool rows of this wave; the horizontal partner is the
                     // neighbouring lane (li ^ 1).  Every lane runs the exchange; even lanes of valid pixels store.
@@ -544,7 +576,7 @@ template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                const float *__restrict__ bias, __bf16 *__restrict__ y,
                                                                int N, int H, int W, int Cout, int act, int tiles_x,
-                                                               int tiles_y) {
+                                                               int tiles_y, unsigned char *__restrict__ mask) {
     constexpr int HW = TW + 2;
     __shared__ float xs[HW * HW * CIN];
     __shared__ float wsh[9 * CIN * 16];
@@ -576,6 +608,7 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
     const int gy = y0 + py, gx = x0 + px;
     if (gy < H && gx < W) {
         __bf16 *yo = y + ((size_t)(n * H + gy) * W + gx) * Cout + n0;
+        unsigned bits = 0;                                      // sign mask of the 16 channels (SqDropEpi::mask layout)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             if (n0 + q * 8 >= Cout) break;
@@ -584,25 +617,29 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
             for (int j = 0; j < 8; ++j) {
                 float v = a[q * 8 + j] + (bias ? bias[n0 + q * 8 + j] : 0.f);
                 o[j] = (__bf16)sq_act(v, act);
+                bits |= ((float)o[j] > 0.f ? 1u : 0u) << (q * 8 + j);
             }
             *reinterpret_cast<bf16x8 *>(yo + q * 8) = o;
         }
+        if (mask)
+            *reinterpret_cast<unsigned short *>(mask + ((((size_t)(n * H + gy) * W + gx) * Cout + n0) >> 3)) = (unsigned short)bits;
     }
 }
 
-template <int BN, int KS, int KC, typename TIO, bool JN = false, bool PL = false>
+template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN>
 int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int H, int W, int Cin, int Cout,
            int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
-    if constexpr (!JN && !PL && KS == 3 && sizeof(TIO) == 2) {  // the junction / pool forms are their own instantiations,
-        if (drop.j_g)                                           // so that the plain kernels keep their register budget
-            return launch<BN, KS, KC, TIO, true, false>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
-        if (drop.pool)
-            return launch<BN, KS, KC, TIO, false, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    if constexpr (FORM == FORM_PLAIN && KS == 3 && sizeof(TIO) == 2) {
+        if (drop.j_g) return launch<BN, KS, KC, TIO, FORM_JN>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+        if (drop.pool) return launch<BN, KS, KC, TIO, FORM_PL>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+        if (drop.mask)
+            return gate ? launch<BN, KS, KC, TIO, FORM_MG>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop)
+                        : launch<BN, KS, KC, TIO, FORM_MK>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
     }
     using C = CfgB<BN, KS, KC>;
     static bool attr_set = false;
     static int occ = 2;                                         // resident blocks per CU (registers / LDS)
-    auto kern = conv_mfma_bf16_kernel<BN, KS, KC, TIO, JN, PL>;
+    auto kern = conv_mfma_bf16_kernel<BN, KS, KC, TIO, FORM>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
@@ -796,6 +833,28 @@ extern "C" int sq_conv2d_nhwc_fwd_dropout_pool_bf16(const void *x, const void *w
     return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, K, act, stream, nullptr, d);
 }
 
+// conv + bias + ReLU with the sign mask of the output beside it (mask: N*H*W*Cout/8 bytes, bit c & 7 of byte
+// (pixel * Cout + c) >> 3; K = 3, Cout % 16 == 0): what the dgrad of the NEXT conv gates on, at 1/16 of the tensor's bytes
+extern "C" int sq_conv2d_nhwc_fwd_mask_bf16(const void *x, const void *wp, const float *bias, void *y, void *mask, int N,
+                                            int H, int W, int Cin, int Cout, int K, int act, void *stream) {
+    SQ_REQUIRE(mask && K == 3 && Cout % 16 == 0, "sq_conv2d_nhwc_fwd_mask_bf16: mask, K = 3, Cout %% 16 == 0");
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    d.mask = reinterpret_cast<unsigned char *>(mask);
+    return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, K, act, stream, nullptr, d);
+}
+
+// sq_conv2d_nhwc_dgrad_gate_bf16 with the gate read from such a mask: dx passes (times scale) where the bit is set
+extern "C" int sq_conv2d_nhwc_dgrad_maskgate_bf16(const void *dy, const void *wp_t, const void *mask, float scale, void *dx,
+                                                  int N, int H, int W, int Cin, int Cout, int K, void *stream) {
+    SQ_REQUIRE(mask && K == 3 && Cout % 16 == 0, "sq_conv2d_nhwc_dgrad_maskgate_bf16: mask, K = 3, Cout %% 16 == 0");
+    SQ_REQUIRE(scale > 0.f, "sq_conv2d_nhwc_dgrad_maskgate_bf16: scale must be positive");
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    d.gscale = scale;
+    d.mask = const_cast<unsigned char *>(reinterpret_cast<const unsigned char *>(mask));
+    // `gate` only selects the form here (non-NULL = read the mask); the tensor behind it is not touched
+    return conv_fwd_bf16_impl(dy, wp_t, nullptr, dx, N, H, W, Cin, Cout, K, SQ_ACT_NONE, stream, mask, d);
+}
+
 // dX of a convolution whose INPUT was the ReLU output `gate` (N,H,W,Cout): the dgrad convolution of dy with
 // the transposed packed filter, passed only where gate > 0 -- the upstream activation's backward fused in,
 // one pass over dX saved.
@@ -842,8 +901,16 @@ extern "C" int sq_conv2d_nhwc_dgrad_junction_bf16(const void *dy, const void *wp
 // first conv of down0 in the bf16 graph: f32 image (1..7 channels) in, bf16 activation out.
 extern "C" int sq_conv3x3_first_fwd_bf16(const float *x, const float *w, const float *bias, void *y, int N, int H,
                                          int W, int Cin, int Cout, int act, void *stream) {
+    return sq_conv3x3_first_fwd_mask_bf16(x, w, bias, y, nullptr, N, H, W, Cin, Cout, act, stream);
+}
+
+// ... and the sign mask of the output (1 bit per element, NHWC order, Cout % 16 == 0) beside it; mask may be NULL
+extern "C" int sq_conv3x3_first_fwd_mask_bf16(const float *x, const float *w, const float *bias, void *y, void *mask, int N,
+                                              int H, int W, int Cin, int Cout, int act, void *stream) {
     SQ_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 7 && Cout > 0 && Cout % 8 == 0,
                "sq_conv3x3_first_fwd_bf16: bad arguments (Cin 1..7, Cout %% 8 == 0)");
+    SQ_REQUIRE(!mask || Cout % 16 == 0, "sq_conv3x3_first_fwd_mask_bf16: the mask needs Cout %% 16 == 0");
+    unsigned char *mk = reinterpret_cast<unsigned char *>(mask);
     SQ_REQUIRE_ALIGNED(y);
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const dim3 grid((unsigned)(tiles_x * tiles_y) * N, (Cout + 15) / 16);
@@ -852,7 +919,7 @@ extern "C" int sq_conv3x3_first_fwd_bf16(const float *x, const float *w, const f
 #define SQ_FIRST(C)                                                                                                \
     case C:                                                                                                        \
         hipLaunchKernelGGL(conv_first_bf16_kernel<C>, grid, dim3(256), 0, st, x, w, bias, yo, N, H, W, Cout, act,  \
-                           tiles_x, tiles_y);                                                                      \
+                           tiles_x, tiles_y, mk);                                                                  \
         break;
     switch (Cin) { SQ_FIRST(1) SQ_FIRST(2) SQ_FIRST(3) SQ_FIRST(4) SQ_FIRST(5) SQ_FIRST(6) SQ_FIRST(7) }
 #undef SQ_FIRST

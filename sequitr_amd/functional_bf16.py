@@ -130,7 +130,13 @@ class _ConvBlock(torch.autograd.Function):
         first = x.dtype == torch.float32
         ctx.gate, ctx.junction = gate, junction
         f = w1.shape[3]
-        y1 = ob.conv3x3_first(x, w1, b1, act='relu') if first else ob.conv2d(x, ob.pack_weights(w1), b1, 3, f, act='relu')
+        m1 = None
+        if FUSE_MASK and f % 16 == 0:
+            # conv1's ReLU sign mask (1 bit per element) leaves its epilogue: conv2's dgrad gates on it in the backward
+            # instead of reading y1 again (y1 itself stays: it is conv2's wgrad operand)
+            y1, m1 = ob.conv3x3_first_mask(x, w1, b1) if first else ob.conv2d_mask(x, ob.pack_weights(w1), b1, 3, f)
+        else:
+            y1 = ob.conv3x3_first(x, w1, b1, act='relu') if first else ob.conv2d(x, ob.pack_weights(w1), b1, 3, f, act='relu')
         m = y2 = None
         if poolbox is not None and mask is None and y1.shape[1] % 2 == 0 and y1.shape[2] % 2 == 0:
             # an encoder level: the max-pooled copy the next level reads leaves conv2's epilogue with the block output
@@ -149,13 +155,13 @@ class _ConvBlock(torch.autograd.Function):
                 out, m = ob.dropout_fwd(y2, rate, seed=seed, mask=mask, step_dev=step_dev)
         ctx.rate, ctx.first = rate, first
         ctx.sinks = (grad_sink(w1), grad_sink(b1), grad_sink(w2), grad_sink(b2))
-        ctx.save_for_backward(x, w1, w2, y1, y2 if m is not None else out, m)
+        ctx.save_for_backward(x, w1, w2, y1, y2 if m is not None else out, m, m1)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        x, w1, w2, y1, y2, m = ctx.saved_tensors
+        x, w1, w2, y1, y2, m, m1 = ctx.saved_tensors
         s1w, s1b, s2w, s2b = ctx.sinks
         f = w2.shape[3]
         dout = dout.contiguous()
@@ -172,7 +178,10 @@ class _ConvBlock(torch.autograd.Function):
         else:
             d2 = ob.act_bwd(dout, y2, 'relu')
         dw2, db2 = ob.conv2d_wgrad(y1, d2, 3, want_bias=True, dw_out=s2w, db_out=s2b)
-        d1 = ob.conv2d_dgrad_relu(d2, ob.pack_weights(w2, transform=True), y1, 3)
+        if m1 is not None:
+            d1 = ob.conv2d_dgrad_mask(d2, ob.pack_weights(w2, transform=True), m1, 3, f)
+        else:
+            d1 = ob.conv2d_dgrad_relu(d2, ob.pack_weights(w2, transform=True), y1, 3)
         if ctx.first:
             dw1, db1 = ob.conv3x3_first_wgrad(x, d1, dw_out=s1w, db_out=s1b)
             dx = None
@@ -191,6 +200,7 @@ class _ConvBlock(torch.autograd.Function):
 
 
 FUSE_POOL = __import__("os").environ.get("SQ_FUSE_POOL", "1") != "0"
+FUSE_MASK = __import__("os").environ.get("SQ_FUSE_MASK", "1") != "0"
 
 
 def conv_block(x, w1, b1, w2, b2, rate=0.0, seed=0, mask=None, step_dev=None, pool_follows=False):

@@ -68,6 +68,51 @@ def conv2d_dropout(x, wp, bias, K, Cout, act, rate, seed=0, step_dev=None):
     return y
 
 
+def sign_mask_like(y):
+    """storage for the sign mask of a (N,H,W,C) ReLU output: N*H*W*C/8 bytes"""
+    N, H, W, C = y.shape
+    if C % 16:
+        raise ValueError("sign mask: C=%d must be a multiple of 16" % C)
+    return torch.empty((N, H, W, C // 8), dtype=torch.uint8, device=y.device)
+
+
+def conv2d_mask(x, wp, bias, K, Cout, act="relu"):
+    """(y, sign mask of y) of act(conv(x)): the mask leaves the conv's epilogue beside y."""
+    _chk(x, "x", ndim=4), _chk(wp, "wp")
+    N, H, W, Cin = x.shape
+    if bias is not None:
+        _chk(bias, "bias", dtype=torch.float32)
+    y = torch.empty((N, H, W, Cout), dtype=BF16, device=x.device)
+    m = sign_mask_like(y)
+    _lib.check(_lib.load().sq_conv2d_nhwc_fwd_mask_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(m), N, H, W, Cin, Cout, K,
+                                                       ACT[act], _stream()), "sq_conv2d_nhwc_fwd_mask_bf16")
+    return y, m
+
+
+def conv3x3_first_mask(x, w, bias, act="relu"):
+    """conv3x3_first with the sign mask of its output."""
+    _chk(x, "x", dtype=torch.float32, ndim=4), _chk(w, "w", dtype=torch.float32, ndim=4)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    y = torch.empty((N, H, W, Cout), dtype=BF16, device=x.device)
+    m = sign_mask_like(y)
+    _lib.check(_lib.load().sq_conv3x3_first_fwd_mask_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(m), N, H, W, Cin, Cout,
+                                                         ACT[act], _stream()), "sq_conv3x3_first_fwd_mask_bf16")
+    return y, m
+
+
+def conv2d_dgrad_mask(dy, wp_t, mask, K, Cout, scale=1.0):
+    """conv2d_dgrad_relu with the gate read from a sign mask (conv2d_mask / conv3x3_first_mask) instead of the tensor."""
+    _chk(dy, "dy", ndim=4), _chk(wp_t, "wp_t"), _chk(mask, "mask", dtype=torch.uint8)
+    N, H, W, Cin = dy.shape
+    if mask.numel() != N * H * W * Cout // 8:
+        raise ValueError("mask of %d bytes does not fit (%d,%d,%d,%d)" % (mask.numel(), N, H, W, Cout))
+    dx = torch.empty((N, H, W, Cout), dtype=BF16, device=dy.device)
+    _lib.check(_lib.load().sq_conv2d_nhwc_dgrad_maskgate_bf16(_ptr(dy), _ptr(wp_t), _ptr(mask), float(scale), _ptr(dx), N, H,
+                                                             W, Cin, Cout, K, _stream()), "sq_conv2d_nhwc_dgrad_maskgate_bf16")
+    return dx
+
+
 def conv2d_dropout_pool(x, wp, bias, K, Cout, act, rate, seed=0, step_dev=None):
     """(y, maxpool2x2(y)) with y = dropout(act(conv(x))) (rate 0: no dropout), one kernel: the pooled tensor is written from
     the conv's epilogue instead of being re-read from y by a pooling pass."""

@@ -455,3 +455,57 @@ def test_pool_from_the_block_epilogue_gives_the_same_step(dropout, monkeypatch):
     assert out[0][0] == out[1][0]
     for k in out[1][1]:
         assert np.array_equal(out[0][1][k], out[1][1][k]), k
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 48, 16, 16), (1, 64, 64, 32, 32), (1, 32, 32, 64, 64), (2, 16, 16, 128, 128),
+                                   (1, 36, 20, 32, 48), (1, 24, 24, 64, 16)])
+def test_sign_mask_of_the_forward_conv_and_the_dgrad_gated_by_it(shape):
+    """conv2d_mask: y as the plain conv writes it, mask bit (pixel, c) == (y > 0); conv2d_dgrad_mask == conv2d_dgrad_relu
+    gated by the tensor, with and without the dropout scale (ragged tiles and partial channel blocks included)."""
+    N, H, W, Cin, Cout = shape
+    x = dev(tiles(71, N, H, W, Cin), torch.bfloat16)
+    w, b = dev(rand_weights(72, (3, 3, Cin, Cout), 0.1)), dev(rand_weights(73, (Cout,), 0.1))
+    wp = ob.pack_weights(w)
+    y_ref = ob.conv2d(x, wp, b, 3, Cout, act="relu")
+    y, m = ob.conv2d_mask(x, wp, b, 3, Cout)
+    assert torch.equal(y, y_ref)
+    bits = np.unpackbits(m.cpu().numpy().reshape(N, H, W, Cout // 8), axis=-1, bitorder="little")
+    assert np.array_equal(bits.astype(bool), (y_ref.float() > 0).cpu().numpy())
+    dy = dev(tiles(74, N, H, W, 32), torch.bfloat16)
+    w2 = dev(rand_weights(75, (3, 3, Cout, 32), 0.1))          # the next conv Cout -> 32; its dgrad returns Cout channels
+    wp_t = ob.pack_weights(w2, transform=True)
+    for scale in (1.0, 1.0 / 0.6):
+        assert torch.equal(ob.conv2d_dgrad_mask(dy, wp_t, m, 3, Cout, scale=scale),
+                           ob.conv2d_dgrad_relu(dy, wp_t, y_ref, 3, scale=scale))
+
+
+def test_first_conv_sign_mask():
+    x = dev(tiles(81, 2, 32, 48, 1))
+    w, b = dev(rand_weights(82, (3, 3, 1, 16), 0.3)), dev(rand_weights(83, (16,), 0.1))
+    y_ref = ob.conv3x3_first(x, w, b, act="relu")
+    y, m = ob.conv3x3_first_mask(x, w, b)
+    assert torch.equal(y, y_ref)
+    bits = np.unpackbits(m.cpu().numpy(), axis=-1, bitorder="little")
+    assert np.array_equal(bits.astype(bool), (y_ref.float() > 0).cpu().numpy())
+
+
+def test_mask_gate_gives_the_same_step(monkeypatch):
+    """FB.FUSE_MASK on / off: same loss, same gradients, bit for bit."""
+    from sequitr_amd.train import UNetTrainer
+    from sequitr_amd import functional_bf16 as FB
+    base = {"shape": (64, 64), "dropout": 0.4, "device": "cuda:0", "seed": 5, "filters": (16, 32, 64), "dtype": "bf16"}
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 64, 64, 1)).astype(np.float32)
+    lab = rng.random((2, 64, 64)) < 0.4
+    onehot = np.stack([~lab, lab], -1).astype(np.uint8)
+    wmap = (1 + rng.random((2, 64, 64, 1))).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to("cuda:0")
+    out = []
+    for fuse in (True, False):
+        monkeypatch.setattr(FB, "FUSE_MASK", fuse)
+        t = UNetTrainer(dict(base))
+        loss = t.forward_backward(d(x), d(onehot), d(wmap))
+        out.append((loss.item(), t.grads()))
+    assert out[0][0] == out[1][0]
+    for k in out[1][1]:
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k
