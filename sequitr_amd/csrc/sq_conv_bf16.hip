@@ -26,6 +26,10 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef SQ_CONV_EARLY_ISSUE
+#define SQ_CONV_EARLY_ISSUE 2       // where the next item's loads are requested: 0 = top of the loop, 1 = after the commit
+#endif                              // (before the epilogue), 2 = after the commit in the forms it was measured faster in
+
 namespace {
 
 constexpr int TH = 16, TW = 16;
@@ -530,11 +534,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     commit(true);
     __syncthreads();
     int tile = t_begin, chunk = 0;
+    // EARLY: the loads of the next item are requested as soon as the staging registers are free again -- right after the
+    // commit, BEFORE the epilogue of the tile that just finished -- so a block has a tile in flight during its epilogue
+    // as well.  Measured per form at level 0 (r02t16 / r02t17): pool form 78 -> 69 us, junction form 124 -> 118 us, plain and
+    // mask-out forms 62 -> 66 us (their short epilogues gain nothing and the request now queues behind the stores).
+    constexpr bool EARLY = SQ_CONV_EARLY_ISSUE == 1 || (SQ_CONV_EARLY_ISSUE == 2 && (PL || JN));
+    auto step = [&](int &t, int &c) { if (++c == nchunk) { c = 0; ++t; } };
+    if (EARLY && nitems > 1) {
+        int t1 = t_begin, c1 = 0;
+        step(t1, c1);
+        issue(t1, c1, restage_w);
+    }
     for (int it = 0; it < nitems; ++it) {
-        int ntile = tile, nchk = chunk + 1;
-        if (nchk == nchunk) { nchk = 0; ntile = tile + 1; }
+        int ntile = tile, nchk = chunk;
+        step(ntile, nchk);
         const bool has_next = it + 1 < nitems;
-        if (has_next) issue(ntile, nchk, restage_w);
+        if (!EARLY && has_next) issue(ntile, nchk, restage_w);
         if constexpr (GATE_EARLY) {
             if (gate && chunk == nchunk - 1) gate_fetch(tile);
         }
@@ -562,6 +577,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         if (has_next) {
             __syncthreads();
             commit(restage_w);
+        }
+        if (EARLY && it + 2 < nitems) {
+            int t2 = ntile, c2 = nchk;
+            step(t2, c2);
+            issue(t2, c2, restage_w);
         }
         if (chunk == nchunk - 1) epilogue(tile);
         if (has_next) __syncthreads();
