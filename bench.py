@@ -669,7 +669,7 @@ def main_centroids(args):
            "config": {"workload": "CentroidWriter.write on 32 x 512x512 masks, 60 disks per tile",
                       "components": int(sum(len(f) for f in frames))},
            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kms * 1e-3) / 1e9, 1), "peak": 8000.0,
-                        "unit": "GB/s", "frac": round(alg_bytes / (kms * 1e-3) / 8e12, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(alg_bytes / (kms * 1e-3) / 8e12, 4), "traffic": pmc_step_traffic("centroids")[0], "traffic_source": pmc_step_traffic("centroids")[1],
                         "kernel_ms_per_step": round(kms, 4),
                         "algorithmic_bytes_per_pixel": 15}}
     if not args.no_cpu_baseline:
@@ -719,7 +719,7 @@ def main_weightmap(args):
            "dtype": "int32/f64", "data": "synthetic",
            "config": {"workload": "ImageWeightMap(w0=10, sigma=5) on 16 x 512x512 binary label tiles, f32 maps left in HBM"},
            "roofline": {"bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(alg / (kms * 1e-3) / 8e12, 4), "traffic": None,
+                        "frac": round(alg / (kms * 1e-3) / 8e12, 4), "traffic": pmc_step_traffic("weightmap")[0], "traffic_source": pmc_step_traffic("weightmap")[1],
                         "kernel_ms_per_step": round(kms, 4), "algorithmic_bytes_per_pixel": 20}}
     if not args.no_cpu_baseline:
         from oracle import weightmap_ref
@@ -833,7 +833,7 @@ def main_frontend(args):
            "config": {"workload": "ImageNorm + tiling of 8 x 1200x1600 uint16 frames into %d tiles of 512x512" % tiles.shape[0],
                       "tiles_per_frame": tl.tiles_per_frame},
            "roofline": {"bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(alg / (kms * 1e-3) / 8e12, 4), "traffic": None},
+                        "frac": round(alg / (kms * 1e-3) / 8e12, 4), "traffic": pmc_step_traffic("frontend")[0], "traffic_source": pmc_step_traffic("frontend")[1]},
            "end_to_end": {"value": round(npx / dt / 1e6, 2), "unit": "Mpixels/s (frame pixels)",
                           "what": "host uint16 frames -> pinned -> H2D -> norm/tile -> U-Net -> stitch -> host masks, "
                                   "2 frames (24 tiles) per batch, uploads overlapped", "seconds": round(dt, 4),

@@ -117,6 +117,179 @@ __global__ __launch_bounds__(256) void edt_cols_weight_kernel(const float *__res
     }
 }
 
+// ---- round-2 forms of the two passes (W <= 1024, H <= 2048; larger images keep the kernels above) ----------------------
+// rows: the feature ballots of the WHOLE row are taken first (all loads of the row in flight at once), the nearest feature
+// to the left / right of every pixel then comes out of registers and g is written once (the kernel above re-reads the row
+// and read-modify-writes g, one dependent round trip per 64-pixel segment and direction).
+constexpr int ROW_SEGS = 16;
+__global__ __launch_bounds__(256) void edt_rows_v2_kernel(const float *__restrict__ img, unsigned short *__restrict__ g,
+                                                          int rows, int W) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float *row = img + (size_t)r * W;
+    const int nseg = (W + 63) / 64;
+    float v[ROW_SEGS];
+#pragma unroll
+    for (int sg = 0; sg < ROW_SEGS; ++sg) {
+        const int col = sg * 64 + lane;
+        v[sg] = (sg < nseg && col < W) ? row[col] : 0.f;
+    }
+    u64 F[ROW_SEGS];
+#pragma unroll
+    for (int sg = 0; sg < ROW_SEGS; ++sg)
+        F[sg] = (sg < nseg) ? __ballot(sg * 64 + lane < W && (1.0 - (double)v[sg]) == 0.0) : 0ULL;   // feature <=> (1 - image) == 0
+    // right-to-left sweep over the segments: column of the first feature after each segment
+    int nxt[ROW_SEGS];
+    int next = 2 * G_INF;
+#pragma unroll
+    for (int sg = ROW_SEGS - 1; sg >= 0; --sg) {
+        nxt[sg] = next;
+        if (F[sg]) next = sg * 64 + __ffsll((long long)F[sg]) - 1;
+    }
+    int last = -G_INF;                                          // column of the last feature before the segment
+    const u64 upto = lane == 63 ? ~0ULL : ((2ULL << lane) - 1ULL), from = ~0ULL << lane;
+#pragma unroll
+    for (int sg = 0; sg < ROW_SEGS; ++sg) {
+        if (sg < nseg) {
+            const int col = sg * 64 + lane;
+            const u64 ml = F[sg] & upto, mr = F[sg] & from;
+            const int left = ml ? sg * 64 + 63 - __clzll((long long)ml) : last;
+            const int right = mr ? sg * 64 + __ffsll((long long)mr) - 1 : nxt[sg];
+            int d = col - left;
+            d = d < G_INF ? d : G_INF;
+            const int dr = right - col;
+            d = dr < d ? dr : d;
+            if (col < W) g[(size_t)r * W + col] = (unsigned short)d;
+            if (F[sg]) last = sg * 64 + 63 - __clzll((long long)F[sg]);
+        }
+    }
+}
+
+// columns + map: a block owns a strip of CS columns of one image with g for ALL rows in LDS (H x CS x 2 bytes); the outward
+// search of the kernel above then runs on LDS (it issued two dependent global loads per step), lanes along x.  "No feature
+// in this image" is a block-local fact: every row with a feature has a finite g in every column.
+constexpr int CS = 32, RSPLIT = 8;                           // RSPLIT blocks share a strip, each maps H / RSPLIT of its rows (the
+                                                              // strip is re-read from L2 by each: parallelism over bytes)
+template <bool WANT_D2>
+__global__ __launch_bounds__(256) void edt_cols_weight_v2_kernel(const float *__restrict__ img,
+                                                                 const unsigned short *__restrict__ g,
+                                                                 double *__restrict__ out64, float *__restrict__ out32,
+                                                                 int *__restrict__ d2out, int H, int W, double w0, double denom) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short gs[];       // [H][CS], then the block minima [ceil(H/8)][CS]
+    __shared__ int any_feature;
+    const int nblk8 = (H + 7) / 8;
+    unsigned short *m8 = gs + (size_t)H * CS;                   // m8[b][x] = min of g over rows 8b .. 8b+7 of column x
+    const int strips = (W + CS - 1) / CS;
+    const int part = blockIdx.x % RSPLIT, sb = blockIdx.x / RSPLIT;
+    const int n = sb / strips, x0 = (sb % strips) * CS;
+    const int rows_per = (H + RSPLIT - 1) / RSPLIT, y_lo = part * rows_per, y_hi = min(H, y_lo + rows_per);
+    const unsigned short *gi = g + (size_t)n * H * W;
+    if (threadIdx.x == 0) any_feature = 0;
+    __syncthreads();
+    int seen = 0;
+    for (int i = threadIdx.x; i < H * CS; i += 256) {
+        const int y = i / CS, x = x0 + i % CS;
+        const unsigned short v = x < W ? gi[(size_t)y * W + x] : (unsigned short)G_INF;
+        gs[i] = v;
+        seen |= v < G_INF;
+    }
+    if (__any(seen) && (threadIdx.x & 63) == 0) any_feature = 1;             // benign race: every writer stores 1
+    __syncthreads();
+    for (int i = threadIdx.x; i < nblk8 * CS; i += 256) {
+        const int b = i / CS, xx = i % CS;
+        int m = G_INF;
+        for (int r = 8 * b; r < min(H, 8 * b + 8); ++r) m = min(m, (int)gs[r * CS + xx]);
+        m8[i] = (unsigned short)m;
+    }
+    __syncthreads();
+    const bool has = any_feature != 0;
+    const int xl = threadIdx.x % CS, x = x0 + xl;
+    for (int y = y_lo + threadIdx.x / CS; y < y_hi; y += 256 / CS) {
+        if (x >= W) continue;
+        int best;
+        if (!has) {
+            best = (y + 1) * (y + 1) + x * x;                   // scipy's artefact for an image without background (see above)
+        } else {
+            // min over y' of g(y')^2 + (y - y')^2, searched outwards in blocks of 8 rows: a block is skipped when its nearest
+            // row is already too far (and with it every block beyond) or when (nearest row)^2 + (its smallest g)^2 cannot
+            // beat the best so far; the blocks that can are scanned exactly, eight independent candidates at a time.
+            // Same minimum as the row-by-row search above: only candidates that cannot lower it are left out.
+            const unsigned short *gc = gs + xl, *mc = m8 + xl;
+            const int g0 = gc[y * CS];
+            best = g0 * g0;
+            auto scan = [&](int b) {
+                const int r0 = 8 * b;
+                if (r0 + 8 <= H) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int v = gc[(r0 + k) * CS], dy = y - (r0 + k);
+                        const int c = v * v + dy * dy;
+                        best = c < best ? c : best;
+                    }
+                } else {
+                    for (int r = r0; r < H; ++r) {
+                        const int v = gc[r * CS], dy = y - r;
+                        const int c = v * v + dy * dy;
+                        best = c < best ? c : best;
+                    }
+                }
+            };
+            const int b0 = y >> 3;
+            scan(b0);
+            bool up = true, dn = true;
+            for (int db = 1; up || dn; ++db) {
+                const int bu = b0 - db, bd = b0 + db;
+                if (up) {
+                    const int du = y - (8 * bu + 7);            // distance to the nearest row of the block above
+                    if (bu < 0 || du * du >= best) up = false;
+                    else { const int m = mc[bu * CS]; if (du * du + m * m < best) scan(bu); }
+                }
+                if (dn) {
+                    const int dd = 8 * bd - y;
+                    if (bd >= nblk8 || dd * dd >= best) dn = false;
+                    else { const int m = mc[bd * CS]; if (dd * dd + m * m < best) scan(bd); }
+                }
+            }
+        }
+        const size_t p = ((size_t)n * H + y) * W + x;
+        if (WANT_D2) {
+            d2out[p] = best;
+        } else {
+            const double image = (double)img[p];
+            const double bg = 1.0 - image;
+            const double d = sqrt((double)best);
+            const double v = w0 * bg * exp(-(d * d) / denom) + image + 1.0;   // the reference's expression, as above
+            if (out64) out64[p] = v;
+            if (out32) out32[p] = (float)v;
+        }
+    }
+}
+
+inline bool edt_v2_fits(int H, int W) {
+    static const bool on = [] { const char *e = getenv("SQ_EDT_V2"); return !(e && e[0] == '0'); }();
+    return on && W <= 64 * ROW_SEGS && H <= 2048;
+}
+
+template <bool WANT_D2>
+int edt_v2(const float *img, unsigned short *g, double *out64, float *out32, int *d2, int N, int H, int W, double w0,
+           double denom, hipStream_t st, const char *who) {
+    const int rows = N * H;
+    hipLaunchKernelGGL(edt_rows_v2_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, img, g, rows, W);
+    int rc = sq_check_launch(who);
+    if (rc) return rc;
+    const int lds = (H + (H + 7) / 8) * CS * 2;
+    auto kern = edt_cols_weight_v2_kernel<WANT_D2>;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               lds) != hipSuccess) {
+        sq_set_error("%s: cannot reserve %d bytes of LDS", who, lds);
+        return SQ_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(N * ((W + CS - 1) / CS) * RSPLIT)), dim3(256), lds, st, img, g, out64, out32, d2, H, W,
+                       w0, denom);
+    return sq_check_launch(who);
+}
+
 inline unsigned wm_grid(int64_t items) {
     int64_t b = (items + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -153,6 +326,10 @@ extern "C" int sq_edt_sq_f32(const float *img, int32_t *d2, void *workspace, int
     unsigned short *g;
     int *flag;
     hipStream_t st = (hipStream_t)stream;
+    if (img && workspace && N > 0 && H > 0 && W > 0 && edt_v2_fits(H, W) && (int64_t)N * H * W < ((int64_t)1 << 31) &&
+        (((uintptr_t)workspace) & 15u) == 0)
+        return edt_v2<true>(img, reinterpret_cast<unsigned short *>(reinterpret_cast<int *>(workspace) + ((N + 3) / 4) * 4),
+                            nullptr, nullptr, d2, N, H, W, 0.0, 1.0, st, "sq_edt_sq_f32");
     int rc = edt_common(img, workspace, N, H, W, &g, &flag, st, "sq_edt_sq_f32");
     if (rc) return rc;
     hipLaunchKernelGGL(edt_cols_weight_kernel<true>, dim3(wm_grid((int64_t)N * H * W)), dim3(256), 0, st, img, g, flag,
@@ -166,9 +343,13 @@ extern "C" int sq_weightmap_edt_f32(const float *img, double *out64, float *out3
     unsigned short *g;
     int *flag;
     hipStream_t st = (hipStream_t)stream;
+    const double denom = 2.0 * (sigma * sigma) + 1e-99;         // 2.*self.sigma**2 + 1e-99
+    if (img && workspace && N > 0 && H > 0 && W > 0 && edt_v2_fits(H, W) && (int64_t)N * H * W < ((int64_t)1 << 31) &&
+        (((uintptr_t)workspace) & 15u) == 0)
+        return edt_v2<false>(img, reinterpret_cast<unsigned short *>(reinterpret_cast<int *>(workspace) + ((N + 3) / 4) * 4),
+                             out64, out32, nullptr, N, H, W, w0, denom, st, "sq_weightmap_edt_f32");
     int rc = edt_common(img, workspace, N, H, W, &g, &flag, st, "sq_weightmap_edt_f32");
     if (rc) return rc;
-    const double denom = 2.0 * (sigma * sigma) + 1e-99;         // 2.*self.sigma**2 + 1e-99
     hipLaunchKernelGGL(edt_cols_weight_kernel<false>, dim3(wm_grid((int64_t)N * H * W)), dim3(256), 0, st, img, g, flag,
                        out64, out32, (int *)nullptr, N, H, W, w0, denom);
     return sq_check_launch("sq_weightmap_edt_f32");
