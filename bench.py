@@ -1195,7 +1195,8 @@ def main():
                                     % total_tiles if args.scaling == "strong" else
                                     "one 32-tile batch per GPU per step"),
                        "tiles_per_step": int(total_tiles), "tiles_this_rank": int(x_all.shape[0]),
-                       "parity": "logits and masks bit-exact vs oracle/sq_oracle.c (tests/test_gpu_unet.py)"},
+                       "parity": "logits and masks bit-exact vs oracle/sq_oracle.c (tests/test_gpu_unet.py); the oracle is parity "
+                                 "UNPINNED against the reference (its U-Net leaf ops are abstract, unet.py:326-343)"},
             "roofline": {
                 "bound": "mfma",
                 "kernel": "conv_mfma_f32_v2_kernel, all 17 launches of a step incl. the pool / head / first-block / "
