@@ -379,6 +379,11 @@ int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, vo
  * Cout % 4 == 0.  The drop-in for sq_conv2d_nhwc_fwd_f32 where the bf16 matrix rate is wanted. */
 int sq_conv2d_nhwc_fwd_mixed_f32(const float *x, const void *wp, const float *bias, float *y, int N, int H, int W,
                                  int Cin, int Cout, int K, int act, void *stream);
+/* dgrad of such a conv whose INPUT was the output `gate` (N,H,W,Cout) of a ReLU / leaky-ReLU (act): the result leaves through
+ * that activation's backward in the epilogue, dx = gate > 0 ? v : v * slope -- the sq_act_bwd_f32 pass that followed the
+ * dgrad in the GAN's first-order backward passes (gan.py:90-98 chains), same bits */
+int sq_conv2d_nhwc_dgrad_actgate_mixed_f32(const float *dy, const void *wp_t, const float *gate, int act, float *dx, int N,
+                                           int H, int W, int Cin, int Cout, int K, void *stream);
 /* its weight gradient: dW (K,K,Cin,Cout) f32, db (Cout) f32 or NULL from f32 X and f32 dY (rounded to bf16 in
  * LDS); Cin % 16 == 0, Cout % 16 == 0. */
 int64_t sq_conv2d_nhwc_wgrad_workspace_mixed_f32(int N, int H, int W, int Cin, int Cout, int K);

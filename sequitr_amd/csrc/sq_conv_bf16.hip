@@ -60,6 +60,7 @@ struct SqDropEpi {
     // written by the forward conv beside y (FORM_MK), read by the dgrad that gates on that output (FORM_MG) in place
     // of the tensor itself -- 1/16 of its bytes
     unsigned char *mask = nullptr;
+    const float *gate_f32 = nullptr;                            // FORM_GF (f32 tensors): (N,H,W,Cout) activation output, slope in gscale
 };
 
 template <int BN, int KS, int KC>
@@ -175,7 +176,9 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
 // FORM: epilogue variants, each its own instantiation so that the plain kernel keeps its register budget
 //   1 JN: decoder-junction backward (SqDropEpi::j_*)        2 PL: max-pooled copy of the output (SqDropEpi::pool)
 //   3 MK: sign mask of the output written beside it (mask)  4 MG: gate read from such a mask instead of a tensor
-enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4 };
+//   5 GF: f32 tensors (the GAN's mixed form): the result leaves through the backward of the activation whose output
+//         `gate_f32` is -- dx = gate > 0 ? v : v * gscale -- the act_bwd pass that followed this dgrad
+enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4, FORM_GF = 5 };
 template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const TIO *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     using C = CfgB<BN, KS, KC>;
     constexpr int NR = BN / 16, PAD = KS / 2;
     constexpr bool JN = FORM == FORM_JN, PL = FORM == FORM_PL, MK = FORM == FORM_MK, MG = FORM == FORM_MG;
+    constexpr bool GF = FORM == FORM_GF;
     constexpr bool F32IO = sizeof(TIO) == 4;                    // f32 activations in HBM, bf16 in LDS
     constexpr int ES = (int)sizeof(TIO), XV = F32IO ? 2 : 1;    // 16-byte loads per 8-channel LDS item
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -433,7 +437,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                 const bool ok = gy < H && gx < W && co < Cout;
                 offs[r] = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * ES) : OOB;
             }
-            if constexpr (F32IO) {                              // f32 store of the f32 accumulators; no gate / dropout
+            if constexpr (F32IO) {                              // f32 store of the f32 accumulators; no dropout
+                float4 gq[4];
+                (void)gq;
+                if constexpr (GF) {
+                    const __amdgpu_buffer_rsrc_t gfrsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float *>(drop.gate_f32), 0, (int)((size_t)N * H * W * Cout * 4), 0x00020000);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto gl = __builtin_amdgcn_raw_buffer_load_b128(gfrsrc, offs[r], 0, 0);
+                        gq[r] = *reinterpret_cast<const float4 *>(&gl);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);         // inside the branch, as for the bf16 gate below
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float4 o;
@@ -441,6 +457,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                     o.y = actf(acc[r][nb][1] + bv.y);
                     o.z = actf(acc[r][nb][2] + bv.z);
                     o.w = actf(acc[r][nb][3] + bv.w);
+                    if constexpr (GF) {                         // one f32 multiply where the activation was not active: act_bwd's
+                        o.x = gq[r].x > 0.f ? o.x : o.x * drop.gscale;
+                        o.y = gq[r].y > 0.f ? o.y : o.y * drop.gscale;
+                        o.z = gq[r].z > 0.f ? o.z : o.z * drop.gscale;
+                        o.w = gq[r].w > 0.f ? o.w : o.w * drop.gscale;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
                         __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), yrsrc, offs[r], 0, 0);
                     acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -649,6 +671,9 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
 template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN>
 int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int H, int W, int Cin, int Cout,
            int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
+    if constexpr (FORM == FORM_PLAIN && sizeof(TIO) == 4) {
+        if (drop.gate_f32) return launch<BN, KS, KC, TIO, FORM_GF>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    }
     if constexpr (FORM == FORM_PLAIN && KS == 3 && sizeof(TIO) == 2) {
         if (drop.j_g) return launch<BN, KS, KC, TIO, FORM_JN>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
         if (drop.pool) return launch<BN, KS, KC, TIO, FORM_PL>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
@@ -810,6 +835,26 @@ extern "C" int sq_conv2d_nhwc_fwd_mixed_f32(const float *x, const void *wp, cons
     if (bias) SQ_REQUIRE_ALIGNED(bias);
     return dispatch_kc<float>(x, reinterpret_cast<const __bf16 *>(wp), bias, y, N, H, W, Cin, Cout, K, act,
                               reinterpret_cast<hipStream_t>(stream), nullptr, SqDropEpi{0u, 1.f, 0u, nullptr});
+}
+
+// dgrad of a conv (f32 tensors, bf16 multiply) whose input was the output `gate` of a leaky-ReLU / ReLU: the result leaves
+// through that activation's backward, dx = gate > 0 ? v : v * slope (slope 0.2 / 0) -- sq_conv2d_nhwc_fwd_mixed_f32 on dY
+// with the dgrad pack followed by sq_act_bwd_f32, in one kernel, same bits
+extern "C" int sq_conv2d_nhwc_dgrad_actgate_mixed_f32(const float *dy, const void *wp_t, const float *gate, int act, float *dx,
+                                                      int N, int H, int W, int Cin, int Cout, int K, void *stream) {
+    SQ_REQUIRE(dy && wp_t && gate && dx, "sq_conv2d_nhwc_dgrad_actgate_mixed_f32: null tensor pointer");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && (K == 1 || K == 3), "sq_conv2d_nhwc_dgrad_actgate_mixed_f32: bad shape / K");
+    SQ_REQUIRE(Cin % 8 == 0 && Cin > 0 && Cout % 4 == 0 && Cout > 0,
+               "sq_conv2d_nhwc_dgrad_actgate_mixed_f32: Cin=%d (multiple of 8), Cout=%d (multiple of 4)", Cin, Cout);
+    SQ_REQUIRE((size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31),
+               "sq_conv2d_nhwc_dgrad_actgate_mixed_f32: tensors must be < 2 GiB");
+    SQ_REQUIRE(act == SQ_ACT_RELU || act == SQ_ACT_LEAKY, "sq_conv2d_nhwc_dgrad_actgate_mixed_f32: activation %d has no gate", act);
+    SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(wp_t); SQ_REQUIRE_ALIGNED(gate); SQ_REQUIRE_ALIGNED(dx);
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    d.gate_f32 = gate;
+    d.gscale = act == SQ_ACT_LEAKY ? 0.2f : 0.0f;
+    return dispatch_kc<float>(dy, reinterpret_cast<const __bf16 *>(wp_t), nullptr, dx, N, H, W, Cin, Cout, K, SQ_ACT_NONE,
+                              reinterpret_cast<hipStream_t>(stream), nullptr, d);
 }
 
 extern "C" int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H,

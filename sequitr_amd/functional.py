@@ -232,6 +232,9 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, act, wscale, gate):
         ctx.gate = gate
+        # x = the activation output of the conv in front (it hangs its ActGate on x): this conv is x's only consumer
+        # (gan.py:149-316 wiring), so in first-order passes its dgrad kernel applies act'(x) in the epilogue
+        ctx.in_gate = _gate_of(x) if gate is not None or FUSE_ACT_GATES else None
         y = ops.conv2d(x, w, bias, act=act, wscale=wscale)
         ctx.act, ctx.wscale, ctx.has_bias = act, wscale, bias is not None
         ctx.w_id, ctx.bias_id = _pid(w), _pid(bias)
@@ -248,7 +251,13 @@ class _Conv2d(torch.autograd.Function):
         dpre = _ActBwd.apply(dy, y, ctx.act) if (y is not None and not gated) else dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _ConvDgrad.apply(dpre, w, ctx.wscale)
+            ig = ctx.in_gate
+            if ig is not None and not ig.applied and not torch.is_grad_enabled():
+                dx = ops.conv_dgrad_actgate(dpre, w, ctx.wscale, x, ig.act)
+                if dx is not None:
+                    ig.applied = True                           # the conv that produced x skips its act_bwd pass
+            if dx is None:
+                dx = _ConvDgrad.apply(dpre, w, ctx.wscale)
         want_w = ctx.needs_input_grad[1] and _want(ctx.w_id)
         need_b = ctx.has_bias and ctx.needs_input_grad[2] and _want(ctx.bias_id)
         if not want_w and not need_b:

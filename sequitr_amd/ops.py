@@ -816,6 +816,25 @@ def conv_dgrad_raw(dy, w, wscale=1.0):
     return conv2d(dy, w, None, act=None, wscale=wscale, _dgrad=True)
 
 
+def conv_dgrad_actgate(dy, w, wscale, gate, act):
+    """conv_dgrad_raw followed by act_bwd(., gate, act) in one kernel -- or None where that form does not exist (f32
+    precision, small-image mosaics, odd channel counts): the caller then runs the two ops."""
+    K, _, Cin, Cout = w.shape                                   # forward filter: the dgrad maps Cout -> Cin channels
+    N, H, W, C = dy.shape
+    if not (MIXED and ACT[act] and C == Cout and Cout % 8 == 0 and Cin % 4 == 0):
+        return None
+    if (USE_MOSAIC and W < 16 and N * H > 1) or (K == 1 and N * H * W <= 128 and Cout >= 1024 and USE_DENSE):
+        return None
+    _chk(dy, "dy", ndim=4), _chk(gate, "gate", ndim=4)
+    if tuple(gate.shape) != (N, H, W, Cin):
+        return None
+    wp = _packed_filter(w, K, Cout, Cin, wscale, True)
+    dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.load().sq_conv2d_nhwc_dgrad_actgate_mixed_f32(_ptr(dy), _ptr(wp), _ptr(gate), ACT[act], _ptr(dx), N, H, W,
+                                                                 Cout, Cin, K, _stream()), "sq_conv2d_nhwc_dgrad_actgate_mixed_f32")
+    return dx
+
+
 def conv_wgrad_raw(x, dy, K, want_bias=False, dw_out=None, db_out=None, dw_scale=1.0):
     """(dW (K,K,Cin,Cout) * dw_scale, db or None) for every channel mix the GAN / U-Net graphs use; the factor rides
     in the finish kernel on the MFMA paths and is one extra multiply kernel on the small image-side 1x1 forms."""
