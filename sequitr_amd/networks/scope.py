@@ -78,6 +78,8 @@ class VariableStore(object):
                     self.vars[k].copy_(t)
                 else:
                     self.vars[k] = t.requires_grad_(True) if self.trainable else t
+        from .. import ops                                      # the weights changed in place: cached filter packs /
+        ops.invalidate_packs()                                  # transforms of the old values must not be served again
 
 
 def current_store():

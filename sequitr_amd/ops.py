@@ -126,6 +126,7 @@ _PLANS = __import__('weakref').WeakSet()     # live FilterPackPlans: their packs
 def invalidate_packs():
     """drop every cached bf16 filter pack (call after anything that writes parameters in place)"""
     _PACKS.clear()
+    _TRANSFORMS.clear()
     for p in list(_PLANS):
         p.fresh = False
 
@@ -420,14 +421,24 @@ def _workspace(nbytes, device):
     return ws
 
 
+_TRANSFORMS = {}                                  # dgrad filters of PARAMETERS, kept until the next weight update (invalidate_packs)
+
+
 def conv_weight_transform(w):
-    """HWIO (K,K,Cin,Cout) -> dgrad filter (K,K,Cout,Cin), taps rotated by 180 degrees."""
+    """HWIO (K,K,Cin,Cout) -> dgrad filter (K,K,Cout,Cin), taps rotated by 180 degrees.  A parameter's transform is
+    cached until the optimiser writes the weights (the discriminator is differentiated several times per solver step)."""
     _chk(w, "w", ndim=4)
+    cacheable = w.is_leaf and w.requires_grad
+    key = (w.data_ptr(), tuple(w.shape))
+    if cacheable and key in _TRANSFORMS:
+        return _TRANSFORMS[key][1]
     K, _, Cin, Cout = w.shape
     wt = torch.empty((K, K, Cout, Cin), dtype=torch.float32, device=w.device)
     lib = _lib.load()
     _lib.check(lib.sq_conv_weight_transform_f32(_ptr(w), _ptr(wt), K, Cin, Cout, _stream()),
                "sq_conv_weight_transform_f32")
+    if cacheable:
+        _TRANSFORMS[key] = (w, wt)
     return wt
 
 
