@@ -254,6 +254,7 @@ class GenerativeAdverserialNetwork(object):
         self._default_g = generator_fn is generator_network   # ActGate fusion needs the reference's wiring (single consumers)
         self.use_graph = bool(params.get('graph', False))    # replay the solver steps as hipGraphs
         self._graphs = {}
+        self._graph_alpha = {}                                  # last fade-in weight written into each graph's static tensor
         self._plan = None
         self._capture_stream = None
         self.dtype = params.get('dtype', 'f32')
@@ -530,6 +531,7 @@ class GenerativeAdverserialNetwork(object):
         if entry == 'warm':
             sx, sz = X.clone(), Z.clone()
             sa = torch.full((X.shape[0],), float(alpha), dtype=torch.float32, device=self.device)
+            self._graph_alpha[key] = float(alpha)
             sr = torch.empty((X.shape[0],), dtype=torch.float32, device=self.device) if kind == 'd' else None
             if self._capture_stream is None:
                 self._capture_stream = torch.cuda.Stream(device=self.device)
@@ -545,7 +547,10 @@ class GenerativeAdverserialNetwork(object):
             opt.t = t_host                                      # the capture executed nothing
             entry = self._graphs[key] = (g_grad, g_adam, sx, sz, sa, sr, grads, losses, table)
         g_grad, g_adam, sx, sz, sa, sr, grads, losses = entry[:8]     # entry[8]: the Adam table the graph reads
-        sx.copy_(X), sz.copy_(Z), sa.fill_(float(alpha))
+        sx.copy_(X), sz.copy_(Z)
+        if self._graph_alpha.get(key) != float(alpha):          # the fade-in weight is refilled only when it moves
+            sa.fill_(float(alpha))
+            self._graph_alpha[key] = float(alpha)
         if sr is not None:
             sr.copy_(self._mixing_r(X.shape[0]))
         g_grad.replay()
