@@ -384,6 +384,11 @@ int sq_conv2d_nhwc_fwd_mixed_f32(const float *x, const void *wp, const float *bi
  * dgrad in the GAN's first-order backward passes (gan.py:90-98 chains), same bits */
 int sq_conv2d_nhwc_dgrad_actgate_mixed_f32(const float *dy, const void *wp_t, const float *gate, int act, float *dx, int N,
                                            int H, int W, int Cin, int Cout, int K, void *stream);
+/* both forms on a batch of small images (Nimg, h, w, C) convolved as ONE mosaic image of R x Cc cells (sq_mosaic_pack_f32's
+ * layout, 3x3 only) without building it: loads, gate and stores address the compact tensors.  gate == NULL: forward with
+ * bias / act; gate != NULL: the act-gated dgrad (`act` = the gate's activation).  Same bits as pack -> conv -> unpack. */
+int sq_conv2d_nhwc_mixed_mosaic_f32(const float *x, const void *wp, const float *bias, const float *gate, float *y, int Nimg,
+                                    int h, int w, int Cin, int Cout, int act, int R, int Cc, void *stream);
 /* its weight gradient: dW (K,K,Cin,Cout) f32, db (Cout) f32 or NULL from f32 X and f32 dY (rounded to bf16 in
  * LDS); Cin % 16 == 0, Cout % 16 == 0. */
 int64_t sq_conv2d_nhwc_wgrad_workspace_mixed_f32(int N, int H, int W, int Cin, int Cout, int K);

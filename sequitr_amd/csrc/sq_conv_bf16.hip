@@ -61,7 +61,13 @@ struct SqDropEpi {
     // of the tensor itself -- 1/16 of its bytes
     unsigned char *mask = nullptr;
     const float *gate_f32 = nullptr;                            // FORM_GF (f32 tensors): (N,H,W,Cout) activation output, slope in gscale
-};
+    // MOS (f32 tensors): the image the kernel tiles is a MOSAIC of mos_n small images (mos_h x mos_w, cells of pitch
+    // h+1 / w+1 in a grid mos_cc wide, a zero row / column after every image standing in for the SAME padding --
+    // sq_mosaic_pack_f32's layout) that is never materialised: loads, the gate and the stores address the compact
+    // (mos_n, mos_h, mos_w, C) tensors directly, separator pixels read as zero and are not stored
+    int mos_h = 0, mos_w = 0, mos_cc = 0, mos_n = 0;
+    unsigned mos_mh = 0, mos_mw = 0;                            // ceil(2^16 / (h+1)), ceil(2^16 / (w+1)): q = (v * m) >> 16, exact for
+};                                                              // v < 2^13 at pitches <= 9 (set by the entry point)
 
 template <int BN, int KS, int KC>
 struct CfgB {
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
 //   5 GF: f32 tensors (the GAN's mixed form): the result leaves through the backward of the activation whose output
 //         `gate_f32` is -- dx = gate > 0 ? v : v * gscale -- the act_bwd pass that followed this dgrad
 enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4, FORM_GF = 5 };
-template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN>
+template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN, bool MOS = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const TIO *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
     TIO *__restrict__ y, int N, int H, int W, int Cin, int Cout, int act, int tiles_x, int tiles_y,
@@ -205,12 +211,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const int nitems = (t_end - t_begin) * nchunk;
     const bool restage_w = nchunk > 1;
 
+    const size_t io_pixels = MOS ? (size_t)drop.mos_n * drop.mos_h * drop.mos_w : (size_t)N * H * W;   // pixels behind x / y
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<TIO *>(x), 0, (int)((size_t)N * H * W * Cin * ES), 0x00020000);
+        const_cast<TIO *>(x), 0, (int)(io_pixels * Cin * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16 *>(wp), 0, (int)((size_t)nchunk * Cout * C::KP * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        y, 0, (int)((size_t)N * H * W * Cout * ES), 0x00020000);
+        y, 0, (int)(io_pixels * Cout * ES), 0x00020000);
     // dgrad fused with the upstream ReLU's backward: outputs pass only where gate (N,H,W,Cout) > 0
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16 *>(gate), 0, gate ? (int)((size_t)N * H * W * Cout * 2) : 0, 0x00020000);
@@ -220,15 +227,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
         drop.pool, 0, (PL && drop.pool) ? (int)((size_t)N * (H >> 1) * (W >> 1) * Cout * 2) : 0, 0x00020000);
 
+    // MOS: compact pixel index of mosaic pixel (gy, gx), or -1 for a separator / padding cell / outside
+    auto mos_pixel = [&](int gy, int gx) {
+        if ((unsigned)gy >= (unsigned)H || (unsigned)gx >= (unsigned)W) return -1;
+        const int cc = (int)(((unsigned)gx * drop.mos_mw) >> 16), xx = gx - cc * (drop.mos_w + 1);
+        const int rr = (int)(((unsigned)gy * drop.mos_mh) >> 16), yy = gy - rr * (drop.mos_h + 1);
+        const int im = rr * drop.mos_cc + cc;
+        return (xx < drop.mos_w && yy < drop.mos_h && im < drop.mos_n) ? (im * drop.mos_h + yy) * drop.mos_w + xx : -1;
+    };
+
     uint4 xr[C::XSLOTS][XV], wr[C::WSLOTS];
     int xrel[C::XSLOTS], xpy[C::XSLOTS], xpx[C::XSLOTS];
+    int xpix[MOS ? C::XSLOTS : 1];                              // MOS: compact pixel of every slot, recomputed per TILE (chunk 0)
 #pragma unroll
     for (int sl = 0; sl < C::XSLOTS; ++sl) {
         const int idx = tid + sl * 256;
         const int pix = idx / C::XQ, q = idx % C::XQ;
         xpy[sl] = pix / C::HALO_W;
         xpx[sl] = pix % C::HALO_W;
-        xrel[sl] = idx < C::XITEMS ? ((xpy[sl] * W + xpx[sl]) * Cin + q * 8) * ES : (int)OOB;
+        xrel[sl] = idx < C::XITEMS ? (MOS ? q * 8 * ES : ((xpy[sl] * W + xpx[sl]) * Cin + q * 8) * ES) : (int)OOB;
     }
     int wrel[C::WSLOTS];
 #pragma unroll
@@ -244,11 +261,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         const int base = (((n * H + y0) * W + x0) * Cin + chunk * KC) * ES;
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
-            const bool inb = (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
-                             xrel[sl] != (int)OOB;
+            bool inb;
+            unsigned off;
+            if constexpr (MOS) {
+                if (chunk == 0) xpix[sl] = xrel[sl] != (int)OOB ? mos_pixel(y0 + xpy[sl], x0 + xpx[sl]) : -1;
+                const int px = xpix[sl];                        // items of a tile are issued chunk 0 first
+                inb = px >= 0;
+                off = (unsigned)((px * Cin + chunk * KC) * ES + xrel[sl]);
+            } else {
+                inb = (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W && xrel[sl] != (int)OOB;
+                off = (unsigned)(base + xrel[sl]);
+            }
 #pragma unroll
             for (int h = 0; h < XV; ++h) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? (unsigned)(base + xrel[sl] + 16 * h) : OOB, 0, 0);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? off + 16 * h : OOB, 0, 0);
                 xr[sl][h] = *reinterpret_cast<const uint4 *>(&v);
             }
         }
@@ -434,15 +460,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gy = ty * TH + 4 * wv + r;
-                const bool ok = gy < H && gx < W && co < Cout;
-                offs[r] = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * ES) : OOB;
+                if constexpr (MOS) {
+                    const int px = co < Cout ? mos_pixel(gy, gx) : -1;
+                    offs[r] = px >= 0 ? (unsigned)((px * Cout + co) * ES) : OOB;
+                } else {
+                    const bool ok = gy < H && gx < W && co < Cout;
+                    offs[r] = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * ES) : OOB;
+                }
             }
             if constexpr (F32IO) {                              // f32 store of the f32 accumulators; no dropout
                 float4 gq[4];
                 (void)gq;
                 if constexpr (GF) {
                     const __amdgpu_buffer_rsrc_t gfrsrc = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<float *>(drop.gate_f32), 0, (int)((size_t)N * H * W * Cout * 4), 0x00020000);
+                        const_cast<float *>(drop.gate_f32), 0, (int)(io_pixels * Cout * 4), 0x00020000);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const auto gl = __builtin_amdgcn_raw_buffer_load_b128(gfrsrc, offs[r], 0, 0);
@@ -668,10 +699,13 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
     }
 }
 
-template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN>
+template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN, bool MOS = false>
 int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int H, int W, int Cin, int Cout,
            int act, hipStream_t st, const __bf16 *gate, const SqDropEpi &drop) {
-    if constexpr (FORM == FORM_PLAIN && sizeof(TIO) == 4) {
+    if constexpr (FORM == FORM_PLAIN && !MOS && sizeof(TIO) == 4) {
+        if (drop.mos_h && KS == 3)
+            return drop.gate_f32 ? launch<BN, KS, KC, TIO, FORM_GF, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop)
+                                 : launch<BN, KS, KC, TIO, FORM_PLAIN, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
         if (drop.gate_f32) return launch<BN, KS, KC, TIO, FORM_GF>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
     }
     if constexpr (FORM == FORM_PLAIN && KS == 3 && sizeof(TIO) == 2) {
@@ -684,7 +718,7 @@ int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int
     using C = CfgB<BN, KS, KC>;
     static bool attr_set = false;
     static int occ = 2;                                         // resident blocks per CU (registers / LDS)
-    auto kern = conv_mfma_bf16_kernel<BN, KS, KC, TIO, FORM>;
+    auto kern = conv_mfma_bf16_kernel<BN, KS, KC, TIO, FORM, MOS>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
@@ -855,6 +889,38 @@ extern "C" int sq_conv2d_nhwc_dgrad_actgate_mixed_f32(const float *dy, const voi
     d.gscale = act == SQ_ACT_LEAKY ? 0.2f : 0.0f;
     return dispatch_kc<float>(dy, reinterpret_cast<const __bf16 *>(wp_t), nullptr, dx, N, H, W, Cin, Cout, K, SQ_ACT_NONE,
                               reinterpret_cast<hipStream_t>(stream), nullptr, d);
+}
+
+// the two mixed-precision forms above on a BATCH OF SMALL IMAGES convolved as one mosaic image (R x Cc cells of pitch
+// h+1 / w+1, sq_mosaic_pack_f32's layout) without building the mosaic: x, gate, y / dx are the compact (Nimg, h, w, C)
+// tensors.  Same fmaf chain per output as the packed route (separator pixels read as zero, are not stored).  gate == NULL:
+// plain forward (bias / act apply); gate != NULL: the act-gated dgrad (bias and act ignored, `act` names the gate's activation).
+extern "C" int sq_conv2d_nhwc_mixed_mosaic_f32(const float *x, const void *wp, const float *bias, const float *gate, float *y,
+                                               int Nimg, int h, int w, int Cin, int Cout, int act, int R, int Cc,
+                                               void *stream) {
+    SQ_REQUIRE(x && wp && y, "sq_conv2d_nhwc_mixed_mosaic_f32: null tensor pointer");
+    SQ_REQUIRE(Nimg > 0 && h > 0 && w > 0 && R > 0 && Cc > 0 && (int64_t)R * Cc >= Nimg,
+               "sq_conv2d_nhwc_mixed_mosaic_f32: need R * Cc >= Nimg (Nimg=%d R=%d Cc=%d)", Nimg, R, Cc);
+    SQ_REQUIRE(Cin % 8 == 0 && Cin > 0 && Cout % 4 == 0 && Cout > 0,
+               "sq_conv2d_nhwc_mixed_mosaic_f32: Cin=%d (multiple of 8), Cout=%d (multiple of 4)", Cin, Cout);
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY && (!gate || act != SQ_ACT_NONE),
+               "sq_conv2d_nhwc_mixed_mosaic_f32: bad activation %d", act);
+    const int H = R * (h + 1), W = Cc * (w + 1);
+    SQ_REQUIRE((size_t)H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31), "sq_conv2d_nhwc_mixed_mosaic_f32: too large");
+    SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(wp); SQ_REQUIRE_ALIGNED(y);
+    if (bias) SQ_REQUIRE_ALIGNED(bias);
+    if (gate) SQ_REQUIRE_ALIGNED(gate);
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    SQ_REQUIRE(h <= 8 && w <= 8 && H < (1 << 13) && W < (1 << 13), "sq_conv2d_nhwc_mixed_mosaic_f32: images up to 8 x 8, mosaic < 8192");
+    d.mos_h = h; d.mos_w = w; d.mos_cc = Cc; d.mos_n = Nimg;
+    d.mos_mh = (65536u + (unsigned)h) / (unsigned)(h + 1);      // ceil(2^16 / (h+1))
+    d.mos_mw = (65536u + (unsigned)w) / (unsigned)(w + 1);
+    if (gate) {
+        d.gate_f32 = gate;
+        d.gscale = act == SQ_ACT_LEAKY ? 0.2f : 0.0f;
+    }
+    return dispatch_kc<float>(x, reinterpret_cast<const __bf16 *>(wp), gate ? nullptr : bias, y, 1, H, W, Cin, Cout, 3,
+                              gate ? (int)SQ_ACT_NONE : act, reinterpret_cast<hipStream_t>(stream), nullptr, d);
 }
 
 extern "C" int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H,

@@ -83,6 +83,7 @@ def mosaic_unpack(m, N, H, W, R, Cc):
 
 
 USE_DENSE = os.environ.get("SQ_DENSE", "1") != "0"        # A/B switch for the split-reduction dense kernel
+MOSAIC_IN_KERNEL = os.environ.get("SQ_MOSAIC_IN_KERNEL", "1") != "0"   # A/B: mosaic addressing inside the mixed conv
 
 # "mixed" convolutions: f32 tensors, bf16 multiply, f32 accumulate (sq_conv2d_nhwc_{fwd,wgrad}_mixed_f32).  While the
 # flag is set, conv2d / conv2d_dgrad / conv2d_wgrad route every layer the mixed kernels take (Cin % 8, Cout % 4;
@@ -261,6 +262,14 @@ def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None, _dgrad=False):
         if K == 1 and P % 16 == 0:                            # pixels are independent: a free view
             return conv2d(x.view(1, P // 16, 16, Cin), w, bias, act, wscale, _dgrad=_dgrad).view(N, H, W, Cout)
         plan = _mosaic_plan(N, H, W) if (K == 3 and Cin % 4 == 0 and Cout % 4 == 0) else None
+        if plan is not None and MOSAIC_IN_KERNEL and MIXED and Cin % 8 == 0:
+            # the mixed kernel addresses the compact tensors through the mosaic map itself: no pack / unpack launches
+            wp = _packed_filter(w, K, Cin, Cout, wscale, _dgrad)
+            y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.load().sq_conv2d_nhwc_mixed_mosaic_f32(_ptr(x), _ptr(wp), _ptr(bias), None, _ptr(y), N, H, W, Cin,
+                                                                  Cout, ACT[act], plan[0], plan[1], _stream()),
+                       "sq_conv2d_nhwc_mixed_mosaic_f32")
+            return y
         if plan is not None:
             ym = conv2d(mosaic_pack(x, *plan), w, bias, act, wscale, _dgrad=_dgrad)
             return mosaic_unpack(ym, N, H, W, *plan)
@@ -834,11 +843,21 @@ def conv_dgrad_actgate(dy, w, wscale, gate, act):
     N, H, W, C = dy.shape
     if not (MIXED and ACT[act] and C == Cout and Cout % 8 == 0 and Cin % 4 == 0):
         return None
-    if (USE_MOSAIC and W < 16 and N * H > 1) or (K == 1 and N * H * W <= 128 and Cout >= 1024 and USE_DENSE):
+    if K == 1 and N * H * W <= 128 and Cout >= 1024 and USE_DENSE:
         return None
     _chk(dy, "dy", ndim=4), _chk(gate, "gate", ndim=4)
     if tuple(gate.shape) != (N, H, W, Cin):
         return None
+    if USE_MOSAIC and W < 16 and N * H > 1:                     # the small-image levels: mosaic addressing, or the two ops
+        plan = _mosaic_plan(N, H, W) if (K == 3 and MOSAIC_IN_KERNEL) else None
+        if plan is None:
+            return None
+        wp = _packed_filter(w, K, Cout, Cin, wscale, True)
+        dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dy.device)
+        _lib.check(_lib.load().sq_conv2d_nhwc_mixed_mosaic_f32(_ptr(dy), _ptr(wp), None, _ptr(gate), _ptr(dx), N, H, W, Cout,
+                                                              Cin, ACT[act], plan[0], plan[1], _stream()),
+                   "sq_conv2d_nhwc_mixed_mosaic_f32")
+        return dx
     wp = _packed_filter(w, K, Cout, Cin, wscale, True)
     dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dy.device)
     _lib.check(_lib.load().sq_conv2d_nhwc_dgrad_actgate_mixed_f32(_ptr(dy), _ptr(wp), _ptr(gate), ACT[act], _ptr(dx), N, H, W,

@@ -135,3 +135,26 @@ def test_gan_solver_steps_in_mixed_mode(tmp_path):
     assert any(np.abs(after[k] - before[k]).max() > 0 for k in before)
     img = g.predict(latent=np.zeros((2, 1, 1, 512), np.float32))
     assert tuple(img.shape) == (2, 16, 16, 2) and img.dtype == torch.float32
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(32, 4, 4, 512, 512), (32, 8, 8, 256, 256), (8, 4, 4, 64, 32), (5, 8, 8, 32, 64),
+                                            (3, 4, 8, 16, 8)])
+def test_mosaic_addressing_inside_the_mixed_conv_equals_pack_conv_unpack(N, H, W, Cin, Cout, monkeypatch):
+    """sq_conv2d_nhwc_mixed_mosaic_f32 (the kernel addresses the compact small-image tensors through the mosaic map) against
+    mosaic_pack -> conv -> mosaic_unpack: forward with bias + leaky, dgrad, and the act-gated dgrad, bit for bit."""
+    x = torch.from_numpy(tiles(91, N, H, W, Cin)).cuda()
+    w = torch.from_numpy(rand_weights(92, (3, 3, Cin, Cout), 0.05)).cuda()
+    b = torch.from_numpy(rand_weights(93, (Cout,), 0.1)).cuda()
+    dy = torch.from_numpy(tiles(94, N, H, W, Cout)).cuda()
+    out = []
+    for inside in (True, False):
+        monkeypatch.setattr(ops, "MOSAIC_IN_KERNEL", inside)
+        with ops.mixed_precision():
+            y = ops.conv2d(x, w, b, act="leaky", wscale=0.7)
+            dx = ops.conv_dgrad_raw(dy, w, 0.7)
+            gated = ops.conv_dgrad_actgate(dy, w, 0.7, x, "leaky")
+            if gated is None:                                   # the unfused pair the tape runs where the fused form does not exist
+                gated = ops.act_bwd(dx, x, "leaky")
+        out.append((y, dx, gated))
+    for a, bb in zip(out[0], out[1]):
+        assert torch.equal(a, bb)
