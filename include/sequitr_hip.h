@@ -398,6 +398,10 @@ int sq_conv2d_nhwc_wgrad_mixed_f32(const float *x, const float *dy, float *dw, f
  * kernel is wscale * raw dW (gan.py:75-79); saves the scalar-multiply pass over every weight gradient */
 int sq_conv2d_nhwc_wgrad_scaled_mixed_f32(const float *x, const float *dy, float *dw, float *db, float *workspace, int N,
                                           int H, int W, int Cin, int Cout, int K, float dw_scale, void *stream);
+/* ... on a batch of small images (Nimg, h, w, C) taken as one mosaic image of R x Cc cells without building the mosaics
+ * (see sq_conv2d_nhwc_mixed_mosaic_f32); workspace as for (1, R*(h+1), Cc*(w+1), Cin, Cout, K = 3) */
+int sq_conv2d_nhwc_wgrad_mixed_mosaic_f32(const float *x, const float *dy, float *dw, float *db, float *workspace, int Nimg,
+                                          int h, int w, int Cin, int Cout, int R, int Cc, float dw_scale, void *stream);
 int sq_conv2d_nhwc_wgrad_scaled_f32(const float *x, const float *dy, float *dw, float *db, float *workspace, int N, int H,
                                     int W, int Cin, int Cout, int K, float dw_scale, void *stream);
 

@@ -77,10 +77,17 @@ __device__ __forceinline__ uint4 f32x8_to_bf16x8(const uint4 &a, const uint4 &b)
     return __builtin_bit_cast(uint4, h);
 }
 
-template <int KS, int NI, int NO, int PF, typename TIO>
+// MOS: the image the kernel tiles is a mosaic of mos.n small images (sq_conv_bf16.hip, SqDropEpi::mos_*; the layout of
+// sq_mosaic_pack_f32) that is never built: X and dY loads address the compact (n, h, w, C) tensors, separator pixels read 0
+struct SqMos {
+    int h = 0, w = 0, cc = 0, n = 0;
+    unsigned mh = 0, mw = 0;                                    // ceil(2^16 / (h+1)), ceil(2^16 / (w+1))
+};
+
+template <int KS, int NI, int NO, int PF, typename TIO, bool MOS = false>
 __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf16_kernel(
     const TIO *__restrict__ x, const TIO *__restrict__ dy, float *__restrict__ partials, int N, int H,
-    int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block) {
+    int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block, SqMos mos) {
     using C = WB<KS, NI, NO>;
     constexpr int PAD = KS / 2;
     constexpr int ES = (int)sizeof(TIO), XV = ES == 4 ? 2 : 1;  // 16-byte loads per 8-channel LDS item
@@ -92,11 +99,19 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
     const int ci0 = (blockIdx.y / nco) * C::CI, co0 = (blockIdx.y % nco) * C::CO;
     const int t_begin = blockIdx.x * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
 
+    const size_t io_pixels = MOS ? (size_t)mos.n * mos.h * mos.w : (size_t)N * H * W;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<TIO *>(x), 0, (int)((size_t)N * H * W * Cin * ES), 0x00020000);
+        const_cast<TIO *>(x), 0, (int)(io_pixels * Cin * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<TIO *>(dy), 0, (int)((size_t)N * H * W * Cout * ES), 0x00020000);
+        const_cast<TIO *>(dy), 0, (int)(io_pixels * Cout * ES), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
+    auto mos_pixel = [&](int gy, int gx) {                      // compact pixel of mosaic pixel (gy, gx), -1: separator / outside
+        if ((unsigned)gy >= (unsigned)H || (unsigned)gx >= (unsigned)W) return -1;
+        const int cc = (int)(((unsigned)gx * mos.mw) >> 16), xx = gx - cc * (mos.w + 1);
+        const int rr = (int)(((unsigned)gy * mos.mh) >> 16), yy = gy - rr * (mos.h + 1);
+        const int im = rr * mos.cc + cc;
+        return (xx < mos.w && yy < mos.h && im < mos.n) ? (im * mos.h + yy) * mos.w + xx : -1;
+    };
 
     // 16-byte items: item = (pixel, plane, half); a pixel's 32 NI bytes are contiguous in HBM.  The index
     // decode is redone per tile (a handful of integer ops) rather than kept in registers: the accumulators
@@ -123,8 +138,16 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
 #pragma unroll
         for (int sl = 0; sl < C::XSLOTS; ++sl) {
             const int py = xpos[sl] & 0xFFFF, px = xpos[sl] >> 16;
-            const bool inb = (unsigned)(y0 - PAD + py) < (unsigned)H && (unsigned)(x0 - PAD + px) < (unsigned)W;
-            const unsigned off = inb ? (unsigned)(xbase + xrel[sl]) : OOB;
+            bool inb;
+            unsigned off;
+            if constexpr (MOS) {
+                const int pc = py != 0x7FFF ? mos_pixel(y0 - PAD + py, x0 - PAD + px) : -1;
+                inb = pc >= 0;
+                off = (unsigned)((pc * Cin + ci0 + ((tid + sl * 256) % (2 * NI)) * 8) * ES);
+            } else {
+                inb = (unsigned)(y0 - PAD + py) < (unsigned)H && (unsigned)(x0 - PAD + px) < (unsigned)W;
+                off = inb ? (unsigned)(xbase + xrel[sl]) : OOB;
+            }
 #pragma unroll
             for (int h = 0; h < XV; ++h) {
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? off + 16 * h : OOB, 0, 0);
@@ -135,8 +158,16 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
         for (int sl = 0; sl < C::YSLOTS; ++sl) {
             const int idx = tid + sl * 256, pix = idx / (2 * NO), rem = idx % (2 * NO);
             const int py = pix / TW, px = pix % TW;
-            const bool inb = (y0 + py) < H && (x0 + px) < W;
-            const unsigned off = inb ? (unsigned)(ybase + ((py * W + px) * Cout + rem * 8) * ES) : OOB;
+            bool inb;
+            unsigned off;
+            if constexpr (MOS) {
+                const int pc = mos_pixel(y0 + py, x0 + px);
+                inb = pc >= 0;
+                off = (unsigned)((pc * Cout + co0 + rem * 8) * ES);
+            } else {
+                inb = (y0 + py) < H && (x0 + px) < W;
+                off = inb ? (unsigned)(ybase + ((py * W + px) * Cout + rem * 8) * ES) : OOB;
+            }
 #pragma unroll
             for (int h = 0; h < XV; ++h) {
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, inb ? off + 16 * h : OOB, 0, 0);
@@ -281,6 +312,7 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
 
 // factor the finish kernel applies to dW (not db): set by the *_scaled_* entry points around their dispatch, 1 otherwise
 thread_local float t_dw_scale = 1.0f;
+thread_local SqMos t_mos;                                       // set by sq_conv2d_nhwc_wgrad_mixed_mosaic_f32 around its dispatch
 // > 0: the launch is the 1x1 wgrad of a 2x2/s2 transpose conv in space-to-depth form (Cout = 4 * t_convT_cout); the
 // finish kernel then writes the transpose conv's own parameter layouts (sq_convT2x2s2_wgrad_bf16)
 thread_local int t_convT_cout = 0;
@@ -367,6 +399,46 @@ void plan(int N, int H, int W, int Cin, int Cout, int *gx, int *tpb, int64_t *ws
     *ws_floats = (int64_t)(*gx) * npairs * C::RED_FLOATS;
 }
 
+template <int KS, int NI, int NO>
+int finish(float *ws, float *dw, float *db, int gx, int Cin, int Cout, hipStream_t st) {
+    using C = WB<KS, NI, NO>;
+    const int npairs = (Cin / C::CI) * (Cout / C::CO);
+    int G = sq_group_size(gx);
+    if (G > 16) G = 16;                                         // >= 16 consecutive floats (64 B) per load of a group
+    const int64_t total = (int64_t)npairs * C::RED_FLOATS;
+    const int OUT = 256 / G;
+    hipLaunchKernelGGL((conv_wgrad_bf16_finish_kernel<KS, NI, NO>), dim3((unsigned)((total + OUT - 1) / OUT)), dim3(256), 0, st,
+                       ws, dw, db, gx, Cin, Cout, G, t_dw_scale, KS == 1 ? t_convT_cout : 0);
+    return sq_check_launch("sq_conv2d_nhwc_wgrad_bf16(finish)");
+}
+
+// the mosaic form (f32 tensors, 3x3): same plan, same finish; X / dY are the compact small-image tensors
+template <int KS, int NI, int NO, int PF>
+int launch_mos(const float *x, const float *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin, int Cout,
+               hipStream_t st) {
+    using C = WB<KS, NI, NO>;
+    static bool attr_set = false;
+    auto kern = conv_wgrad_bf16_kernel<KS, NI, NO, PF, float, true>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess) {
+            sq_set_error("conv_wgrad_bf16: cannot reserve %d bytes of LDS", C::LDS_BYTES);
+            return SQ_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    int gx, tpb;
+    int64_t wsf;
+    plan<KS, NI, NO>(N, H, W, Cin, Cout, &gx, &tpb, &wsf);
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int npairs = (Cin / C::CI) * (Cout / C::CO);
+    hipLaunchKernelGGL(kern, dim3(gx, npairs), dim3(256), C::LDS_BYTES, st, x, dy, ws, N, H, W, Cin, Cout, tiles_x, tiles_y,
+                       tiles_x * tiles_y * N, tpb, t_mos);
+    int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_mixed_mosaic_f32");
+    if (rc) return rc;
+    return finish<KS, NI, NO>(ws, dw, db, gx, Cin, Cout, st);
+}
+
 template <int KS, int NI, int NO, typename TIO>
 int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin,
            int Cout, hipStream_t st) {
@@ -376,6 +448,9 @@ int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, 
     constexpr int acc_regs = C::NTAP * NI * NO * 4, set_regs = (C::XSLOTS + C::YSLOTS) * 4 * (int)(sizeof(TIO) / 2);
     constexpr int budget = (wgrad_occ<KS, NI, NO>() == 1 ? 300 : SQ_WGRAD_BUDGET2) - acc_regs - 40;
     constexpr int PF = budget / set_regs >= 4 ? 4 : (budget / set_regs >= 3 ? 3 : (budget / set_regs >= 2 ? 2 : 1));
+    if constexpr (sizeof(TIO) == 4 && KS == 3) {
+        if (t_mos.h) return launch_mos<KS, NI, NO, PF>(x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
+    }
     auto kern = conv_wgrad_bf16_kernel<KS, NI, NO, PF, TIO>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -391,17 +466,12 @@ int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, 
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int npairs = (Cin / C::CI) * (Cout / C::CO);
     hipLaunchKernelGGL(kern, dim3(gx, npairs), dim3(256), C::LDS_BYTES, st, x, dy, ws, N, H, W, Cin, Cout, tiles_x,
-                       tiles_y, tiles_x * tiles_y * N, tpb);
+                       tiles_y, tiles_x * tiles_y * N, tpb, SqMos{});
     int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_bf16");
     if (rc) return rc;
-    int G = sq_group_size(gx);
-    if (G > 16) G = 16;                                         // >= 16 consecutive floats (64 B) per load of a group
-    const int64_t total = (int64_t)npairs * C::RED_FLOATS;
-    const int OUT = 256 / G;
-    hipLaunchKernelGGL((conv_wgrad_bf16_finish_kernel<KS, NI, NO>), dim3((unsigned)((total + OUT - 1) / OUT)), dim3(256), 0, st,
-                       ws, dw, db, gx, Cin, Cout, G, t_dw_scale, KS == 1 ? t_convT_cout : 0);
-    return sq_check_launch("sq_conv2d_nhwc_wgrad_bf16(finish)");
+    return finish<KS, NI, NO>(ws, dw, db, gx, Cin, Cout, st);
 }
+
 
 // SQ_WGRAD_BF16_NARROW=1: 16 x 16 channel blocks everywhere (A/B switch for the wider blocks);
 // SQ_WGRAD_BF16_MAX="ni,no": upper bound on the block shape (tuning experiments)
@@ -553,6 +623,26 @@ extern "C" int sq_convT2x2s2_wgrad_bf16(const void *x, const void *g, float *dw,
     t_convT_cout = Cout;
     const int rc = sq_conv2d_nhwc_wgrad_bf16(x, g, dw, db, workspace, N, H, W, Cin, 4 * Cout, 1, stream);
     t_convT_cout = 0;
+    return rc;
+}
+
+// the same on a batch of small images (Nimg, h, w, C) taken as ONE mosaic image of R x Cc cells (sq_mosaic_pack_f32's layout,
+// 3x3 only) without building the mosaics of X and dY: same sums as pack -> wgrad (separator pixels contribute zeros).
+// Workspace: sq_conv2d_nhwc_wgrad_workspace_bf16(1, R*(h+1), Cc*(w+1), Cin, Cout, 3).
+extern "C" int sq_conv2d_nhwc_wgrad_mixed_mosaic_f32(const float *x, const float *dy, float *dw, float *db, float *workspace,
+                                                     int Nimg, int h, int w, int Cin, int Cout, int R, int Cc, float dw_scale,
+                                                     void *stream) {
+    SQ_REQUIRE(Nimg > 0 && h > 0 && w > 0 && h <= 8 && w <= 8 && R > 0 && Cc > 0 && (int64_t)R * Cc >= Nimg,
+               "sq_conv2d_nhwc_wgrad_mixed_mosaic_f32: images up to 8 x 8, R * Cc >= Nimg (Nimg=%d R=%d Cc=%d)", Nimg, R, Cc);
+    const int H = R * (h + 1), W = Cc * (w + 1);
+    SQ_REQUIRE(H < (1 << 13) && W < (1 << 13), "sq_conv2d_nhwc_wgrad_mixed_mosaic_f32: mosaic < 8192");
+    t_mos.h = h; t_mos.w = w; t_mos.cc = Cc; t_mos.n = Nimg;
+    t_mos.mh = (65536u + (unsigned)h) / (unsigned)(h + 1);
+    t_mos.mw = (65536u + (unsigned)w) / (unsigned)(w + 1);
+    t_dw_scale = dw_scale;
+    const int rc = sq_conv2d_nhwc_wgrad_mixed_f32(x, dy, dw, db, workspace, 1, H, W, Cin, Cout, 3, stream);
+    t_dw_scale = 1.0f;
+    t_mos = SqMos{};
     return rc;
 }
 

@@ -480,6 +480,18 @@ def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None, dw_scale=1.
             return conv2d_wgrad(x.view(1, P // 16, 16, Cin), dy.view(1, P // 16, 16, Cout), K, want_bias,
                                 dw_out, db_out, dw_scale)
         plan = _mosaic_plan(N, H, W) if K == 3 else None
+        if plan is not None and MOSAIC_IN_KERNEL and MIXED:
+            lib = _lib.load()
+            MH, MW = plan[0] * (H + 1), plan[1] * (W + 1)
+            nbytes = lib.sq_conv2d_nhwc_wgrad_workspace_mixed_f32(1, MH, MW, Cin, Cout, K)
+            if nbytes >= 0:                                     # both channel counts % 16: the mixed kernel, mosaic addressed inside
+                ws = _workspace(nbytes, x.device)
+                dw = _grad_out(dw_out, (K, K, Cin, Cout), x.device)
+                db = _grad_out(db_out, (Cout,), x.device) if want_bias else None
+                _lib.check(lib.sq_conv2d_nhwc_wgrad_mixed_mosaic_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W,
+                                                                    Cin, Cout, plan[0], plan[1], float(dw_scale), _stream()),
+                           "sq_conv2d_nhwc_wgrad_mixed_mosaic_f32")
+                return dw, db
         if plan is not None:                                  # separator cells of dY are zero: they add nothing
             return conv2d_wgrad(mosaic_pack(x, *plan), mosaic_pack(dy, *plan), K, want_bias, dw_out, db_out, dw_scale)
     lib = _lib.load()

@@ -155,6 +155,7 @@ def test_mosaic_addressing_inside_the_mixed_conv_equals_pack_conv_unpack(N, H, W
             gated = ops.conv_dgrad_actgate(dy, w, 0.7, x, "leaky")
             if gated is None:                                   # the unfused pair the tape runs where the fused form does not exist
                 gated = ops.act_bwd(dx, x, "leaky")
-        out.append((y, dx, gated))
+            dw, db = ops.conv2d_wgrad(x, dy, 3, want_bias=True, dw_scale=0.7) if (Cin % 16 == 0 and Cout % 16 == 0) else (y, y)
+        out.append((y, dx, gated, dw, db))
     for a, bb in zip(out[0], out[1]):
         assert torch.equal(a, bb)
