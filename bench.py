@@ -63,13 +63,18 @@ def rank_setup():
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script, one per GPU, with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, and relay rank 0's single JSON line.  The parent never touches the
-    GPU (no torch.cuda call has run: `import torch` does not initialise HIP) and never re-execs itself; any failed
+    GPU (no torch.cuda call at all: `import torch` does not initialise HIP) and never re-execs itself; any failed
     child makes the exit code non-zero and ends the others (by PID)."""
     import socket
     import subprocess
     gloo = os.environ.get("SQ_BENCH_BACKEND", "nccl") == "gloo"
-    have = torch.cuda.device_count()                    # counts devices without initialising the runtime
-    if not gloo and have < n:
+    # The launcher must never initialise HIP (it fork+execs the ranks): the GPU count comes from the render nodes / KFD
+    # topology / *_VISIBLE_DEVICES (sequitr_amd/hwinfo.py), not from torch.cuda -- whose amdsmi route falls back to
+    # hipGetDeviceCount.  Unknown (None) or the gloo rehearsal: no check, a rank that cannot set its device exits
+    # non-zero and that exit code is propagated below.
+    from sequitr_amd.hwinfo import count_gpus
+    have = None if gloo else count_gpus()
+    if have is not None and have < n:
         sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (SQ_BENCH_BACKEND=gloo rehearses the N-rank "
                          "control flow on one card)\n" % (n, have))
         return 2
@@ -289,7 +294,7 @@ def parity_on_o1_fixture(params, device, with_cpu=True):
                                    "mask_bit_exact": bool(np.array_equal(gmask[:1], unet_oracle.predict_mask(ref))),
                                    "logits_max_abs_diff": float(np.abs(glog[:1] - ref).max())}
     if with_cpu:
-        threads = int(os.environ.get("SQ_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+        threads = int(os.environ.get("SQ_CPU_THREADS", min(os.cpu_count() or 1, 16)))    # a parity leg, not a timing
         cl = TorchCpuUNet(w, params, threads=threads)(xb)
         cm = np.argmax(cl, -1).astype(np.uint8)
         diff = gmask != cm
@@ -393,22 +398,39 @@ def timed_passes(fn, warm=3, timed=10, budget_s=12.0):
     return times, warm
 
 
+def cpu_thread_candidates():
+    """thread counts the CPU legs try (BASELINE.md section 3 / VERDICT r2 item 9): 16 (the 1-GPU box's CPU share), 64,
+    os.cpu_count() and the scheduler affinity of this process; SQ_CPU_THREADS pins one."""
+    if os.environ.get("SQ_CPU_THREADS"):
+        return [int(os.environ["SQ_CPU_THREADS"])]
+    ncpu = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = ncpu
+    return sorted({min(t, ncpu) for t in (16, 64, ncpu, aff) if t >= 1})
+
+
 def cpu_baseline(weights, params, gpu_net=None):
     """Bounded CPU sample as BASELINE.md section 3 prescribes: the torch-CPU (oneDNN, fp32, channels_last) restatement
-    of the same net on tiles of the same workload, batch 1 and batch 8, 3 warm-up + 10 timed passes each, median /
-    min / max, CPU model and thread count stated.  Never the thing shipped, only the reported baseline."""
+    of the same net on tiles of the same workload, threads in {16, 64, os.cpu_count()} x batch in {1, 8}, 3 warm-up +
+    <= 10 timed passes each (about 4 s per cell), median / min / max; `value` is the BEST cell's median with its thread
+    count and batch, CPU model stated.  Never the thing shipped, only the reported baseline."""
     from oracle.torch_ref import TorchCpuUNet
-    # a 1-GPU box owns a 16-core share of the host (more threads only thrash the cgroup)
-    threads = int(os.environ.get("SQ_CPU_THREADS", min(os.cpu_count() or 1, 16)))
-    net = TorchCpuUNet(weights, params, threads=threads)
     xb = np.random.default_rng(1).standard_normal((8, TILE, TILE, 1)).astype(np.float32)
-    rows = {}
-    for nb in (1, 8):
-        xin = xb[:nb]
-        times, warm = timed_passes(lambda: net(xin))
-        rate = [nb * TILE * TILE / t / 1e6 for t in times]
-        rows["batch_%d" % nb] = {"median": round(float(np.median(rate)), 3), "min": round(min(rate), 3),
-                                 "max": round(max(rate), 3), "warmup": warm, "timed": len(times)}
+    rows, best = {}, None
+    net = None
+    for threads in cpu_thread_candidates():
+        net = TorchCpuUNet(weights, params, threads=threads)
+        for nb in (1, 8):
+            xin = xb[:nb]
+            times, warm = timed_passes(lambda: net(xin), budget_s=4.0)
+            rate = [nb * TILE * TILE / t / 1e6 for t in times]
+            cell = {"median": round(float(np.median(rate)), 3), "min": round(min(rate), 3), "max": round(max(rate), 3),
+                    "warmup": warm, "timed": len(times), "threads": net.threads, "batch": nb}
+            rows["threads_%d_batch_%d" % (net.threads, nb)] = cell
+            if best is None or cell["median"] > best["median"]:
+                best = cell
     iou = near = None
     if gpu_net is not None:                       # matched-IoU check of the timed GPU net against this CPU run
         cpu_logits = net(xb)
@@ -416,14 +438,31 @@ def cpu_baseline(weights, params, gpu_net=None):
         gpu_mask = gpu_net.predict(torch.from_numpy(xb).to(gpu_net.device)).cpu().numpy()
         iou = [round(v, 6) for v in iou_per_class(gpu_mask, cpu_mask, gpu_net.n_outputs)]
         near = int((gpu_mask != cpu_mask).sum())
-    best = rows["batch_8"]
-    return {"value": best["median"], "unit": "Mpixels/s", "cores": net.threads, "kind": "port",
-            "cpu_model": cpu_model_name(), "os_cpu_count": os.cpu_count(), "passes": rows,
+    return {"value": best["median"], "unit": "Mpixels/s", "cores": best["threads"], "batch": best["batch"],
+            "kind": "port", "cpu_model": cpu_model_name(), "os_cpu_count": os.cpu_count(), "passes": rows,
             "iou_gpu_vs_cpu_per_class": iou, "pixels_differing_gpu_vs_cpu": near,
             "sample": "CPU restatement (torch-oneDNN fp32 channels_last, oracle/torch_ref.py) of the same U-Net, standing "
-                      "in for the reference TF-CPU path (TensorFlow not installable); value = median over %d timed "
-                      "passes of 8 x 512x512 tiles after 3 warm-up passes, %d threads; batch 1 beside it"
-                      % (best["timed"], net.threads)}
+                      "in for the reference TF-CPU path (TensorFlow not installable); threads x batch sweep, value = the "
+                      "best cell: median over %d timed passes of %d x 512x512 tiles after 3 warm-up passes, %d threads"
+                      % (best["timed"], best["batch"], best["threads"])}
+
+
+def best_cpu_threads(fn_for_threads, budget_s=6.0):
+    """pick the thread count for a slow CPU leg (training / GAN): one pass per candidate, fastest wins"""
+    cands = cpu_thread_candidates()
+    if len(cands) == 1:
+        return cands[0]
+    best, best_t = cands[0], None
+    for th in cands:
+        torch.set_num_threads(th)
+        t0 = time.perf_counter()
+        fn_for_threads()
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best, best_t = th, dt
+        if dt > budget_s:
+            break
+    return best
 
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
@@ -498,8 +537,6 @@ def cpu_baseline_train(params, x, onehot, wmap):
     unet_loss_and_grads: forward + weighted softmax-CE + backward) + a numpy Adam update, on 2 of the 16 tiles."""
     from oracle import torch_ref
     from sequitr_amd.networks.unet import init_unet_weights
-    threads = int(os.environ.get("SQ_CPU_THREADS", min(os.cpu_count() or 1, 16)))
-    torch.set_num_threads(threads)
     w = init_unet_weights(params, seed=0)
     m = {k: np.zeros_like(v) for k, v in w.items()}
     v2 = {k: np.zeros_like(v) for k, v in w.items()}
@@ -516,7 +553,9 @@ def cpu_baseline_train(params, x, onehot, wmap):
             m[k] = 0.9 * m[k] + 0.1 * g[k]
             v2[k] = 0.999 * v2[k] + 0.001 * g[k] * g[k]
             w[k] = (w[k] - lr_t * m[k] / (np.sqrt(v2[k]) + 1e-8)).astype(np.float32)
-    times, warm = timed_passes(one, warm=1, timed=5, budget_s=20.0)
+    threads = best_cpu_threads(one)                  # one pass per candidate thread count; the fastest is timed
+    torch.set_num_threads(threads)
+    times, warm = timed_passes(one, warm=1, timed=5, budget_s=15.0)
     rate = [nt * TILE * TILE / t / 1e6 for t in times]
     return {"value": round(float(np.median(rate)), 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
             "cpu_model": cpu_model_name(), "min": round(min(rate), 3), "max": round(max(rate), 3),
@@ -953,8 +992,6 @@ def cpu_baseline_gan(level=6, nb=2):
     float32) of one d_loss gradient + one g_loss gradient evaluation at level 6 on `nb` samples."""
     from oracle import torch_gan_ref as ref
     from sequitr_amd.networks.gan import GenerativeAdverserialNetwork
-    threads = int(os.environ.get("SQ_CPU_THREADS", min(os.cpu_count() or 1, 16)))
-    torch.set_num_threads(threads)
     g = GenerativeAdverserialNetwork({"num_levels": 7, "batch_size": nb, "device": "cuda:0", "seed": 0}, mode=None)
     g.build()
     sd = g.store.state_dict()
@@ -976,7 +1013,9 @@ def cpu_baseline_gan(level=6, nb=2):
             torch.autograd.grad(d_loss, [W[n] for n in d_names], allow_unused=True)
             _, _, g_loss = ref.losses(X, Z, 1.0, r, W, filters, level)
             torch.autograd.grad(g_loss, [W[n] for n in g_names], allow_unused=True)
-        times, warm = timed_passes(one, warm=1, timed=5, budget_s=20.0)
+        threads = best_cpu_threads(one)
+        torch.set_num_threads(threads)
+        times, warm = timed_passes(one, warm=1, timed=5, budget_s=15.0)
     finally:
         ref.DT = old
     rate = [nb * 256 * 256 / t / 1e6 for t in times]

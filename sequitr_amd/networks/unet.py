@@ -699,6 +699,18 @@ class UNet2DBf16(UNet2D):
             return FB.conv3x3_first(x, w, b, act='relu')
         return FB.conv2d(x, w, b, act='relu')
 
+    _WIRING = ('build', 'build_loss', 'down_layer', 'up_layer')
+
+    def _plain_wiring(self):
+        """The backward fusions that skip a gradient pass (BlockGate in the head / head + loss / up_junction / the
+        pool + skip pair, JunctionHandoff, the pool box) rest on the reference's wiring: a block output feeds the pool
+        and its skip junction, or the next up_layer, or the head, and nothing else (unet.py:241-253).  A subclass that
+        overrides the wiring (deep supervision, an extra skip) may consume net[-1] or `merged` twice; one gated and
+        one ungated contribution would then be summed and the producer would skip its activation backward.  So the
+        single-consumer promises are made only while build / build_loss / down_layer / up_layer are this class's own
+        (ADVICE r2); otherwise every tensor takes the ordinary tape entries -- same forward bits, full backward."""
+        return all(getattr(type(self), h) is getattr(UNet2DBf16, h) for h in self._WIRING)
+
     def conv_block(self, x, filters):
         """unet.py:265-277.  While neither conv_layer nor dropout_layer is overridden the block is one tape
         entry (FB.conv_block): same forward kernels, backward with the two ReLU gradients fused away."""
@@ -723,7 +735,7 @@ class UNet2DBf16(UNet2D):
         """unet.py:282-296.  Every encoder level but the last is followed by the max pool (unet.py:241-243): its block
         then writes the pooled tensor from conv2's epilogue (FB.conv_block(pool_follows=True)) and pool_layer picks it up."""
         self._pool_next = (self.training and self.fuse_block and isinstance(name, int) and name < len(self.filters) - 1
-                           and type(self).pool_layer is UNet2DBf16.pool_layer)
+                           and type(self).pool_layer is UNet2DBf16.pool_layer and self._plain_wiring())
         try:
             return UNet.down_layer(self, x, filters, name=name)
         finally:
@@ -734,14 +746,18 @@ class UNet2DBf16(UNet2D):
         if self.training:
             # build() hands the last block's output to the head and to nothing else (unet.py:252-253)
             labels = getattr(self, '_loss_inputs', None)
-            if labels is not None and x.shape[-1] in (16, 32) and filters <= 5:
-                self._loss = FB.conv1x1_head_loss(x, w, b, labels[0], labels[1], x_single_use=x is self._net[-1])
+            if labels is not None and x.shape[-1] in (16, 32) and filters <= 5 and self._plain_wiring():
+                self._loss = FB.conv1x1_head_loss(x, w, b, labels[0], labels[1], x_single_use=self._only_use(x))
                 self._head_wb = (w, b)
                 return self._loss                               # build_loss(): the loss stands in for the logits
-            return FB.conv1x1_head(x, w, b, x_single_use=x is self._net[-1])
+            return FB.conv1x1_head(x, w, b, x_single_use=self._only_use(x))
         from .. import ops_bf16 as ob
         logits, self._mask = ob.head_fwd(x, w, b)
         return logits
+
+    def _only_use(self, x):
+        """x is the last block's output and the caller is its only differentiable consumer (the reference's wiring)"""
+        return bool(self._net) and x is self._net[-1] and self._plain_wiring()
 
     def logits(self):
         """unet.py:220-222.  After build_loss() the logits were never stored: they are evaluated here, on demand,
@@ -771,7 +787,7 @@ class UNet2DBf16(UNet2D):
         return FB.convT2x2s2(x, self._kernel((2, 2, filters, x.shape[-1])), self._bias(filters))
 
     def pool_layer(self, x):
-        if self.training and self.fuse_block:
+        if self.training and self.fuse_block and self._plain_wiring():
             # the same tensor is the skip operand of a decoder junction later: share a box with it so the
             # junction's skip gradient is added inside this pool's backward (FB._MaxPool)
             box = {}
@@ -798,8 +814,8 @@ class UNet2DBf16(UNet2D):
             entry = self._skip_boxes.get(id(bridge))
             box = entry[1] if entry is not None and entry[0] is bridge else None
             # build() feeds net[-1] to this up_layer only (unet.py:248): its block gate can ride in the dgrad epilogue
-            merged = FB.up_junction(x, w, b, bridge, self.bridge_type, box, x_single_use=x is self._net[-1],
-                                    merged_single_use=True)     # merged goes straight into the block below
+            merged = FB.up_junction(x, w, b, bridge, self.bridge_type, box, x_single_use=self._only_use(x),
+                                    merged_single_use=type(self).conv_block is UNet2DBf16.conv_block)   # merged goes straight into the block below
             out = self.conv_block(merged, filters)
         return out
 

@@ -46,10 +46,15 @@ def epoch_schedule(n_items, batch, world):
     """Data-parallel epoch plan with the SAME number of full-batch steps on every rank (each step is one gradient
     all-reduce: ranks that disagree on the count dead-lock RCCL).  steps = (n_items // world) // batch; one seeded
     permutation of the whole stack per epoch is cut into world x steps x batch indices and the remainder of the
-    epoch is dropped.  Returns (order(epoch, rank) -> steps*batch item indices, steps).  Raises when a rank would
-    not get one full batch -- a short batch would be mis-weighted by Adam's 1/world gradient scale."""
+    epoch is dropped (a different remainder every epoch).  Returns (order(epoch, rank) -> steps*batch item indices,
+    steps); `order.batch` is the batch size actually used and `order.dropped` the tiles left out per epoch, for the
+    caller to log.  A single rank with fewer than `batch` tiles trains on one short batch per epoch (no collective can
+    dead-lock and Adam's gradient scale is 1); with world > 1 a rank without one full batch raises -- a short batch
+    would be mis-weighted by the 1/world gradient scale."""
     n_items, batch, world = int(n_items), int(batch), int(world)
-    steps = (n_items // world) // batch
+    if world == 1 and 0 < n_items < batch:
+        batch = n_items
+    steps = (n_items // world) // batch if batch > 0 else 0
     if steps < 1:
         raise ValueError("data-parallel training needs at least batch_size x world = %d x %d tiles, got %d"
                          % (batch, world, n_items))
@@ -59,6 +64,8 @@ def epoch_schedule(n_items, batch, world):
         import numpy as np
         perm = np.random.default_rng(int(epoch)).permutation(n_items)
         return perm[rank * per_rank:(rank + 1) * per_rank]
+    order.batch = batch
+    order.dropped = n_items - per_rank * world
     return order, steps
 
 

@@ -23,13 +23,10 @@ logger = logging.getLogger('server_process')
 
 
 def detect_gpus():
-    """Device names without initialising a GPU runtime in the server process."""
-    try:
-        import torch
-        n = torch.cuda.device_count()
-    except Exception:
-        n = 0
-    return ['/device:GPU:%d' % i for i in range(n)]
+    """Device names without initialising a GPU runtime in the server process (render nodes / KFD topology /
+    *_VISIBLE_DEVICES: sequitr_amd/hwinfo.py -- no torch.cuda call, the server forks one worker per job)."""
+    from .hwinfo import count_gpus
+    return ['/device:GPU:%d' % i for i in range(count_gpus() or 0)]
 
 
 def setup(config_file='server.config', jobdir='', logdir='', outdir='', modeldir=''):
@@ -60,6 +57,24 @@ class Server(object):
         self.python = python or sys.executable
         self.running = {}                                      # job file -> (Popen, gpu or None, JobWrapper)
         self.finished = []                                     # (job ID, return code)
+        self.unparsed = {}                                     # job file -> ((size, mtime_ns), polls seen unchanged)
+        self.settle = max(float(self.delay), 1.0)              # seconds a broken file must have been left alone
+
+    def _settled(self, fn):
+        """True once a file that does not parse has stopped changing: jobs are submitted by dropping files into the
+        polled folder, so a file caught mid-write (a non-atomic copy, NFS) must not be discarded -- the rename keeps
+        the inode and the finished job would land under .invalid and never run.  Settled = the same (size, mtime) on
+        two consecutive polls AND last written at least `settle` seconds ago."""
+        try:
+            st = os.stat(fn)
+        except OSError:
+            self.unparsed.pop(fn, None)
+            return False
+        sig = (st.st_size, st.st_mtime_ns)
+        seen, polls = self.unparsed.get(fn, (None, 0))
+        polls = polls + 1 if seen == sig else 1
+        self.unparsed[fn] = (sig, polls)
+        return polls >= 2 and time.time() - st.st_mtime >= self.settle
 
     def pending(self):
         """settled .job files, highest priority first (job header only: worker.py:42-84)"""
@@ -68,12 +83,14 @@ class Server(object):
             fn = os.path.join(self.jobdir, f)
             if not f.endswith('.job') or fn in self.running:
                 continue
-            job = worker.parse_job_file(fn, header_only=True)
+            job = worker.parse_job_file(fn, header_only=True, quiet=fn in self.unparsed)
             if job is not None:
+                self.unparsed.pop(fn, None)
                 jobs.append(job)
-            else:                                              # logged once by the parser; never polled again
+            elif self._settled(fn):                            # logged once here; never polled again
                 logger.error('Job file {0} cannot be parsed: renamed to .job.invalid'.format(fn))
                 os.rename(fn, fn + '.invalid')
+                self.unparsed.pop(fn, None)
         return sorted(jobs, key=lambda j: -int(j.priority))
 
     def _free_gpu(self):
@@ -120,7 +137,7 @@ class Server(object):
     def serve(self, once=False):
         while True:
             busy = self.poll_once()
-            if once and not busy and not self.pending():
+            if once and not busy and not self.pending() and not self.unparsed:
                 return self.finished
             time.sleep(self.delay if not once else min(self.delay, 0.2))
 

@@ -47,10 +47,14 @@ class UNetTrainer(object):
             self.pack_plan = PackPlan(self.pbucket.flat, {n: (self.net._vars[n], self.pbucket.offsets[n][0])
                                                          for n in self.pbucket.names})
         self.last_loss = None
-        # Adam's step counter lives on the device ({step, lr_t bits}) so a captured step replays correctly;
-        # the same counter salts the dropout seeds.
+        # Adam's step counter lives on the device ({step, lr_t bits}) so a captured step replays correctly.
         self.step_state = torch.zeros(2, dtype=torch.int32, device=dev)
-        self.net._step_dev = self.step_state
+        # The dropout salt is its own device counter: it advances once per forward/backward PASS (inside the captured
+        # graph), not once per optimiser step, and starts at a rank-dependent offset -- so the micro-batches of one
+        # accumulated step and the ranks of a data-parallel step all draw different masks (config 4's global batch
+        # of 128 sees 128 mask sets, not 16: ADVICE r2).
+        self.drop_salt = torch.full((1,), (self._rank() * 0x3C6EF35F) & 0x7FFFFFFF, dtype=torch.int32, device=dev)
+        self.net._step_dev = self.drop_salt
         self._graphs = None
 
     def load_state_dict(self, weights):
@@ -92,8 +96,13 @@ class UNetTrainer(object):
         else:
             loss = F.weighted_softmax_cross_entropy(self.net.build(x), onehot, weights)
         loss.backward()
+        self.drop_salt.add_(1)                                  # next pass, next masks (captured with the pass)
         self.last_loss = loss.detach()
         return self.last_loss
+
+    def _rank(self):
+        import torch.distributed as dist
+        return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
 
     def _world(self):
         import torch.distributed as dist
@@ -119,7 +128,7 @@ class UNetTrainer(object):
         GPUs).  Each micro-batch runs forward/backward (graph replay when captured); its gradient bucket is added,
         scaled by 1/k, into an accumulator (sq_axpy_f32), so after the last one the bucket holds the mean gradient
         of the rank's share; then the usual ONE all-reduce and ONE Adam launch.  Returns the mean loss.  The dropout
-        salt is the optimiser step counter, so the micro-batches of one step share their mask pattern."""
+        salt advances with every pass (and differs by rank), so every micro-batch draws its own masks."""
         k = len(micro_batches)
         if k == 1:
             return self.step(*micro_batches[0])

@@ -97,10 +97,19 @@ class JobWrapper(object):
         return parse_job_file(filename, header_only=header_only)
 
 
-@serverlogs.exception_logger
-def parse_job_file(filename, header_only=False):
+def parse_job_file(filename, header_only=False, quiet=False):
     """``<name>.job`` -> JobWrapper (None, with the reason logged, when the file is unusable).
-    header_only stops after identity + module/func: enough for a server to queue the job."""
+    header_only stops after identity + module/func: enough for a server to queue the job.
+    quiet: return None without logging (a server re-polling a file it has already reported once)."""
+    if quiet:
+        try:
+            return _parse_job_file(filename, header_only)
+        except Exception:                                      # noqa: BLE001 -- reported by the first, loud poll
+            return None
+    return _parse_job_file_logged(filename, header_only)
+
+
+def _parse_job_file(filename, header_only=False):
     if not isinstance(filename, str):
         raise Exception("Job filename is not correctly formed")
     if not filename.endswith('.job'):
@@ -128,6 +137,14 @@ def parse_job_file(filename, header_only=False):
         if lib_path and os.path.exists(lib_path):
             job._lib_path = lib_path
     return job
+
+
+@serverlogs.exception_logger
+def _parse_job_file_logged(filename, header_only=False):
+    return _parse_job_file(filename, header_only)
+
+
+_parse_job_file_logged.__wrapped__.__name__ = 'parse_job_file'     # the name the reference's log line carries
 
 
 def worker(args, log=True):

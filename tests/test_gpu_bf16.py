@@ -255,6 +255,41 @@ def test_fused_conv_block_backward_equals_the_unfused_tape():
         assert np.array_equal(ga[k], gb[k]), k
 
 
+def test_overridden_wiring_switches_the_single_consumer_fusions_off():
+    """the gate / handoff fusions promise that a block output has ONE differentiable consumer, which is the
+    reference's wiring (unet.py:241-253), not a property of every subclass.  A net whose build() reads the last block's
+    output twice (a second head: deep supervision) must get the full backward: loss and every gradient equal, bit for
+    bit, to the op-by-op tape (fuse_block=False), and the fusions must report themselves off."""
+    from sequitr_amd.train import UNetTrainer
+    from sequitr_amd.networks.unet import UNet2DBf16
+
+    class TwoHeads(UNet2DBf16):
+        def build(self, features):
+            logits = UNet2DBf16.build(self, features)
+            with self.variable_scope('UNet'), self.variable_scope('to_image'):      # the same head variables again
+                again = self.conv_layer_1x1(self._net[-2], self.n_outputs)
+            return logits + 0.5 * again
+
+    base = {"shape": (64, 64), "dropout": 0.4, "device": "cuda:0", "seed": 5, "filters": (16, 32, 64), "dtype": "bf16",
+            "fuse_head_loss": False}
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 64, 64, 1)).astype(np.float32)
+    lab = rng.random((2, 64, 64)) < 0.4
+    onehot = np.stack([~lab, lab], -1).astype(np.uint8)
+    wmap = (1 + rng.random((2, 64, 64, 1))).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to("cuda:0")
+    a = UNetTrainer(dict(base, fuse_block=True), net_cls=TwoHeads)
+    b = UNetTrainer(dict(base, fuse_block=False), net_cls=TwoHeads)
+    assert not a.net._plain_wiring() and UNetTrainer(dict(base)).net._plain_wiring()
+    la = a.forward_backward(d(x), d(onehot), d(wmap))
+    lb = b.forward_backward(d(x), d(onehot), d(wmap))
+    assert la.item() == lb.item()
+    ga, gb = a.grads(), b.grads()
+    for k in gb:
+        assert np.array_equal(ga[k], gb[k]), k
+    assert np.abs(ga["UNet/to_image/kernel"]).max() > 0
+
+
 def test_pack_plan_equals_the_single_packs():
     """PackPlan (one launch per step) writes exactly what pack_weights / to_bf16 write one by one."""
     from sequitr_amd.train import UNetTrainer

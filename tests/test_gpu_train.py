@@ -379,3 +379,31 @@ def test_step_accumulate_equals_one_big_batch_f32():
     y = torch.arange(1001, dtype=torch.float32, device="cuda:0")
     ops.axpy_(y[1:], x[1:], 0.5)                                 # misaligned views: scalar path
     assert torch.equal(y[1:], torch.arange(1, 1001, dtype=torch.float32, device="cuda:0") + 0.5) and y[0] == 0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_micro_batches_of_one_step_draw_different_dropout_masks(dtype):
+    """the dropout salt is a per-PASS device counter (and is offset by the rank), not the optimiser step,
+    so the k micro-batches of step_accumulate see k mask sets.  Two passes over the SAME tiles inside one step must
+    therefore give different losses / gradients (with one shared mask set they would be bit-identical), eager and
+    replayed, and the salt must count passes."""
+    params = {"shape": (64, 64), "dropout": 0.4, "device": "cuda:0", "seed": 3, "filters": (16, 32, 64), "dtype": dtype}
+    mb = tuple(dev(t) for t in _batch(31, 2, 64))
+    for graphed in (False, True):
+        t = UNetTrainer(params, learning_rate=0.003)
+        base = int(t.drop_salt.item())
+        if graphed:
+            t.capture(*mb, warmup=1)
+        l1 = t.forward_backward(*mb).item() if not graphed else None
+        if not graphed:
+            g1 = {k: v.copy() for k, v in t.grads().items()}
+            l2 = t.forward_backward(*mb).item()
+            g2 = t.grads()
+            assert l1 != l2 and any(not np.array_equal(g1[k], g2[k]) for k in g1)
+            assert int(t.drop_salt.item()) == base + 2
+        else:
+            t.step_accumulate([mb, mb, mb])
+            assert int(t.drop_salt.item()) == base + 1 + 3 and t.step_count == 2
+    # the same pass index gives the same masks on a fresh trainer (run-to-run reproducible)
+    a, b = UNetTrainer(params), UNetTrainer(params)
+    assert a.forward_backward(*mb).item() == b.forward_backward(*mb).item()

@@ -43,6 +43,14 @@ def test_epoch_schedule_same_step_count_on_every_rank_full_batches_only():
         assert not np.array_equal(order(0, 0), order(1, 0))                   # reshuffled every epoch
     with pytest.raises(ValueError):
         epoch_schedule(31, 16, 2)                                             # no rank may step with a short batch
+    # a single rank with a small stack trains on one short batch (no collective, gradient scale 1) ...
+    order, steps = epoch_schedule(5, 16, 1)
+    assert steps == 1 and order.batch == 5 and order.dropped == 0 and sorted(order(0, 0).tolist()) == list(range(5))
+    # ... and the tiles an epoch leaves out are reported for the caller to log
+    order, steps = epoch_schedule(63, 16, 2)
+    assert order.batch == 16 and order.dropped == 63 - 2 * 16
+    with pytest.raises(ValueError):
+        epoch_schedule(0, 16, 1)
 
 
 def _sched_worker(rank, world, port, ret):

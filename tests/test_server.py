@@ -54,3 +54,36 @@ def test_failed_and_unparsable_jobs_are_told_apart_from_finished_ones(tmp_path):
     assert done["good"] == 0 and done["bad"] != 0
     assert sorted(os.listdir(str(jobs))) == ["JOB_bad.job.failed", "JOB_garbage.job.invalid", "JOB_good.job.complete"]
     assert srv.pending() == []
+
+
+def test_a_job_file_caught_mid_write_is_not_discarded(tmp_path):
+    """ADVICE r2 (server.pending): jobs are submitted by dropping files into the polled folder, so the first poll can
+    see half a file.  It must be left alone (not renamed to .job.invalid -- the rename keeps the inode, the finished
+    content would land under .invalid and never run), picked up once the writer finishes, and only a file that has
+    stopped changing for `settle` seconds is invalidated."""
+    import time
+    jobs, out = tmp_path / "jobs", tmp_path / "out"
+    jobs.mkdir(), out.mkdir()
+    whole = write_job(jobs, func="SERVER_test", params="{}", options="{}", ID="late", name="JOB_tmp.job")
+    text = open(whole).read()
+    os.remove(whole)
+    fn = jobs / "JOB_late.job"
+    fn.write_text(text[:len(text) // 3])                                   # the copy has only started
+    srv = server.Server(str(jobs), str(out), gpus=[0], max_processes=1, delay=0.05)
+    srv.settle = 0.6
+    for _ in range(3):                                                     # several polls inside the settle window
+        assert srv.pending() == [] and os.path.exists(str(fn))
+        time.sleep(0.05)
+    fn.write_text(text)                                                    # the writer finishes
+    assert [j.ID for j in srv.pending()] == ["late"] and srv.unparsed == {}
+    done = dict(srv.serve(once=True))
+    assert done == {"late": 0} and os.listdir(str(jobs)) == ["JOB_late.job.complete"]
+    # a file that stays broken is invalidated, but only after it has been left alone for `settle` seconds
+    bad = jobs / "JOB_bad.job"
+    bad.write_text("[job]\nID = x\n")
+    t0 = time.time()
+    while os.path.exists(str(bad)):
+        assert srv.pending() == []
+        assert time.time() - t0 < 5
+        time.sleep(0.05)
+    assert time.time() - t0 >= 0.5 and os.path.exists(str(bad) + ".invalid")
