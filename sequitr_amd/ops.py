@@ -417,17 +417,100 @@ def wsoftmax_ce(logits, onehot, weights, want_grad=True, grad_scale=1.0):
 # ----------------------------------------------------------------------------------------------
 # training-side operators (gradients of the ops above; include/sequitr_hip.h "Training side")
 # ----------------------------------------------------------------------------------------------
-_WS_CACHE = {}
+class WorkspaceArena(object):
+    """Scratch memory for the kernels that take a caller-provided workspace (split reductions, block partials), with an
+    OWNER STREAM.  A workspace is one buffer that consecutive launches reuse; that is only sound while all of them are
+    ordered on one stream, and a captured hipGraph bakes the buffer's address into its kernel nodes.  Rules:
+
+      * the buffer only grows; a buffer that is replaced is RETIRED, never freed while the arena lives -- a captured
+        graph (or a kernel still in flight) may hold its address, and a block allocated during a capture belongs to
+        that graph's private pool, which the caching allocator returns to the driver once the graph is gone;
+      * outside a capture the arena belongs to the stream that used it last: a launch from another stream first makes
+        that stream wait for everything the previous owner enqueued (strict arenas -- SQ_WS_STRICT=1 or strict=True
+        -- raise instead, so that an accidental multi-stream schedule is noticed rather than serialised); `hand_over()`
+        is the explicit form a trainer calls when it moves between its warm-up, capture and replay streams;
+      * inside a capture every launch that uses the arena must come from ONE capturing stream: a stream forked inside
+        the capture (a side "lane") needs an arena of its own -- two lanes sharing one buffer is a race the graph does
+        not order -- and that always raises.
+
+    The library-wide default arena (one per device) serves callers that own nothing (the GAN, the stand-alone
+    operators); UNetTrainer and the captured predictors own theirs and select it with `use_arena`."""
+
+    def __init__(self, name='default', strict=None):
+        self.name = name
+        self.strict = (os.environ.get('SQ_WS_STRICT', '0') != '0') if strict is None else bool(strict)
+        self.buf = None
+        self.retired = []
+        self.owner = None                  # torch.cuda.Stream (a reference: its handle cannot be recycled under us)
+        self.capture_owner = None          # raw handle of the capturing stream seen first in the current capture
+
+    def _own(self, device):
+        cur = torch.cuda.current_stream(device)
+        if torch.cuda.is_current_stream_capturing():
+            if self.capture_owner is None:
+                self.capture_owner = cur.cuda_stream
+            elif self.capture_owner != cur.cuda_stream:
+                raise _lib.SequitrHipError(
+                    "workspace arena %r: used from two capturing streams (0x%x, 0x%x) -- a stream forked inside a "
+                    "capture needs its own WorkspaceArena" % (self.name, self.capture_owner, cur.cuda_stream))
+            return
+        self.capture_owner = None
+        if self.owner is None:
+            self.owner = cur
+        elif self.owner.cuda_stream != cur.cuda_stream:
+            if self.strict:
+                raise _lib.SequitrHipError(
+                    "workspace arena %r belongs to stream 0x%x, launch on stream 0x%x: call hand_over() (the new "
+                    "stream then waits for the old one) or give the second stream its own arena"
+                    % (self.name, self.owner.cuda_stream, cur.cuda_stream))
+            cur.wait_stream(self.owner)
+            self.owner = cur
+
+    def hand_over(self, stream=None):
+        """Make `stream` (default: the current one) the owner; it waits for all work of the previous owner."""
+        new = stream if stream is not None else torch.cuda.current_stream()
+        if self.owner is not None and self.owner.cuda_stream != new.cuda_stream:
+            new.wait_stream(self.owner)
+        self.owner = new
+        return self
+
+    def acquire(self, nbytes, device):
+        self._own(device)
+        if self.buf is None or self.buf.numel() * 4 < nbytes or self.buf.device != torch.device(device):
+            if self.buf is not None:
+                self.retired.append(self.buf)                    # its address may be baked into a captured graph
+            self.buf = torch.empty((max(int(nbytes), 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
+        return self.buf
+
+
+_DEFAULT_ARENAS = {}                              # device index -> the library-wide default arena
+_ARENA = [None]                                   # the arena of the object launching right now (see use_arena)
+
+
+class use_arena(object):
+    """`with use_arena(trainer.arena): ...` -- every workspace the block's launches ask for comes from that arena.
+    A plain module-level slot, not a thread-local: autograd runs the backward of these launches on its own device
+    thread, and one host thread drives one GPU (the reference's one-process-per-job model)."""
+
+    def __init__(self, arena):
+        self.arena, self.prev = arena, None
+
+    def __enter__(self):
+        self.prev, _ARENA[0] = _ARENA[0], self.arena
+        return self.arena
+
+    def __exit__(self, *exc):
+        _ARENA[0] = self.prev
 
 
 def _workspace(nbytes, device):
-    """Per-device scratch reused across launches on the same stream (caller-owned memory)."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
-    ws = _WS_CACHE.get(key)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty((max(int(nbytes), 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
-        _WS_CACHE[key] = ws
-    return ws
+    """Caller-owned scratch for one launch: from the active arena (use_arena) or the device's default arena."""
+    arena = _ARENA[0]
+    if arena is None:
+        arena = _DEFAULT_ARENAS.get(device.index)
+        if arena is None:
+            arena = _DEFAULT_ARENAS[device.index] = WorkspaceArena('default:%s' % (device.index,))
+    return arena.acquire(nbytes, device)
 
 
 _TRANSFORMS = {}                                  # dgrad filters of PARAMETERS, kept until the next weight update (invalidate_packs)

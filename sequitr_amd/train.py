@@ -47,6 +47,10 @@ class UNetTrainer(object):
             self.pack_plan = PackPlan(self.pbucket.flat, {n: (self.net._vars[n], self.pbucket.offsets[n][0])
                                                          for n in self.pbucket.names})
         self.last_loss = None
+        # Every workspace this trainer's launches use (split-K partials of the weight gradients, head / loss partials)
+        # comes from ITS arena: one buffer, one owner stream, never freed while a captured graph may hold its address
+        # (ops.WorkspaceArena; DESIGN 4b "the round-2 memory access fault").
+        self.arena = ops.WorkspaceArena('UNetTrainer')
         # Adam's step counter lives on the device ({step, lr_t bits}) so a captured step replays correctly.
         self.step_state = torch.zeros(2, dtype=torch.int32, device=dev)
         # The dropout salt is its own device counter: it advances once per forward/backward PASS (inside the captured
@@ -89,13 +93,14 @@ class UNetTrainer(object):
     def forward_backward(self, x, onehot, weights):
         """Leaves the (local) gradients in the flat gradient bucket; returns the loss tensor."""
         self.gbucket.flat.zero_()
-        if self.pack_plan is not None:
-            self.pack_plan.run()                                # every bf16 filter pack of the step, one launch
-        if self.fuse_head_loss and hasattr(self.net, 'build_loss'):
-            loss = self.net.build_loss(x, onehot, weights)      # bf16 graph: head + loss as one tape entry
-        else:
-            loss = F.weighted_softmax_cross_entropy(self.net.build(x), onehot, weights)
-        loss.backward()
+        with ops.use_arena(self.arena):
+            if self.pack_plan is not None:
+                self.pack_plan.run()                            # every bf16 filter pack of the step, one launch
+            if self.fuse_head_loss and hasattr(self.net, 'build_loss'):
+                loss = self.net.build_loss(x, onehot, weights)  # bf16 graph: head + loss as one tape entry
+            else:
+                loss = F.weighted_softmax_cross_entropy(self.net.build(x), onehot, weights)
+            loss.backward()
         self.drop_salt.add_(1)                                  # next pass, next masks (captured with the pass)
         self.last_loss = loss.detach()
         return self.last_loss
@@ -143,6 +148,7 @@ class UNetTrainer(object):
                     raise ValueError("UNetTrainer: captured for batch shape %s, got %s" % (tuple(sx.shape), tuple(x.shape)))
                 if x is not sx:
                     sx.copy_(x), so.copy_(onehot), sw.copy_(weights)
+                self.arena.hand_over()                          # the replay's launches use the arena on THIS stream
                 g_fb.replay()
                 loss = sloss
             else:
@@ -176,6 +182,7 @@ class UNetTrainer(object):
                 self.step(sx, so, sw)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.arena.hand_over()                                  # warm-up stream -> the stream the replays will run on
         world = self._world()
         g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_fb):
@@ -191,6 +198,7 @@ class UNetTrainer(object):
             raise ValueError("UNetTrainer: captured for batch shape %s, got %s" % (tuple(sx.shape), tuple(x.shape)))
         if x is not sx:
             sx.copy_(x), so.copy_(onehot), sw.copy_(weights)
+        self.arena.hand_over()
         g_fb.replay()
         allreduce_sum_(self.gbucket.flat, self.group)
         self.step_count += 1

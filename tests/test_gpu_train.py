@@ -407,3 +407,47 @@ def test_micro_batches_of_one_step_draw_different_dropout_masks(dtype):
     # the same pass index gives the same masks on a fresh trainer (run-to-run reproducible)
     a, b = UNetTrainer(params), UNetTrainer(params)
     assert a.forward_backward(*mb).item() == b.forward_backward(*mb).item()
+
+
+def test_workspace_arena_has_one_owner_stream_and_never_frees_a_baked_buffer(monkeypatch):
+    """every workspace has a stream owner.  (1) growth retires the old buffer (a captured graph may
+    hold its address); (2) a launch from a second stream makes that stream wait for the owner (or raises when the
+    arena is strict); (3) hand_over() is the explicit transfer; (4) two capturing streams sharing one arena always
+    raises; (5) a trainer's launches take ITS arena, not the library default, also in the autograd thread."""
+    from sequitr_amd._lib import SequitrHipError
+    d = torch.device("cuda:0")
+    a = ops.WorkspaceArena("t", strict=False)
+    b1 = a.acquire(1 << 20, d)
+    assert a.acquire(1000, d) is b1 and a.owner.cuda_stream == torch.cuda.current_stream().cuda_stream
+    b2 = a.acquire(8 << 20, d)
+    assert b2 is not b1 and a.retired == [b1] and b2.numel() * 4 >= 8 << 20
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        assert a.acquire(1000, d) is b2 and a.owner.cuda_stream == s.cuda_stream      # waited, then took ownership
+    strict = ops.WorkspaceArena("strict", strict=True)
+    strict.acquire(1000, d)
+    with torch.cuda.stream(s):
+        with pytest.raises(SequitrHipError, match="hand_over"):
+            strict.acquire(1000, d)
+        strict.hand_over()
+        strict.acquire(1000, d)
+    # inside a capture: one capturing stream per arena (checked on the ownership logic alone, no capture is opened)
+    cap = ops.WorkspaceArena("cap")
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    cap.acquire(1000, d)
+    with torch.cuda.stream(s):
+        with pytest.raises(SequitrHipError, match="two capturing streams"):
+            cap.acquire(1000, d)
+    monkeypatch.undo()
+    torch.cuda.synchronize()
+    # a trainer's workspaces come from its own arena (forward AND the autograd thread's backward)
+    params = {"shape": (32, 32), "dropout": 0.0, "device": "cuda:0", "seed": 3, "filters": (16, 32), "dtype": "bf16"}
+    t = UNetTrainer(params)
+    default = ops._DEFAULT_ARENAS.get(0)
+    before = None if default is None else (default.buf, len(default.retired))
+    assert t.arena.buf is None
+    t.forward_backward(*[dev(v) for v in _batch(5, 2, 32)])
+    assert t.arena.buf is not None and t.arena.owner.cuda_stream == torch.cuda.current_stream().cuda_stream
+    after = ops._DEFAULT_ARENAS.get(0)
+    assert (None if after is None else (after.buf, len(after.retired))) == before
+    assert ops._ARENA[0] is None
