@@ -520,6 +520,21 @@ def config3_inputs(dev, seed=2, nb=16, tile=TILE):
     return x, onehot, wmap
 
 
+def disk_image_inputs(dev, seed=2, nb=16, tile=TILE, noise=0.5):
+    """config 3's tensors with tiles that CARRY their labels (the matched-IoU training test / job): image = the disk
+    label plus N(0, noise) pixel noise, per-tile ImageNorm'd (sequitr/pipeline.py:350-356: (x - mean) / std), labels
+    and ImageWeightMap(10, 5) weights as config3_inputs.  Returns (x, onehot, wmap, lab) -- lab a host bool array."""
+    from sequitr_amd.weightmap import device_weightmaps
+    rng = np.random.default_rng(seed)
+    lab = disk_labels(rng, nb, tile)
+    img = lab.astype(np.float32) + noise * rng.standard_normal((nb, tile, tile)).astype(np.float32)
+    img = (img - img.mean(axis=(1, 2), keepdims=True)) / (1e-99 + img.std(axis=(1, 2), keepdims=True))
+    x = torch.from_numpy(img[..., None].astype(np.float32)).to(dev)
+    onehot = torch.from_numpy(np.stack([~lab, lab], -1).astype(np.uint8)).to(dev)
+    wmap = device_weightmaps(lab.astype(np.float32), 10., 5., device=dev)
+    return x, onehot, wmap, lab
+
+
 def pmc_step_traffic(tag):
     """HBM bytes per step from the committed rocprofv3 PMC passes of this mode (profiles/r*_pmc_<tag>_traffic.json:
     FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of the step; separate passes), with its source file; or None."""

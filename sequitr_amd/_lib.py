@@ -74,6 +74,7 @@ SIGNATURES = {
                       + [c_int64, c_int, c_void_p]),
     "sq_adam_step_dev_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 4 + [c_void_p, c_float, c_void_p]),
     "sq_adam_advance_dev": (c_int, [c_void_p, c_float, c_float, c_float, c_void_p]),
+    "sq_adam_advance_warmup_dev": (c_int, [c_void_p, c_float, c_float, c_float, c_int, c_void_p]),
     "sq_adam_apply_dev_f32": (c_int, [c_void_p] * 4 + [c_int64, c_float, c_float, c_float, c_void_p, c_float, c_void_p]),
     "sq_adam_multi_chunk": (c_int, []),
     "sq_adam_apply_multi_dev_f32": (c_int, [c_void_p, c_int, c_int64, c_float, c_float, c_float, c_void_p, c_float, c_void_p]),

@@ -309,11 +309,14 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float4 *__restri
 // Adam (tf.train.AdamOptimizer form): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps)
 // graph-safe step bookkeeping: the step counter lives in device memory, so a captured hipGraph
 // replays with the right bias correction.  state[0] = step (int32), state[1] = lr_t (float bits).
-__global__ void adam_prepare_kernel(int *__restrict__ state, float lr, float b1, float b2) {
+// warmup > 0: the learning rate ramps linearly, lr * min(1, t / warmup), evaluated on the device from the same counter
+// (a replayed graph walks the schedule by itself; the host never rewrites a kernel argument).
+__global__ void adam_prepare_kernel(int *__restrict__ state, float lr, float b1, float b2, int warmup) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const int t = state[0] + 1;
         state[0] = t;
-        const double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
+        const double ramp = (warmup > 0 && t < warmup) ? (double)t / (double)warmup : 1.0;
+        const double lr_t = (double)lr * ramp * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
         reinterpret_cast<float *>(state)[1] = (float)lr_t;
     }
 }
@@ -575,8 +578,15 @@ extern "C" int sq_axpy_f32(float *y, const float *x, float alpha, int64_t n, voi
 // slots): ONE advance per minimize(), then one apply per tensor
 extern "C" int sq_adam_advance_dev(int32_t *state, float lr, float beta1, float beta2, void *stream) {
     SQ_REQUIRE(state, "sq_adam_advance_dev: null state");
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, SQ_ST(stream), state, lr, beta1, beta2);
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, SQ_ST(stream), state, lr, beta1, beta2, 0);
     return sq_check_launch("sq_adam_advance_dev");
+}
+
+extern "C" int sq_adam_advance_warmup_dev(int32_t *state, float lr, float beta1, float beta2, int warmup_steps,
+                                          void *stream) {
+    SQ_REQUIRE(state && warmup_steps >= 0, "sq_adam_advance_warmup_dev: bad arguments");
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, SQ_ST(stream), state, lr, beta1, beta2, warmup_steps);
+    return sq_check_launch("sq_adam_advance_warmup_dev");
 }
 
 extern "C" int sq_adam_apply_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float beta1, float beta2,
@@ -605,7 +615,7 @@ extern "C" int sq_adam_apply_multi_dev_f32(const void *table, int n_entries, int
 extern "C" int sq_adam_step_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
                                     float beta2, float eps, int32_t *state, float grad_scale, void *stream) {
     SQ_REQUIRE(p && g && m && v && state && n > 0, "sq_adam_step_dev_f32: bad arguments");
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, SQ_ST(stream), state, lr, beta1, beta2);
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, SQ_ST(stream), state, lr, beta1, beta2, 0);
     int rc = sq_check_launch("sq_adam_step_dev_f32(prepare)");
     if (rc) return rc;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, SQ_ST(stream), p, g, m, v, n, 0.f, state, beta1,

@@ -229,11 +229,18 @@ def SERVER_train(params, options):
     params: images (.npy (N,H,W[,C]) float), labels (.npy (N,H,W) class indices or one-hot), weights
     (.npy (N,H,W[,1]); when absent computed with ImageWeightMap(w0, sigma), sequitr/pipeline.py:455-479, on
     the GPU -- sq_weightmap_edt_f32 -- and kept there), dtype ('f32' | 'bf16' activations), plus the
-    NetConfiguration keys (name, shape, num_outputs,
-    learning_rate, num_epochs, batch_size, dropout, filters, bridge, warm_start ...).
-    Under torchrun (WORLD_SIZE > 1) the tiles shard across ranks and gradients are all-reduced over
-    RCCL once per step.  Rank 0 saves ``weights.npz`` + ``net.config`` into the next numbered folder
-    of MODELDIR/<name>/ (sequitr/utils.py:143-223 layout) and ``train.json`` into params['output'].
+    NetConfiguration keys (name, shape, num_outputs, learning_rate, num_epochs, batch_size, dropout, filters,
+    bridge, warm_start ...) and warmup_steps (linear learning-rate warm-up).
+    options: gpu, max_steps, graph (default True: the step is captured once and replayed as hipGraphs).
+
+    The data path of a step never leaves the device: tiles, one-hot labels and weight maps are uploaded ONCE and stay
+    in HBM (2.6 MB per 512x512 tile against 288 GB; a stack above params['resident_gib'], default 64, is staged batch by
+    batch through pinned memory instead), an epoch's permutation is one index tensor, a batch is an index_select
+    straight into the captured step's static input buffers, the loss of every step lands in a device-side log that
+    is read back once per epoch (no per-step .item(): the host runs ahead of the GPU).  Under torchrun
+    (WORLD_SIZE > 1) the tiles shard across ranks and gradients are all-reduced over RCCL once per step, between
+    the two graphs.  Rank 0 saves ``weights.npz`` + ``net.config`` into the next numbered folder of MODELDIR/<name>/
+    (sequitr/utils.py:143-223 layout) and ``train.json`` (losses, ms_per_step) into params['output'].
     """
     import torch
     from . import utils
@@ -248,7 +255,11 @@ def SERVER_train(params, options):
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group('nccl', device_id=torch.device(device))
+            backend = os.environ.get('SQ_DIST_BACKEND', 'nccl')    # 'gloo': two ranks on one card (tests)
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=torch.device(device))
+            else:
+                dist.init_process_group(backend)
 
     cfg_keys = ('name', 'shape', 'num_inputs', 'num_outputs', 'num_epochs', 'learning_rate', 'warm_start', 'dropout')
     config = utils.NetConfiguration.from_params({k: params[k] for k in cfg_keys if k in params})
@@ -265,7 +276,7 @@ def SERVER_train(params, options):
     net_p = _net_params(params, device)
     net_p.setdefault('shape', tuple(x.shape[1:3]))
     net_p['dropout'] = float(params.get('dropout', 0.4))
-    trainer = UNetTrainer(net_p, learning_rate=config.learning_rate)
+    trainer = UNetTrainer(net_p, learning_rate=config.learning_rate, warmup_steps=params.get('warmup_steps'))
     if config.warm_start:
         latest = config.warm_start_from()
         if latest:
@@ -275,28 +286,94 @@ def SERVER_train(params, options):
     # Every rank must issue the SAME number of optimiser steps (each one is a gradient all-reduce), so the step count
     # comes from rank-independent quantities only and every step is a full batch: one seeded permutation of the whole
     # stack per epoch, cut into world x steps_per_epoch x batch indices; the remainder of the epoch is dropped.
-    batch = int(params.get('batch_size', 16))
-    order_fn, steps_per_epoch = epoch_schedule(x.shape[0], batch, world)
+    n_items = int(x.shape[0])
+    order_fn, steps_per_epoch = epoch_schedule(n_items, int(params.get('batch_size', 16)), world)
+    batch = order_fn.batch
+    if order_fn.dropped:
+        logger.info('{0} of {1} tiles are left out of every epoch ({2} ranks x {3} steps x batch {4}; a different '
+                    'remainder each epoch)'.format(order_fn.dropped, n_items, world, steps_per_epoch, batch))
     epochs = int(params.get('num_epochs', config.num_epochs))
     max_steps = options.get('max_steps')
-    losses = []
-    t0 = time.time()
+    total_steps = epochs * steps_per_epoch if not max_steps else min(int(max_steps), epochs * steps_per_epoch)
+
+    per_tile = int(np.prod(x.shape[1:])) * 4 + int(np.prod(onehot.shape[1:])) + int(np.prod(onehot.shape[1:3])) * 4
+    resident = n_items * per_tile <= float(params.get('resident_gib', 64)) * 2 ** 30
+    dev = torch.device(device)
+    if resident:                                               # the whole stack lives in HBM for the whole job
+        x_dev = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+        y_dev = torch.from_numpy(np.ascontiguousarray(onehot)).to(dev)
+        w_dev = wmap if isinstance(wmap, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(wmap)).to(dev)
+    bufs = [torch.empty((batch,) + tuple(x.shape[1:]), dtype=torch.float32, device=dev),
+            torch.empty((batch,) + tuple(onehot.shape[1:]), dtype=torch.uint8, device=dev),
+            torch.empty((batch,) + tuple(onehot.shape[1:3]) + (1,), dtype=torch.float32, device=dev)]
+
+    def load_batch(idx_dev, idx_host):
+        """fill the step's static input buffers with the tiles `idx` (device gather, or pinned staging)"""
+        sx, sy, sw = bufs
+        if resident:
+            torch.index_select(x_dev, 0, idx_dev, out=sx)
+            torch.index_select(y_dev, 0, idx_dev, out=sy)
+            torch.index_select(w_dev, 0, idx_dev, out=sw)
+        else:
+            ih = np.sort(idx_host)
+            sx.copy_(torch.from_numpy(np.ascontiguousarray(x[ih], dtype=np.float32)).pin_memory(), non_blocking=True)
+            sy.copy_(torch.from_numpy(np.ascontiguousarray(onehot[ih])).pin_memory(), non_blocking=True)
+            if isinstance(wmap, torch.Tensor):
+                torch.index_select(wmap, 0, torch.from_numpy(ih).to(dev), out=sw)
+            else:
+                sw.copy_(torch.from_numpy(np.ascontiguousarray(wmap[ih])).pin_memory(), non_blocking=True)
+
+    use_graph = bool(options.get('graph', True))
+    loss_log = torch.zeros(max(total_steps, 1), dtype=torch.float32, device=dev)
+    losses, done = [], 0
+    t_start = t_steady = time.time()
+    steady_from = 0
     for epoch in range(epochs):
-        order = order_fn(epoch, rank)
-        for s in range(steps_per_epoch):
-            idx = np.sort(order[s * batch:(s + 1) * batch])
-            xb = torch.from_numpy(np.ascontiguousarray(x[idx], dtype=np.float32)).to(device)
-            yb = torch.from_numpy(np.ascontiguousarray(onehot[idx])).to(device)
-            wb = (wmap[torch.from_numpy(idx).to(device)].contiguous() if isinstance(wmap, torch.Tensor)
-                  else torch.from_numpy(np.ascontiguousarray(wmap[idx])).to(device))
-            losses.append(float(trainer.step(xb, yb, wb).item()))
-            if max_steps and len(losses) >= max_steps:
-                break
-        if max_steps and len(losses) >= max_steps:
+        if done >= total_steps:
             break
+        order = order_fn(epoch, rank)
+        order_dev = torch.from_numpy(np.ascontiguousarray(order)).to(dev) if resident else None
+        first = done
+        for s in range(steps_per_epoch):
+            if done >= total_steps:
+                break
+            sl = slice(s * batch, (s + 1) * batch)
+            load_batch(order_dev[sl] if resident else None, order[sl])
+            if use_graph and done == 0:
+                # the first step runs eagerly (it warms every kernel up and sizes the workspaces), then the step is
+                # captured: (zero, forward, loss, backward) + (Adam), all-reduce between them; later batches are
+                # gathered straight into the capture's static buffers, so step() has nothing to copy
+                trainer.capture(*bufs, warmup=1)
+                bufs[:] = trainer.static_inputs
+                loss_log[0].copy_(trainer.last_loss)
+                torch.cuda.synchronize()
+                t_steady, steady_from = time.time(), 1         # ms_per_step is the replayed steady state
+            else:
+                loss_log[done].copy_(trainer.step(*bufs))
+            done += 1
+        losses.extend(float(v) for v in loss_log[first:done].cpu().numpy())      # ONE read-back per epoch
     torch.cuda.synchronize()
-    info = {'steps': len(losses), 'first_loss': losses[0], 'last_loss': losses[-1], 'seconds': time.time() - t0,
-            'world': world, 'device': device}
+    t_end = time.time()
+    steady = done - steady_from
+    info = {'steps': done, 'first_loss': losses[0], 'last_loss': losses[-1], 'seconds': t_end - t_start,
+            'ms_per_step': (t_end - t_steady) * 1e3 / steady if steady > 0 else None,
+            'steady_steps': steady, 'batch_size': batch, 'tiles': n_items, 'resident': bool(resident),
+            'graph': use_graph, 'dtype': str(net_p.get('dtype', 'f32')), 'warmup_steps': trainer.warmup_steps,
+            'learning_rate': config.learning_rate, 'world': world, 'device': device}
+    # replica check: data-parallel replicas apply the same all-reduced gradient to the same weights, so their
+    # parameters must agree bit for bit; two f64 sums of the flat parameter bucket are compared across the ranks
+    flat = trainer.pbucket.flat.double()
+    chk = torch.stack([flat.sum(), flat.abs().sum()])
+    info['param_checksum'] = [float(v) for v in chk.cpu()]
+    if world > 1:
+        import torch.distributed as dist
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        info['replicas_identical'] = bool(torch.equal(hi, lo))
+        if not info['replicas_identical']:
+            logger.error('data-parallel replicas have diverged: parameter checksums span {0} .. {1}'.format(
+                [float(v) for v in lo.cpu()], [float(v) for v in hi.cpu()]))
     if rank == 0:
         info['model_dir'] = utils.save_model(trainer.state_dict(), config)
         with open(os.path.join(params['output'], 'train.json'), 'w') as f:

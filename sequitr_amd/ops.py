@@ -1076,6 +1076,13 @@ def adam_advance_dev(state, lr, beta1, beta2):
                "sq_adam_advance_dev")
 
 
+def adam_advance_warmup_dev(state, lr, beta1, beta2, warmup_steps):
+    """adam_advance_dev with the linear warm-up lr * min(1, t / warmup_steps) evaluated on the device."""
+    _chk(state, "state", dtype=torch.int32)
+    _lib.check(_lib.load().sq_adam_advance_warmup_dev(_ptr(state), float(lr), float(beta1), float(beta2),
+                                                     int(warmup_steps), _stream()), "sq_adam_advance_warmup_dev")
+
+
 def adam_apply_dev(p, g, m, v, beta1, beta2, eps, state, grad_scale=1.0):
     """Adam update of one tensor with the {step, lr_t} of the last adam_advance_dev."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):

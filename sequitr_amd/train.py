@@ -15,15 +15,20 @@ from .networks.unet import UNet2D, UNet2DBf16, unet_variable_shapes, TRAIN
 from .parallel import FlatBucket, allreduce_sum_
 
 
+DEFAULT_WARMUP_STEPS = 0       # set from the round-3 learning-rate probe (tools/r03_lr_probe.py)
+
+
 class UNetTrainer(object):
     def __init__(self, params, learning_rate=0.01, beta1=0.9, beta2=0.999, epsilon=1e-8, group=None,
-                 net_cls=None, direct_grads=True):
+                 net_cls=None, direct_grads=True, warmup_steps=None):
         # params['dtype'] == 'bf16': bf16 activations + bf16 MFMA, fp32 master weights / Adam (configs 3-4)
         if net_cls is None:
             net_cls = UNet2DBf16 if str(params.get('dtype', 'f32')).lower() in ('bf16', 'bfloat16') else UNet2D
         self.net = net_cls(params, TRAIN)
         self.fuse_head_loss = bool(params.get('fuse_head_loss', True))      # A/B switch (tests compare both tapes)
         self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
+        # linear learning-rate warm-up over the first `warmup_steps` optimiser steps, walked on the device
+        self.warmup_steps = int(params.get('warmup_steps', DEFAULT_WARMUP_STEPS) if warmup_steps is None else warmup_steps)
         self.group = group
         self.step_count = 0
         dev = self.net.device
@@ -114,8 +119,9 @@ class UNetTrainer(object):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def _adam(self, world):
-        ops.adam_step_dev(self.pbucket.flat, self.gbucket.flat, self.m, self.v, self.lr, self.b1, self.b2, self.eps,
-                          self.step_state, grad_scale=1.0 / world)
+        ops.adam_advance_warmup_dev(self.step_state, self.lr, self.b1, self.b2, self.warmup_steps)
+        ops.adam_apply_dev(self.pbucket.flat, self.gbucket.flat, self.m, self.v, self.b1, self.b2, self.eps,
+                           self.step_state, grad_scale=1.0 / world)
 
     def step(self, x, onehot, weights):
         """One optimiser step on this rank's shard of the global batch."""

@@ -87,6 +87,49 @@ def test_train_job_then_segment_with_the_saved_model(tmp_path, monkeypatch):
     assert inter / union > 0.8                                  # IoU of the trained model on its own data
 
 
+def test_train_job_runs_the_captured_device_resident_step_at_config3_size(tmp_path, monkeypatch):
+    """SERVER_train IS the fast path -- the step bench.py --mode train times (UNetTrainer.capture,
+    graph replay) fed from tiles resident in HBM, one loss read-back per epoch.  A bf16 job on 32 tiles of 512x512
+    (batch 16, config 3's label / weight definitions) must report ms_per_step within 10 % of the same captured step
+    driven the way bench.py drives it, in this process; every loss finite and the loss falls."""
+    import torch
+    import bench
+    from sequitr_amd import core
+    from sequitr_amd.train import UNetTrainer
+    monkeypatch.setattr(core.TensorflowConfiguration, "MODELDIR", str(tmp_path / "models"))
+    os.mkdir(str(tmp_path / "models"))
+    d = torch.device("cuda:0")
+    parts = [bench.disk_image_inputs(d, seed=2 + k, nb=16) for k in range(2)]
+    np.save(str(tmp_path / "im.npy"), np.concatenate([p[0].cpu().numpy() for p in parts])[..., 0])
+    np.save(str(tmp_path / "lab.npy"), np.concatenate([p[3] for p in parts]).astype(np.uint8))
+    params = {"images": str(tmp_path / "im.npy"), "labels": str(tmp_path / "lab.npy"), "shape": (512, 512),
+              "num_outputs": 2, "learning_rate": 0.001, "num_epochs": 16, "batch_size": 16, "dropout": 0.4,
+              "seed": 0, "dtype": "bf16"}
+    fn = write_job(tmp_path, "JOB_t.job", func="SERVER_train", params=repr(params), options="{'gpu': 0}")
+    out = str(tmp_path / "out_t")
+    worker.worker(argparse.Namespace(job=fn, out=out))
+    logs = open(os.path.join(out, [f for f in os.listdir(out) if f.startswith("LOG_")][0])).read()
+    assert "exception" not in logs, logs
+    info = json.load(open(os.path.join(out, "train.json")))
+    assert info["steps"] == 32 and info["steady_steps"] == 31 and info["resident"] and info["graph"]
+    assert info["dtype"] == "bf16" and all(np.isfinite(info["losses"])) and info["last_loss"] < info["first_loss"]
+    # the same step, driven as bench.py --mode train drives it
+    x, onehot, wmap, _ = parts[0]
+    tr = UNetTrainer({"shape": (512, 512), "dropout": 0.4, "device": "cuda:0", "seed": 0, "dtype": "bf16"},
+                     learning_rate=0.001)
+    tr.capture(x, onehot, wmap, warmup=2)
+    for _ in range(10):
+        tr.step(x, onehot, wmap)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(31):
+        tr.step(x, onehot, wmap)
+    torch.cuda.synchronize()
+    bench_ms = (time.perf_counter() - t0) * 1e3 / 31
+    assert info["ms_per_step"] <= 1.10 * bench_ms, (info["ms_per_step"], bench_ms)
+
+
 def test_segment_job_writes_centroids(tmp_path):
     """options['centroids']: the step after the hot path (CentroidWriter, sequitr/utils.py:479-578) runs on
     the masks while they are still in HBM; rows equal the reference's scipy loop on the saved masks."""
