@@ -216,22 +216,26 @@ class ConvTimer(object):
         return ms, fl, sum(n for _, _, _, n in self.records)
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per conv_mfma launch (average over the 17 launches of a step) from the rocprofv3
-    PMC passes of THIS command, collected and corrected as MI355X_MICROARCH.md prescribes
-    (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE x2 on gfx950).  PMC counters cannot
-    be read from inside the timed run, so the committed summary is reported; None if absent."""
+def pmc_conv_traffic():
+    """HBM bytes of the conv_mfma launches from the rocprofv3 PMC passes of THIS command, collected and corrected as
+    MI355X_MICROARCH.md prescribes (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE x2 on gfx950): a dict
+    {per_step, per_launch, launches_per_step, algorithmic_per_step} or None.  PMC counters cannot be read from inside
+    the timed run, so the committed summary is reported."""
     import glob
     try:
         fn = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]   # newest round
         with open(fn) as f:
-            pmc_traffic_per_launch.source = os.path.relpath(fn, ROOT)
-            return round(json.load(f)["_summary"]["conv_mfma_hbm_bytes_per_launch_avg"], 1)
+            d = json.load(f)["_summary"]
+        pmc_conv_traffic.source = os.path.relpath(fn, ROOT)
+        return {"per_step": round(d["conv_mfma_hbm_bytes_per_step"], 1),
+                "per_launch": round(d["conv_mfma_hbm_bytes_per_launch_avg"], 1),
+                "launches_per_step": d.get("conv_mfma_launches_per_step"),
+                "algorithmic_per_step": d.get("conv_mfma_algorithmic_bytes_per_step")}
     except Exception:
         return None
 
 
-pmc_traffic_per_launch.source = None
+pmc_conv_traffic.source = None
 
 
 def pmc_mfma_busy():
@@ -586,12 +590,22 @@ def main_train(args):
     sharded over the ranks; a rank with more than 16 tiles runs them as micro-batches of 16 with gradient accumulation
     (UNetTrainer.step_accumulate) -- still one all-reduce and one Adam launch per step."""
     world, rank, dist, dev = rank_setup()
+    out = train_line(args, world, rank, dist, dev)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def train_line(args, world, rank, dist, dev):
+    """the training line as a dict (rank 0; None elsewhere) -- printed by main_train, or attached to the headline as
+    `train_bf16` by the default run"""
     from sequitr_amd.train import UNetTrainer
     from sequitr_amd.parallel import shard_range
     nb = 16
     params = {"shape": (TILE, TILE), "num_inputs": 1, "num_outputs": 2, "filters": FILTERS,
               "bridge": "eltwise_mul", "dropout": 0.4, "device": str(dev), "seed": 0, "dtype": args.dtype}
-    tr = UNetTrainer(params, learning_rate=0.01)
+    tr = UNetTrainer(params)                                         # the trainer's default learning rate + warm-up
     if args.scaling == "strong":
         g_tiles = args.global_tiles or 128
         lo, hi = shard_range(g_tiles // nb, rank, world)             # whole micro-batches of 16 per rank
@@ -640,6 +654,12 @@ def main_train(args):
         alg_bytes = 3.0 * e_fwd * esz * tiles_rank                   # layer-by-layer traffic, x3 with backward
         peak_tf = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         traffic, src = pmc_step_traffic("train_" + args.dtype)
+        # SURVEY 8d's COMPULSORY bytes of a step: what must cross HBM whatever the schedule -- the batch's inputs (image
+        # f32 + one-hot u8 x 2 + weight map f32 per pixel) and the optimiser state (read p, g, m, v; write p, m, v).  At
+        # these bytes the step is compute-bound (AI ~ 10^4 FLOP/B): the schedule bytes above are a property of running
+        # layer by layer, not a floor -- both fractions are reported so that `frac` is not read as "at a bound".
+        n_par = int(tr.pbucket.numel)
+        comp_bytes = float(tiles_rank) * TILE * TILE * (4 + 2 + 4) + 7.0 * 4 * n_par
         out = {"metric": "trained Mpixels/sec on 512x512 tiles (fwd+loss+bwd+allreduce+Adam)",
                "value": round(pix / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -663,6 +683,11 @@ def main_train(args):
                             "frac": round(alg_bytes / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                             "traffic": traffic, "traffic_source": src,
                             "algorithmic_bytes_per_step": alg_bytes, "device_ms_per_step": round(dev_ms, 4),
+                            "algorithmic_bytes_are": "the layer-by-layer schedule's activation traffic (SURVEY A.6 x 3), "
+                                                     "NOT a floor; compulsory bytes beside it",
+                            "compulsory_bytes_per_step": comp_bytes,
+                            "compulsory": {"achieved": round(comp_bytes / (dev_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                                           "frac": round(comp_bytes / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
                             "flops_per_step": flops,
                             "mfma": {"achieved": round(flops / (dev_ms * 1e-3) / 1e12, 2), "peak": peak_tf,
                                      "unit": "TFLOP/s", "frac": round(flops / (dev_ms * 1e-3) / 1e12 / peak_tf, 4)}}}
@@ -672,9 +697,8 @@ def main_train(args):
             except Exception as e:                              # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 def main_centroids(args):
@@ -1047,6 +1071,15 @@ def main_gan(args):
     one iteration = one d_solver + one g_solver (sequitr/networks/gan.py:850-851).  Always weak scaling: the
     reference's batch_size (32, gan.py:431) is per replica, and the minibatch-stdev statistic is per replica."""
     world, rank, dist, dev = rank_setup()
+    out = gan_line(args, world, rank, dist, dev)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def gan_line(args, world, rank, dist, dev):
+    """the GAN line as a dict (rank 0; None elsewhere) -- printed by main_gan, or attached to the headline as `gan_bf16`"""
     from sequitr_amd import ops as sq_ops
     from sequitr_amd.networks.gan import GenerativeAdverserialNetwork
     nb, level = 32, 6
@@ -1098,7 +1131,14 @@ def main_gan(args):
         mfma = {"achieved": round(wc.flops / (dev_ms * 1e-3) / 1e12, 2), "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": round(f_mfma, 4)}
         rl = dict(hbm if f_hbm >= f_mfma else mfma)
+        n_par = sum(int(v.numel()) for _, v in g.get_training_variables(level)[0]) + \
+            sum(int(v.numel()) for _, v in g.get_training_variables(level)[1])
+        comp_bytes = float(X.numel() * 4 + Z.numel() * 4) + 7.0 * 4 * n_par      # inputs + Adam's reads / writes of the two var lists
         rl.update({"bound": "hbm" if f_hbm >= f_mfma else "mfma",
+                   "algorithmic_bytes_are": "the op-by-op schedule's tensor traffic, NOT a floor; compulsory bytes beside it",
+                   "compulsory_bytes_per_step": comp_bytes,
+                   "compulsory": {"achieved": round(comp_bytes / (dev_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                                  "frac": round(comp_bytes / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
                    "kernel": "the whole iteration (d_solver + g_solver, two pairs of replayed hipGraphs); algorithmic "
                              "work counted op by op on one eager iteration: conv-family FLOPs (forward, dgrad, wgrad, "
                              "double-backward convs, dense) and the bytes of every operator's tensor arguments + results",
@@ -1124,9 +1164,8 @@ def main_gan(args):
             except Exception as e:                              # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 def main():
@@ -1138,6 +1177,8 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="--mode train / gan: compute dtype")
     ap.add_argument("--fuse-up", type=int, default=1, help="1 = convT+bridge of up0 inside its first conv (infer mode)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive rate (infer mode)")
+    ap.add_argument("--no-side-lines", action="store_true",
+                    help="infer mode: do not append the train_bf16 / gan_bf16 sub-objects (profiling passes)")
     ap.add_argument("--graph", type=int, default=1, help="--mode train / gan: replay the step as hipGraphs (1) or eager (0)")
     ap.add_argument("--fuse", type=int, default=1, help="0 = hook-by-hook kernels, 1 = fused inference kernels")
     ap.add_argument("--mode", choices=["infer", "infer-bf16", "train", "gan", "centroids", "weightmap", "weightmap2", "frontend"], default="infer",
@@ -1259,10 +1300,16 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": pmc_traffic_per_launch(),
+                # HBM bytes PER STEP over the conv launches (PMC) with the algorithmic bytes per step (in + out of
+                # every conv launch) beside it; per-launch average kept under its own, labelled key
+                "traffic": (pmc_conv_traffic() or {}).get("per_step"),
+                "traffic_is": "HBM bytes per step (all conv_mfma launches of one 32-tile pass), rocprofv3 PMC",
+                "algorithmic_bytes_per_step": (pmc_conv_traffic() or {}).get("algorithmic_per_step"),
+                "traffic_per_launch_avg": (pmc_conv_traffic() or {}).get("per_launch"),
+                "compulsory_bytes_per_step": float(x_all.shape[0]) * TILE * TILE * (4 + 8 + 1) + 4.0 * 1744994,
                 "mfma_busy_pmc": pmc_mfma_busy(),
-                # PMC counters cannot be read inside the timed run: these two come from committed rocprofv3 passes
-                "pmc_source": {"traffic": pmc_traffic_per_launch.source, "mfma_busy_pmc": pmc_mfma_busy.source},
+                # PMC counters cannot be read inside the timed run: these come from committed rocprofv3 passes
+                "pmc_source": {"traffic": pmc_conv_traffic.source, "mfma_busy_pmc": pmc_mfma_busy.source},
                 "launches_per_step": nlaunch // max(1, args.steps),
                 "kernel_ms_per_step": round(conv_ms / max(1, args.steps), 4),
                 "flops_per_step": conv_flops / max(1, args.steps),
@@ -1284,6 +1331,20 @@ def main():
                 out["end_to_end"] = end_to_end_rate(net, x)
             except Exception as e:                              # noqa: BLE001
                 out["end_to_end"] = {"value": None, "what": "failed: %r" % (e,)}
+        if world == 1 and not args.no_side_lines:
+            # BASELINE configs[2] and [4] in the driver's ONE command: the bf16 training step and
+            # the bf16 GAN iteration, 20 timed steps each after capture, each with its own roofline + cpu_baseline.
+            # Same guard as above: a side measurement never costs the headline.
+            del net, x_all, chunks, x
+            torch.cuda.empty_cache()
+            side = argparse.Namespace(**vars(args))
+            side.steps, side.warmup, side.dtype, side.graph, side.scaling, side.global_tiles = 20, 5, "bf16", 1, "weak", 0
+            for key, fn in (("train_bf16", train_line), ("gan_bf16", gan_line)):
+                try:
+                    out[key] = fn(side, 1, 0, None, dev)
+                except Exception as e:                          # noqa: BLE001
+                    out[key] = {"value": None, "failed": repr(e)}
+                torch.cuda.empty_cache()
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

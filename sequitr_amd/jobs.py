@@ -276,7 +276,9 @@ def SERVER_train(params, options):
     net_p = _net_params(params, device)
     net_p.setdefault('shape', tuple(x.shape[1:3]))
     net_p['dropout'] = float(params.get('dropout', 0.4))
-    trainer = UNetTrainer(net_p, learning_rate=config.learning_rate, warmup_steps=params.get('warmup_steps'))
+    # learning_rate: the job's own value when it gives one; otherwise the trainer's default, NOT NetConfiguration's 0.01
+    # (sequitr/utils.py:289), which diverges on the 5-level net under Adam (train.DEFAULT_LEARNING_RATE)
+    trainer = UNetTrainer(net_p, learning_rate=params.get('learning_rate'), warmup_steps=params.get('warmup_steps'))
     if config.warm_start:
         latest = config.warm_start_from()
         if latest:
@@ -359,7 +361,7 @@ def SERVER_train(params, options):
             'ms_per_step': (t_end - t_steady) * 1e3 / steady if steady > 0 else None,
             'steady_steps': steady, 'batch_size': batch, 'tiles': n_items, 'resident': bool(resident),
             'graph': use_graph, 'dtype': str(net_p.get('dtype', 'f32')), 'warmup_steps': trainer.warmup_steps,
-            'learning_rate': config.learning_rate, 'world': world, 'device': device}
+            'learning_rate': trainer.lr, 'world': world, 'device': device}
     # replica check: data-parallel replicas apply the same all-reduced gradient to the same weights, so their
     # parameters must agree bit for bit; two f64 sums of the flat parameter bucket are compared across the ranks
     flat = trainer.pbucket.flat.double()

@@ -2,8 +2,9 @@
 backward, one flat-bucket gradient all-reduce (data parallel) and a fused Adam update.
 
 The reference's U-Net model_fn / loss / optimiser are absent from the tree; the
-loss is SURVEY.md A.3, the optimiser is Adam in tf.train.AdamOptimizer form with the
-reference's `learning_rate` default 0.01 (sequitr/utils.py:289).  Parameters and gradients
+loss is SURVEY.md A.3, the optimiser is Adam in tf.train.AdamOptimizer form; its default learning
+rate and warm-up are this module's DEFAULT_* (the reference's `learning_rate` 0.01, sequitr/utils.py:289,
+diverges on this net -- see below).  Parameters and gradients
 live in two flat fp32 buffers (parallel.FlatBucket): one all-reduce, one optimiser launch.
 """
 import numpy as np
@@ -15,18 +16,28 @@ from .networks.unet import UNet2D, UNet2DBf16, unet_variable_shapes, TRAIN
 from .parallel import FlatBucket, allreduce_sum_
 
 
-DEFAULT_WARMUP_STEPS = 0       # set from the round-3 learning-rate probe (tools/r03_lr_probe.py)
+# Defaults from the round-3 probe on the BASELINE config-3 net (tools/r03_lr_probe.py, profiles/r03_lr_probe.txt,
+# DESIGN.md section 8): Adam's first update is +-lr on EVERY weight whatever the gradient's size; at the reference's
+# learning_rate 0.01 (sequitr/utils.py:289 -- a NetConfiguration field whose optimiser is absent upstream) that is 40 %
+# of a deep-layer weight (sigma 0.024) and the multiplicative bridges carry it to a loss of 1.8e15 on step 2; lr 0.003
+# still jumps to 4e5, lr 0.001 to 11, and a 20-step ramp to 7 (f32, step 15).  With lr 0.003 ramped linearly over the
+# first 40 steps the loss stayed within 1.03 x its initial value in every run (f32 / bf16, two weight + data seeds) and
+# the masks reach IoU ~0.9 with the labels between steps 60 and 100.  Both stay `params` keys.
+DEFAULT_LEARNING_RATE = 0.003
+DEFAULT_WARMUP_STEPS = 40
 
 
 class UNetTrainer(object):
-    def __init__(self, params, learning_rate=0.01, beta1=0.9, beta2=0.999, epsilon=1e-8, group=None,
+    def __init__(self, params, learning_rate=None, beta1=0.9, beta2=0.999, epsilon=1e-8, group=None,
                  net_cls=None, direct_grads=True, warmup_steps=None):
         # params['dtype'] == 'bf16': bf16 activations + bf16 MFMA, fp32 master weights / Adam (configs 3-4)
         if net_cls is None:
             net_cls = UNet2DBf16 if str(params.get('dtype', 'f32')).lower() in ('bf16', 'bfloat16') else UNet2D
         self.net = net_cls(params, TRAIN)
         self.fuse_head_loss = bool(params.get('fuse_head_loss', True))      # A/B switch (tests compare both tapes)
-        self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
+        if learning_rate is None:
+            learning_rate = params.get('learning_rate', DEFAULT_LEARNING_RATE)
+        self.lr, self.b1, self.b2, self.eps = float(learning_rate), beta1, beta2, epsilon
         # linear learning-rate warm-up over the first `warmup_steps` optimiser steps, walked on the device
         self.warmup_steps = int(params.get('warmup_steps', DEFAULT_WARMUP_STEPS) if warmup_steps is None else warmup_steps)
         self.group = group
@@ -190,12 +201,14 @@ class UNetTrainer(object):
         torch.cuda.synchronize()
         self.arena.hand_over()                                  # warm-up stream -> the stream the replays will run on
         world = self._world()
+        warm_loss = self.last_loss.clone()                      # the last warm-up step's loss (capturing runs nothing)
         g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_fb):
             sloss = self.forward_backward(sx, so, sw)
         with torch.cuda.graph(g_opt, pool=g_fb.pool()):
             self._adam(world)
         self._graphs = (g_fb, g_opt, sx, so, sw, sloss)
+        self.last_loss = warm_loss
         return self
 
     def _step_graphed(self, x, onehot, weights):

@@ -33,7 +33,31 @@ def test_flags_and_work_figures_cpu():
     a = np.array([[0, 1], [1, 1]])
     assert bench.iou_per_class(a, a) == [1.0, 1.0] and bench.iou_per_class(a, 1 - a) == [0.0, 0.0]
     # the committed PMC summary the line's roofline.traffic comes from
-    assert bench.pmc_traffic_per_launch() is None or bench.pmc_traffic_per_launch() > 1e8
+    t = bench.pmc_conv_traffic()
+    assert t is None or (t["per_step"] > 1e9 and abs(t["per_step"] - t["per_launch"] * t["launches_per_step"]) < 1e-3 * t["per_step"])
+
+
+def test_hwinfo_counts_gpus_without_a_runtime(tmp_path):
+    """launchers (bench.py --gpus N, the job server) count GPUs from render nodes / KFD topology / *_VISIBLE_DEVICES,
+    never through torch.cuda: fake trees stand in for /dev/dri and /sys/class/kfd."""
+    from sequitr_amd import hwinfo
+    dri, kfd = tmp_path / "dri", tmp_path / "nodes"
+    dri.mkdir(), kfd.mkdir()
+    for i in range(3):
+        (dri / ("renderD%d" % (128 + i))).write_text("")
+    (dri / "card0").write_text("")
+    for i, simd in enumerate((0, 0, 256, 256, 256, 256)):                  # two CPU nodes, four GPUs
+        (kfd / str(i)).mkdir()
+        (kfd / str(i) / "properties").write_text("cpu_cores_count 0\nsimd_count %d\n" % simd)
+    assert hwinfo.kfd_gpu_nodes(str(kfd)) == [2, 3, 4, 5]
+    assert hwinfo.count_gpus({}, str(kfd), str(dri)) == 3                  # the container was handed 3 render nodes
+    assert hwinfo.count_gpus({"ROCR_VISIBLE_DEVICES": "0,1"}, str(kfd), str(dri)) == 2
+    assert hwinfo.count_gpus({"HIP_VISIBLE_DEVICES": ""}, str(kfd), str(dri)) == 0
+    assert hwinfo.count_gpus({}, str(tmp_path / "none"), str(tmp_path / "none")) is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    launcher = src[src.index("def launch_ranks"):src.index("def mfma_conv_flops")]
+    code = [l.split("#")[0] for l in launcher.split('"""')[2].splitlines()]            # body without docstring / comments
+    assert not any("torch.cuda" in l for l in code)
 
 
 def test_gpus_n_launcher_fails_loudly_without_gpus():

@@ -67,7 +67,7 @@ def test_train_job_then_segment_with_the_saved_model(tmp_path, monkeypatch):
     np.save(str(tmp_path / "lab.npy"), np.broadcast_to(lab, (8, 64, 64)).copy())
     params = {"images": str(tmp_path / "im.npy"), "labels": str(tmp_path / "lab.npy"), "shape": (64, 64),
               "num_outputs": 2, "learning_rate": 0.003, "num_epochs": 12, "batch_size": 4, "dropout": 0.0,
-              "filters": (16, 32, 64), "seed": 0}
+              "filters": (16, 32, 64), "seed": 0, "warmup_steps": 0}
     fn = write_job(tmp_path, "JOB_t.job", func="SERVER_train", params=repr(params), options="{'gpu': 0}")
     out = str(tmp_path / "out_t")
     worker.worker(argparse.Namespace(job=fn, out=out))

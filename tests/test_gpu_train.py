@@ -168,7 +168,7 @@ def test_unet_training_with_pinned_dropout_masks_and_adam_step():
     rng = np.random.default_rng(5)
     shapes = [(2, 32, 32, 16), (2, 16, 16, 32), (2, 8, 8, 64), (2, 16, 16, 32), (2, 32, 32, 16)]   # call order
     masks = [(rng.random(s) >= 0.4).astype(np.uint8) for s in shapes]
-    t = UNetTrainer(params, learning_rate=0.01)
+    t = UNetTrainer(params, learning_rate=0.01, warmup_steps=0)     # the plain Adam formula below, no ramp
     w0 = t.state_dict()
     t.net.dropout_masks = [dev(m) for m in masks]
     loss = t.step(dev(x), dev(onehot), dev(wmap))
@@ -192,7 +192,7 @@ def test_training_reduces_loss():
     x = (lab[None, ..., None] * 2.0 + rng.standard_normal((4, 64, 64, 1)) * 0.5).astype(np.float32)
     onehot = np.broadcast_to(np.stack([~lab, lab], -1)[None], (4, 64, 64, 2)).astype(np.uint8).copy()
     wmap = np.ones((4, 64, 64, 1), np.float32)
-    t = UNetTrainer(params, learning_rate=0.003)
+    t = UNetTrainer(params, learning_rate=0.003, warmup_steps=0)
     losses = [t.step(dev(x), dev(onehot), dev(wmap)).item() for _ in range(25)]
     assert losses[-1] < 0.5 * losses[0], losses
 
@@ -335,6 +335,7 @@ def test_config3_full_size_bf16_training_step():
     la, lb = a.step(x, onehot, wmap).item(), b.step(x, onehot, wmap).item()
     la2, lb2, lc2 = a.step(x, onehot, wmap).item(), b.step(x, onehot, wmap).item(), c.step(x, onehot, wmap).item()
     assert np.isfinite(la) and la == lb and la2 == lb2 == lc2 and la2 != la
+    assert la2 < 10 * la                       # the default learning rate + warm-up: no step-2 blow-up (1.8e15 at lr 0.01)
     wa, wb, wc = a.state_dict(), b.state_dict(), c.state_dict()
     for k in wa:
         assert np.array_equal(wa[k], wb[k]) and np.array_equal(wa[k], wc[k]), k
@@ -451,3 +452,46 @@ def test_workspace_arena_has_one_owner_stream_and_never_frees_a_baked_buffer(mon
     after = ops._DEFAULT_ARENAS.get(0)
     assert (None if after is None else (after.buf, len(after.retired))) == before
     assert ops._ARENA[0] is None
+
+
+def test_matched_iou_training_at_config3_scale_f32_and_bf16():
+    """VERDICT r2 item 6 (north_star "at matched IoU"): the BASELINE config-3 net (5 levels, 512x512, dropout 0.4),
+    16 disk-label tiles (image = label + N(0, 0.5) noise, ImageNorm'd; labels = 60 random disks; ImageWeightMap(10, 5)
+    weights from the GPU EDT), 200 captured steps at the trainer's DEFAULT learning rate and warm-up, f32 and bf16:
+      * no blow-up: the loss never exceeds 1.1 x its initial value (lr 0.01 without warm-up: 1.8e15 on step 2);
+      * it falls: every 10-step mean is below the 10-step mean 30 steps earlier, final loss < 0.1 x first (the first
+        ~40 steps are noisy step to step -- Adam moving every weight by +-lr through four multiplicative bridges --,
+        so "monotone" is asserted on window means, not on consecutive steps);
+      * the trained net's masks (inference mode) reach foreground IoU >= 0.7 with the labels (measured ~0.93);
+      * |IoU_bf16 - IoU_f32| <= 0.02.
+    200 steps, not 60: with the default schedule the masks leave "all background" between steps 45 and 100 depending
+    on the seed (profiles/r03_lr_probe.txt) -- the net first fits the class prior, then the bridges open."""
+    import bench
+    from sequitr_amd.networks.unet import UNet2D, UNet2DBf16
+    from sequitr_amd import train as tr_mod
+    d = torch.device("cuda:0")
+    x, onehot, wmap, lab = bench.disk_image_inputs(d, seed=2, nb=16)
+    steps, ious, report = 200, {}, {}
+    for dtype, cls in (("f32", UNet2D), ("bf16", UNet2DBf16)):
+        params = {"shape": (512, 512), "dropout": 0.4, "device": "cuda:0", "seed": 0, "dtype": dtype}
+        t = UNetTrainer(params)
+        assert t.lr == tr_mod.DEFAULT_LEARNING_RATE and t.warmup_steps == tr_mod.DEFAULT_WARMUP_STEPS
+        t.capture(x, onehot, wmap, warmup=1)
+        log = torch.zeros(steps, device=d)
+        log[0].copy_(t.last_loss)
+        for k in range(1, steps):
+            log[k].copy_(t.step(x, onehot, wmap))
+        loss = log.cpu().numpy()
+        win = loss.reshape(-1, 10).mean(axis=1)
+        report[dtype] = [round(float(v), 4) for v in win]
+        assert np.isfinite(loss).all() and loss.max() <= 1.1 * loss[0], (dtype, float(loss.max()), int(loss.argmax()))
+        assert all(win[i + 3] < win[i] for i in range(len(win) - 3)), (dtype, report[dtype])
+        assert loss[-1] < 0.1 * loss[0], (dtype, loss[-1])
+        net = cls(dict(params, dropout=0.0), "infer")
+        net.load_state_dict(t.state_dict())
+        mask = net.predict(x).cpu().numpy().astype(bool)
+        ious[dtype] = float(np.logical_and(mask, lab).sum() / np.logical_or(mask, lab).sum())
+        del t, net
+    print("matched-IoU training: IoU", ious, "10-step loss means", report)
+    assert ious["f32"] >= 0.7 and ious["bf16"] >= 0.7, ious
+    assert abs(ious["f32"] - ious["bf16"]) <= 0.02, ious
