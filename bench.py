@@ -402,17 +402,42 @@ def timed_passes(fn, warm=3, timed=10, budget_s=12.0):
     return times, warm
 
 
-def cpu_thread_candidates():
-    """thread counts the CPU legs try (BASELINE.md section 3 / VERDICT r2 item 9): 16 (the 1-GPU box's CPU share), 64,
-    os.cpu_count() and the scheduler affinity of this process; SQ_CPU_THREADS pins one."""
-    if os.environ.get("SQ_CPU_THREADS"):
-        return [int(os.environ["SQ_CPU_THREADS"])]
+def usable_cpus():
+    """CPUs this process may really use: scheduler affinity clipped by the cgroup CPU quota (a 1-GPU box owns a
+    16-core share of a 256-thread host; os.cpu_count() still says 256)."""
     ncpu = os.cpu_count() or 1
     try:
-        aff = len(os.sched_getaffinity(0))
+        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
     except (AttributeError, OSError):
-        aff = ncpu
-    return sorted({min(t, ncpu) for t in (16, 64, ncpu, aff) if t >= 1})
+        pass
+    for fn in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(fn) as f:
+                tok = f.read().split()
+            if fn.endswith("cpu.max"):
+                quota, period = tok[0], float(tok[1])
+            else:
+                quota = tok[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                    period = float(f2.read().split()[0])
+            if quota not in ("max", "-1") and period > 0:
+                ncpu = min(ncpu, max(1, int(-(-float(quota) // period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return ncpu
+
+
+def cpu_thread_candidates():
+    """thread counts the CPU legs try (BASELINE.md section 3 / VERDICT r2 item 9): 16 (the 1-GPU box's CPU share), 64
+    and os.cpu_count(), each kept only while it is at most 4 x the CPUs this process may really use (usable_cpus():
+    256 threads on a 16-core cgroup share run 250 x slower than 16 and would cost the default run minutes);
+    SQ_CPU_THREADS pins one."""
+    if os.environ.get("SQ_CPU_THREADS"):
+        return [int(os.environ["SQ_CPU_THREADS"])]
+    ncpu, use = os.cpu_count() or 1, usable_cpus()
+    cands = sorted({min(t, ncpu) for t in (16, 64, ncpu, use) if t >= 1})
+    return [t for t in cands if t <= 4 * use] or [use]
 
 
 def cpu_baseline(weights, params, gpu_net=None):
@@ -424,8 +449,18 @@ def cpu_baseline(weights, params, gpu_net=None):
     xb = np.random.default_rng(1).standard_normal((8, TILE, TILE, 1)).astype(np.float32)
     rows, best = {}, None
     net = None
+    probe_best = None
     for threads in cpu_thread_candidates():
         net = TorchCpuUNet(weights, params, threads=threads)
+        net(xb[:1])                                             # primitive creation for this thread count
+        t0 = time.perf_counter()
+        net(xb[:1])
+        probe = time.perf_counter() - t0
+        if probe_best is not None and probe > 2.5 * probe_best:
+            # oversubscribed (the cgroup quota is not always visible): one probe pass says enough, no timed cells
+            rows["threads_%d" % net.threads] = {"skipped": "probe pass %.2f s vs %.2f s at fewer threads" % (probe, probe_best)}
+            break
+        probe_best = probe if probe_best is None else min(probe_best, probe)
         for nb in (1, 8):
             xin = xb[:nb]
             times, warm = timed_passes(lambda: net(xin), budget_s=4.0)
@@ -435,6 +470,8 @@ def cpu_baseline(weights, params, gpu_net=None):
             rows["threads_%d_batch_%d" % (net.threads, nb)] = cell
             if best is None or cell["median"] > best["median"]:
                 best = cell
+    if net.threads != best["threads"]:
+        net = TorchCpuUNet(weights, params, threads=best["threads"])
     iou = near = None
     if gpu_net is not None:                       # matched-IoU check of the timed GPU net against this CPU run
         cpu_logits = net(xb)
@@ -443,7 +480,8 @@ def cpu_baseline(weights, params, gpu_net=None):
         iou = [round(v, 6) for v in iou_per_class(gpu_mask, cpu_mask, gpu_net.n_outputs)]
         near = int((gpu_mask != cpu_mask).sum())
     return {"value": best["median"], "unit": "Mpixels/s", "cores": best["threads"], "batch": best["batch"],
-            "kind": "port", "cpu_model": cpu_model_name(), "os_cpu_count": os.cpu_count(), "passes": rows,
+            "kind": "port", "cpu_model": cpu_model_name(), "os_cpu_count": os.cpu_count(), "usable_cpus": usable_cpus(),
+            "passes": rows,
             "iou_gpu_vs_cpu_per_class": iou, "pixels_differing_gpu_vs_cpu": near,
             "sample": "CPU restatement (torch-oneDNN fp32 channels_last, oracle/torch_ref.py) of the same U-Net, standing "
                       "in for the reference TF-CPU path (TensorFlow not installable); threads x batch sweep, value = the "
@@ -464,6 +502,8 @@ def best_cpu_threads(fn_for_threads, budget_s=6.0):
         dt = time.perf_counter() - t0
         if best_t is None or dt < best_t:
             best, best_t = th, dt
+        elif dt > 1.5 * best_t:                        # more threads are already slower: larger counts will not help
+            break
         if dt > budget_s:
             break
     return best
