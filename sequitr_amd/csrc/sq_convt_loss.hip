@@ -1,5 +1,6 @@
 // conv_transpose_layer hook (sequitr/networks/unet.py:336-338) fused with the up_layer
 // bridge (unet.py:312-319), and the weighted softmax cross-entropy.
+#include <stdlib.h>
 #include "sq_common.h"
 
 namespace {
@@ -14,6 +15,12 @@ namespace {
 // KCH input channels are staged per barrier pair: 16 (any Cin % 16 == 0) or 32 when Cin % 32 == 0 (same chain, c
 // ascending).  Measured on the decoder's three launches (Cin 64 / 128 / 256): KCH 16: 124 us average, KCH 64: 149 us
 // (33.8 KB of LDS per block: half the resident blocks, and these launches live on occupancy).
+// Round 3: the block's memory round trips no longer queue up behind each other.  Before, a block paid one HBM latency per
+// staged chunk (load -> LDS -> barrier -> MFMA -> barrier, nothing in flight during the MFMAs) and one more in the
+// epilogue for the bridge operand: Cin / KCH + 1 serial round trips per block, 3.2 TB/s over the decoder's three
+// launches.  Now (i) the four bridge quads of a lane are requested before the first chunk and are in registers when the
+// epilogue needs them, (ii) chunk c + 1 is requested into registers before the MFMAs of chunk c and committed to LDS
+// after them (the T14 split staging of the conv kernels).  Same fmaf chains, same bits.
 template <int KCH>
 __global__ __launch_bounds__(256) void convT2x2_mfma_f32_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
@@ -27,28 +34,87 @@ __global__ __launch_bounds__(256) void convT2x2_mfma_f32_kernel(
     const int64_t p0 = (int64_t)blockIdx.x * 64;
     const int r0 = blockIdx.y * 64;
 
+    // ---- epilogue geometry first: the bridge operand is requested NOW -----------------------------------
+    const int rho = r0 + 16 * wv + 4 * kk;
+    const bool row_ok = rho < 4 * Cout;
+    const int ab = row_ok ? rho / Cout : 0, o = row_ok ? rho % Cout : 0;
+    const int pa = ab >> 1, pb = ab & 1;
+    size_t off[4];
+    bool ok[4];
+    float4 sk[4];
+    // pixel -> (n, i, j): ONE division pair per lane (32-bit whenever the pixel count allows: a 64-bit division is
+    // ~100 VALU instructions and the kernel issued 6 of them per lane for every 16 MFMAs), then the three other
+    // column blocks by carrying 16 pixels forward
+    int64_t nn;
+    int ii, jj;
+    {
+        const int64_t pl = p0 + li < P ? p0 + li : 0;
+        if (P < ((int64_t)1 << 31)) {
+            const unsigned pu = (unsigned)pl, t = pu / (unsigned)W;
+            jj = (int)(pu - t * (unsigned)W);
+            const unsigned n32 = t / (unsigned)H;
+            ii = (int)(t - n32 * (unsigned)H);
+            nn = n32;
+        } else {
+            jj = (int)(pl % W);
+            const int64_t t = pl / W;
+            ii = (int)(t % H);
+            nn = t / H;
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int64_t p = p0 + cb * 16 + li;
+        ok[cb] = row_ok && p < P;
+        off[cb] = ((size_t)(nn * 2 * H + 2 * ii + pa) * (2 * W) + 2 * jj + pb) * Cout + o;
+        sk[cb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bridge != SQ_BRIDGE_NONE && ok[cb]) sk[cb] = *reinterpret_cast<const float4 *>(skip + off[cb]);
+        jj += 16;                                               // next column block: 16 pixels on
+        while (jj >= W) {
+            jj -= W;
+            if (++ii == H) { ii = 0; ++nn; }
+        }
+    }
+
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && row_ok) bv = *reinterpret_cast<const float4 *>(bias + o);
+
     f32x4 acc[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     constexpr int QPR = KCH / 4;              // float4 per staged row
-    for (int cc = 0; cc < Cin; cc += KCH) {
+    constexpr int NIT = QPR / 4;              // staging: 64 rows x QPR float4 over 256 threads
+    float4 vr[NIT], ur[NIT];
+    auto issue = [&](int cc) {
 #pragma unroll
-        for (int it = 0; it < QPR / 4; ++it) {    // staging: 64 rows x QPR float4 over 256 threads
+        for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 256, srow = idx / QPR, sq = idx % QPR;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), u = make_float4(0.f, 0.f, 0.f, 0.f);
+            vr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ur[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r0 + srow < 4 * Cout)                           // ragged last row block (Cout % 16 != 0)
-                v = *reinterpret_cast<const float4 *>(w + (size_t)(r0 + srow) * Cin + cc + sq * 4);
+                vr[it] = *reinterpret_cast<const float4 *>(w + (size_t)(r0 + srow) * Cin + cc + sq * 4);
             if (p0 + srow < P)
-                u = *reinterpret_cast<const float4 *>(x + (size_t)(p0 + srow) * Cin + cc + sq * 4);
-            float *d = as + srow * CT_PS + sq * 4;
-            *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.y);
-            *reinterpret_cast<float2 *>(d + 2) = make_float2(v.z, v.w);
-            float *e = xs + srow * CT_PS + sq * 4;
-            *reinterpret_cast<float2 *>(e) = make_float2(u.x, u.y);
-            *reinterpret_cast<float2 *>(e + 2) = make_float2(u.z, u.w);
+                ur[it] = *reinterpret_cast<const float4 *>(x + (size_t)(p0 + srow) * Cin + cc + sq * 4);
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, srow = idx / QPR, sq = idx % QPR;
+            float *d = as + srow * CT_PS + sq * 4;
+            *reinterpret_cast<float2 *>(d) = make_float2(vr[it].x, vr[it].y);
+            *reinterpret_cast<float2 *>(d + 2) = make_float2(vr[it].z, vr[it].w);
+            float *e = xs + srow * CT_PS + sq * 4;
+            *reinterpret_cast<float2 *>(e) = make_float2(ur[it].x, ur[it].y);
+            *reinterpret_cast<float2 *>(e + 2) = make_float2(ur[it].z, ur[it].w);
+        }
+    };
+    issue(0);
+    for (int cc = 0; cc < Cin; cc += KCH) {
+        commit();
         __syncthreads();
+        if (cc + KCH < Cin) issue(cc + KCH);                    // in flight during this chunk's MFMAs
 #pragma unroll 4
         for (int s = 0; s < QPR; ++s) {
             const float a = as[(16 * wv + li) * CT_PS + s * 4 + kk];
@@ -62,30 +128,19 @@ __global__ __launch_bounds__(256) void convT2x2_mfma_f32_kernel(
         __syncthreads();
     }
 
-    const int rho = r0 + 16 * wv + 4 * kk;
-    if (rho >= 4 * Cout) return;                                // after the last barrier: safe to leave
-    const int ab = rho / Cout, o = rho % Cout;
-    const int a = ab >> 1, b = ab & 1;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) bv = *reinterpret_cast<const float4 *>(bias + o);
+    if (!row_ok) return;                                        // after the last barrier: safe to leave
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-        const int64_t p = p0 + cb * 16 + li;
-        if (p >= P) continue;
-        const int j = (int)(p % W);
-        const int64_t t = p / W;
-        const int i = (int)(t % H);
-        const int64_t n = t / H;
-        const size_t off = ((size_t)(n * 2 * H + 2 * i + a) * (2 * W) + 2 * j + b) * Cout + o;
+        if (!ok[cb]) continue;
         float4 v = make_float4(acc[cb][0] + bv.x, acc[cb][1] + bv.y, acc[cb][2] + bv.z, acc[cb][3] + bv.w);
         if (!bias) v = make_float4(acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]);
         if (bridge != SQ_BRIDGE_NONE) {
-            const float4 k = *reinterpret_cast<const float4 *>(skip + off);
+            const float4 k = sk[cb];
             if (bridge == SQ_BRIDGE_ADD) v = make_float4(v.x + k.x, v.y + k.y, v.z + k.z, v.w + k.w);
             else if (bridge == SQ_BRIDGE_MUL) v = make_float4(v.x * k.x, v.y * k.y, v.z * k.z, v.w * k.w);
             else v = make_float4(v.x - k.x, v.y - k.y, v.z - k.z, v.w - k.w);
         }
-        *reinterpret_cast<float4 *>(y + off) = v;
+        *reinterpret_cast<float4 *>(y + off[cb]) = v;
     }
 }
 
@@ -162,7 +217,8 @@ extern "C" int sq_convT2x2s2_nhwc_fwd_f32(const float *x, const float *w, const 
     if (skip) SQ_REQUIRE_ALIGNED(skip);
     const int64_t P = (int64_t)N * H * W;
     dim3 grid((unsigned)((P + 63) / 64), (unsigned)((4 * Cout + 63) / 64));
-    if (Cin % 32 == 0)
+    static const int kch = [] { const char *e = getenv("SQ_CONVT_KCH"); return e ? atoi(e) : 32; }();   // A/B switch
+    if (Cin % 32 == 0 && kch == 32)
         hipLaunchKernelGGL(convT2x2_mfma_f32_kernel<32>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                            x, w, bias, skip, y, P, H, W, Cin, Cout, bridge);
     else
