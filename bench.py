@@ -854,46 +854,68 @@ def main_weightmap(args):
 
 def main_weightmap2(args):
     """SURVEY 8f rank 2, second half: ImageWeightMap2 (pipeline.py:482-571) of 16 x 512x512 label tiles (config 3's
-    labels).  Host: boundary points + scipy Delaunay per tile; GPU: point location (simplex rasterisation), the
-    Gaussian and the weight expression (sq_weightmap2_delaunay_f32).  value = end to end incl. the host triangulation;
-    the roofline object is the device part.  CPU leg: the vectorised numpy/scipy restatement (oracle/weightmap_ref.py
-    image_weight_map2: the reference's own per-pixel Python loop takes 2.7 s per tile)."""
+    labels), labels resident in HBM.  One step = the whole map with NO scipy in it (round 3): boundary points on the
+    device (sq_wm2_boundary_points_u8) -> compaction -> D2H (~50 KB per tile) -> the library's exact integer Delaunay on
+    a pool of host threads (sq_delaunay2d_batch_i32) -> H2D -> point location by rasterisation, Gaussian, weight
+    expression (sq_weightmap2_delaunay_f32).  value = end to end; the roofline object is the device part.  CPU leg:
+    the vectorised numpy/scipy restatement (oracle/weightmap_ref.py image_weight_map2: the reference's own per-pixel
+    Python loop takes 2.7 s per tile)."""
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     from sequitr_amd import ops as sq_ops
-    from sequitr_amd.weightmap import boundary_triangulation
+    from sequitr_amd.weightmap import device_weightmaps2
     nb = 16
     lab = disk_labels(np.random.default_rng(2), nb)
-    t0 = time.perf_counter()
-    rows, longest = [], []
-    for n in range(nb):
-        v, l = boundary_triangulation(lab[n])
-        rows.append(np.concatenate([np.full((len(v), 1), n, np.int32), v.reshape(len(v), 6)], axis=1))
-        longest.append(l)
-    host_s = time.perf_counter() - t0
-    simp = torch.from_numpy(np.ascontiguousarray(np.concatenate(rows))).to(dev)
-    lng = torch.from_numpy(np.ascontiguousarray(np.concatenate(longest))).to(dev)
     img = torch.from_numpy(lab.astype(np.float32)).to(dev)
+    tri = os.environ.get("SQ_WM2_TRIANGULATION", "native")
+
+    def step():
+        return device_weightmaps2(img, 10., 5., device=dev, triangulation=tri)
     for _ in range(max(args.warmup, 1)):
-        w = sq_ops.weightmap_delaunay(img, simp, lng, 10., 5.)
+        w = step()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
+    t0 = time.perf_counter()
     for _ in range(args.steps):
-        w = sq_ops.weightmap_delaunay(img, simp, lng, 10., 5.)
+        w = step()
+    torch.cuda.synchronize()
+    step_s = (time.perf_counter() - t0) / args.steps
+    # the stages of one step, timed apart (host clock round synchronised stages; the device part also with events)
+    def clock(fn, reps=5):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps, r
+    t_pts, idx = clock(lambda: torch.nonzero(sq_ops.wm2_boundary_points(img)))
+    counts = torch.bincount(idx[:, 0], minlength=nb).cpu()
+    t_d2h, xy = clock(lambda: idx[:, 1:].to(torch.int32).cpu())
+    offsets = torch.zeros(nb + 1, dtype=torch.int64)
+    offsets[1:] = torch.cumsum(counts, 0)
+    t_tri, (simp, lng) = clock(lambda: sq_ops.delaunay2d_batch(xy, offsets))
+    t_h2d, (simp_d, lng_d) = clock(lambda: (simp.to(dev), lng.to(dev)))
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sq_ops.weightmap_delaunay(img, simp_d, lng_d, 10., 5.)
+    s.record()
+    for _ in range(10):
+        sq_ops.weightmap_delaunay(img, simp_d, lng_d, 10., 5.)
     e.record()
     torch.cuda.synchronize()
-    kms = s.elapsed_time(e) / args.steps
+    kms = s.elapsed_time(e) / 10
     npx = nb * TILE * TILE
     alg = npx * (8 + 4 + 8 + 8 + 8 * 2 + 4 + 4)                  # cover zero + image + cover read + tmp write/read(+halo) + image + f32 map
     res = {"metric": "Delaunay weight maps (ImageWeightMap2) Mpixels/sec on 512x512 label tiles",
-           "value": round(npx / (host_s + kms * 1e-3) / 1e6, 2), "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": round(host_s * 1e3 + kms, 3), "higher_is_better": True, "scaling": "weak",
+           "value": round(npx / step_s / 1e6, 2), "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "int64/f64", "data": "synthetic",
-           "config": {"workload": "ImageWeightMap2(w0=10, sigma=5) on 16 x 512x512 binary label tiles: host scipy "
-                                  "Delaunay of the boundary points, device point location + Gaussian + weights",
-                      "simplices": int(simp.shape[0]), "host_triangulation_ms": round(host_s * 1e3, 2),
-                      "device_ms": round(kms, 4)},
+           "config": {"workload": "ImageWeightMap2(w0=10, sigma=5) on 16 x 512x512 binary label tiles resident in HBM: device "
+                                  "boundary points, native exact Delaunay on host threads, device point location + Gaussian "
+                                  "+ weights (triangulation = %s)" % tri,
+                      "simplices": int(simp.shape[0]), "boundary_points": int(xy.shape[0]),
+                      "stage_ms": {"boundary_points_and_compaction": round(t_pts * 1e3, 3), "points_d2h": round(t_d2h * 1e3, 3),
+                                   "host_triangulation": round(t_tri * 1e3, 3), "simplices_h2d": round(t_h2d * 1e3, 3),
+                                   "device_raster_gauss_weights": round(kms, 4)},
+                      "host_threads": int(os.environ.get("SQ_HOST_THREADS", 16))},
            "roofline": {"bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(alg / (kms * 1e-3) / 8e12, 4), "traffic": None, "kernel_ms_per_step": round(kms, 4),
                         "algorithmic_bytes_per_pixel": 52}}
@@ -902,16 +924,18 @@ def main_weightmap2(args):
         t0 = time.perf_counter()
         ref = [weightmap_ref.image_weight_map2(lab[i].astype(np.float32)) for i in range(2)]
         ct = time.perf_counter() - t0
-        wn = w[:2].cpu().numpy()
-        err = max(float(np.abs(wn[i] - ref[i][..., 0]).max()) for i in range(2))
-        frac = float(np.mean([np.mean(np.abs(wn[i] - ref[i][..., 0]) > 1e-4) for i in range(2)]))
+        wn = w[:2].cpu().numpy()[..., 0]
+        bg = ~lab[:2]
+        err = np.abs(wn - np.stack([r[..., 0] for r in ref]))[bg]
         res["cpu_baseline"] = {"value": round(2 * TILE * TILE / ct / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-                               "sample": "vectorised numpy/scipy restatement with scipy's find_simplex "
+                               "sample": "vectorised numpy/scipy restatement with scipy's Delaunay + find_simplex "
                                          "(oracle/weightmap_ref.py) on 2 of the 16 tiles; the reference's per-pixel "
                                          "Python loop is ~20x slower still (2.7 s per tile)",
-                               "max_abs_diff_vs_cpu": err, "fraction_of_pixels_differing_by_1e-4": round(frac, 4),
-                               "why_they_differ": "pixels on simplex edges / vertices: scipy's walk is path dependent, the "
-                                                  "kernel takes the longest candidate (tests/test_gpu_weightmap.py)"}
+                               "mean_abs_diff_vs_cpu": float(err.mean()), "max_abs_diff_vs_cpu": float(err.max()),
+                               "fraction_of_background_pixels_off_by_0.25": round(float((err > 0.25).mean()), 4),
+                               "why_they_differ": "co-circular lattice points (Qhull's facet order picks the diagonal) and "
+                                                  "pixels on simplex edges (scipy's walk is path dependent, the kernel takes "
+                                                  "the longest candidate): tests/test_gpu_weightmap.py states the bounds"}
     print(json.dumps(res))
 
 

@@ -571,6 +571,18 @@ int sq_weightmap_edt_f32(const float *img, double *out64, float *out32, void *wo
  * pre-filter map (1024 where uncovered, 0 on foreground), applies scipy's gaussian_filter(sigma = 1) and the
  * reference's float64 expression.  out64 (N,H,W) and / or out32; workspace of sq_weightmap2_workspace bytes. */
 int64_t sq_weightmap2_workspace(int N, int H, int W);
+/* ImageWeightMap2's boundary points on the device (sequitr/pipeline.py:516-528: erosion outline of the label XOR the
+ * outline of the label dilated three times, von Neumann element, border value 0): points (N,H,W) uint8, 1 = a vertex
+ * of the triangulation.  img (N,H,W) binary f32. */
+int sq_wm2_boundary_points_u8(const float *img, uint8_t *points, int N, int H, int W, void *stream);
+/* HOST function (no GPU work): exact Delaunay triangulation of each tile's boundary points in place of
+ * scipy.spatial.Delaunay (pipeline.py:531-537) -- integer predicates in 128-bit arithmetic, incremental insertion in scan
+ * order, tiles on a small pool of host threads (SQ_HOST_THREADS, default 16).  xy = the (row, column) int32 pairs of
+ * `nsets` tiles back to back, tile s = points offsets[s] .. offsets[s+1] (0 <= coordinate < 32768, distinct); writes
+ * the (tile, x0, y0, x1, y1, x2, y2) rows and longest edges sq_weightmap2_delaunay_f32 takes; cap = 2 * offsets[nsets]
+ * rows always suffice.  Returns the number of rows, or a negative SQ_E* code. */
+int64_t sq_delaunay2d_batch_i32(const int32_t *xy, const int64_t *offsets, int nsets, int32_t *simplices, double *longest,
+                                int64_t cap);
 int sq_weightmap2_delaunay_f32(const float *img, const int32_t *simplices, const double *longest, int nsimp, double *out64,
                                float *out32, void *workspace, int N, int H, int W, double w0, double sigma, void *stream);
 

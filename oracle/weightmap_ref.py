@@ -62,17 +62,34 @@ def image_weight_map2(label, w0=10., sigma=5.):
     return _finish2(b, d, w0, sigma)
 
 
-def image_weight_map2_raster(label, w0=10., sigma=5.):
+def boundary_points(label):
+    """the boundary-point mask of pipeline.py:516-528 (what _boundary_delaunay triangulates), for the device kernel"""
+    from scipy.ndimage import binary_erosion, binary_dilation
+    s = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    b = np.squeeze(np.asarray(label).astype('bool'))
+    out = lambda m: np.logical_xor(binary_erosion(m, iterations=1, structure=s), m)
+    return np.logical_xor(out(b), out(binary_dilation(b, iterations=3, structure=s)))
+
+
+def image_weight_map2_raster(label, w0=10., sigma=5., vertices=None):
     """The same map with point location by RASTERISATION and the rule of sq_weightmap2_delaunay_f32: a pixel
     covered by several simplices (it lies on an edge / a vertex) takes the largest longest-edge.  Returns
     (map (H,W,1) float64, cover count (H,W) int: 0 = outside the hull, 1 = the reference's answer is determined,
-    >= 2 = tie pixel, where the reference returns whichever incident simplex scipy's walk reaches first)."""
-    b, tri = _boundary_delaunay(label)
-    longest = _longest_edges(tri)
+    >= 2 = tie pixel, where the reference returns whichever incident simplex scipy's walk reaches first).
+    vertices (S,3,2) int: rasterise THIS triangulation of the boundary points instead of scipy's (the library's own
+    exact Delaunay breaks co-circular ties differently from Qhull)."""
+    if vertices is None:
+        b, tri = _boundary_delaunay(label)
+        longest = _longest_edges(tri)
+        V = tri.points[tri.simplices].astype(np.int64)
+    else:
+        b = np.squeeze(np.asarray(label).astype('bool'))
+        V = np.asarray(vertices).astype(np.int64)
+        e = (V - np.roll(V, -1, axis=1)).astype(np.float64)
+        longest = np.sqrt((e ** 2).sum(-1)).max(-1)
     H, W = b.shape
     best = np.zeros((H, W))
     count = np.zeros((H, W), np.int32)
-    V = tri.points[tri.simplices].astype(np.int64)
     for k in range(len(V)):
         (x0, y0), (x1, y1), (x2, y2) = V[k]
         xa, xb, ya, yb = min(x0, x1, x2), max(x0, x1, x2), min(y0, y1, y2), max(y0, y1, y2)

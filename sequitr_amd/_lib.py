@@ -50,6 +50,8 @@ SIGNATURES = {
     "sq_weightmap_edt_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      ctypes.c_double, ctypes.c_double, c_void_p]),
     "sq_weightmap2_workspace": (c_int64, [c_int, c_int, c_int]),
+    "sq_wm2_boundary_points_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sq_delaunay2d_batch_i32": (c_int64, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64]),
     "sq_weightmap2_delaunay_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                            c_int, ctypes.c_double, ctypes.c_double, c_void_p]),
     "sq_frame_stats_workspace": (c_int64, [c_int, c_int, c_int]),

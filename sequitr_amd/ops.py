@@ -1260,6 +1260,41 @@ def weightmap_edt(img, w0=10.0, sigma=5.0, dtype=torch.float32):
     return out
 
 
+def wm2_boundary_points(img):
+    """ImageWeightMap2's boundary-point mask (pipeline.py:516-528) of (N,H,W) binary f32 labels: uint8 (N,H,W)."""
+    _chk(img, "img", ndim=3)
+    N, H, W = img.shape
+    pts = torch.empty((N, H, W), dtype=torch.uint8, device=img.device)
+    _lib.check(_lib.load().sq_wm2_boundary_points_u8(_ptr(img), _ptr(pts), N, H, W, _stream()), "sq_wm2_boundary_points_u8")
+    return pts
+
+
+_DELAUNAY_OUT = {}
+
+
+def delaunay2d_batch(xy, offsets):
+    """HOST: exact Delaunay triangulation of each tile's integer points (sq_delaunay2d_batch_i32, native, threaded).
+    xy (P,2) int32 CPU tensor (row, column), offsets (T+1) int64 CPU tensor.  Returns (simplices (S,7) int32, longest (S)
+    float64) as views of a pinned staging buffer ready for the upload -- overwritten by the next call: upload (or
+    clone) them first."""
+    if xy.device.type != "cpu" or offsets.device.type != "cpu" or xy.dtype != torch.int32 or offsets.dtype != torch.int64:
+        raise TypeError("delaunay2d_batch takes CPU tensors: xy int32 (P,2), offsets int64 (T+1)")
+    xy, offsets = xy.contiguous(), offsets.contiguous()
+    nsets = int(offsets.numel()) - 1
+    cap = max(2 * int(offsets[-1]), 1)
+    buf = _DELAUNAY_OUT.get("buf")
+    if buf is None or buf[0].shape[0] < cap:                    # pinned staging, kept across calls (grow-only)
+        pin = torch.cuda.is_available()
+        room = cap + cap // 4
+        buf = _DELAUNAY_OUT["buf"] = (torch.empty((room, 7), dtype=torch.int32, pin_memory=pin),
+                                      torch.empty((room,), dtype=torch.float64, pin_memory=pin))
+    simp, lng = buf
+    n = _lib.load().sq_delaunay2d_batch_i32(xy.data_ptr(), offsets.data_ptr(), nsets, simp.data_ptr(), lng.data_ptr(), cap)
+    if n < 0:
+        _lib.check(int(n), "sq_delaunay2d_batch_i32")
+    return simp[:n], lng[:n]
+
+
 def weightmap_delaunay(img, simplices, longest, w0=10.0, sigma=5.0, dtype=torch.float32):
     """The per-pixel part of ImageWeightMap2 (pipeline.py:514-566) on the device: img (N,H,W) binary f32, simplices
     (S,7) int32 {tile, x0,y0, x1,y1, x2,y2}, longest (S) float64 -- see sq_weightmap2_delaunay_f32."""

@@ -112,17 +112,47 @@ def boundary_triangulation(label):
     return verts.astype(np.int32), longest
 
 
-def device_weightmaps2(labels, w0=10., sigma=5., device=None, dtype=None):
-    """ImageWeightMap2 (pipeline.py:482-571) of a stack of binary label images with the per-pixel work on the GPU:
-    the host triangulates each tile's boundary points (scipy / Qhull, ~40 ms per 512x512 tile, 1 % of the
-    reference's time), the device locates every background pixel in the triangulation, takes the simplex's longest
-    edge, filters and applies the weight expression (sq_weightmap2_delaunay_f32).  Returns the (N,H,W,1) tensor the
+def device_weightmaps2(labels, w0=10., sigma=5., device=None, dtype=None, triangulation='native'):
+    """ImageWeightMap2 (pipeline.py:482-571) of a stack of binary label images, returned as the (N,H,W,1) tensor the
     training step takes (float32; dtype=torch.float64 for the reference's own precision), left in HBM.
-    Exact wherever one simplex covers the pixel; on simplex edges / vertices the reference's answer depends on the
-    path of scipy's walk, here the largest candidate is taken (tests/test_gpu_weightmap.py states the bound)."""
+
+    triangulation='native' (default, round 3): no scipy anywhere -- the boundary points are found on the device
+    (sq_wm2_boundary_points_u8), compacted there, copied to the host (~50 KB per tile), triangulated by the library's own
+    exact integer Delaunay on a pool of host threads (sq_delaunay2d_batch_i32, ~4 ms per 512x512 tile per thread against
+    Qhull's 22-38 ms under the GIL), and the simplices go back for the per-pixel part (sq_weightmap2_delaunay_f32:
+    point location by rasterisation, scipy-order Gaussian, the reference's float64 expression).
+    triangulation='scipy': round 2's path -- scipy's morphology and Qhull on the host, one tile at a time.
+
+    Exact wherever the Delaunay triangulation is unique and one simplex covers the pixel.  On simplex edges / vertices
+    the reference's answer depends on the path of scipy's walk (here the largest candidate is taken), and among
+    co-circular lattice points on Qhull's facet order (the native triangulation breaks those ties its own way);
+    tests/test_gpu_weightmap.py states both bounds against the reference-generated vectors."""
     import torch
     from . import ops
     dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    if triangulation not in ('native', 'scipy'):
+        raise ValueError("triangulation must be 'native' or 'scipy'")
+    if triangulation == 'native':
+        if isinstance(labels, torch.Tensor):
+            lab = labels.to(dev)
+        else:
+            lab = torch.from_numpy(np.ascontiguousarray(np.asarray(labels))).to(dev)
+        if lab.dim() == 4 and lab.shape[-1] == 1:
+            lab = lab[..., 0]
+        img = (lab > 0).to(torch.float32).contiguous()
+        N = img.shape[0]
+        idx = torch.nonzero(ops.wm2_boundary_points(img)).to(torch.int32).cpu()   # (P,3) [tile, row, column], scan order
+        counts = np.bincount(idx[:, 0].numpy(), minlength=N)
+        offsets = torch.zeros(N + 1, dtype=torch.int64)
+        offsets[1:] = torch.from_numpy(np.cumsum(counts))
+        if int(counts.min()) < 3:
+            raise ValueError('ImageWeightMap2 needs at least three boundary points per tile (tile %d has %d): the '
+                             'reference\'s Delaunay call fails there too' % (int(counts.argmin()), int(counts.min())))
+        simp, lng = ops.delaunay2d_batch(idx[:, 1:].contiguous(), offsets)
+        simp_d, lng_d = simp.to(dev, non_blocking=True), lng.to(dev, non_blocking=True)
+        w = ops.weightmap_delaunay(img, simp_d, lng_d, w0, sigma, dtype=dtype or torch.float32)
+        torch.cuda.current_stream(dev).synchronize()            # the pinned staging buffer is reused by the next call
+        return w.reshape(tuple(w.shape) + (1,))
     if isinstance(labels, torch.Tensor):
         labels = labels.detach().cpu().numpy()
     lab = np.asarray(labels)

@@ -96,7 +96,8 @@ def _wm2_check(lab, ref, w0=10., sigma=5., ref_is_f32=False, window=None):
     its walk reaches first and the kernel takes the one with the longest edge); elsewhere within the map's range w0."""
     from scipy.ndimage import maximum_filter
     from sequitr_amd.weightmap import device_weightmaps2
-    got = device_weightmaps2(lab[None], w0, sigma, device="cuda:0", dtype=torch.float64).cpu().numpy()[0]
+    got = device_weightmaps2(lab[None], w0, sigma, device="cuda:0", dtype=torch.float64,
+                             triangulation="scipy").cpu().numpy()[0]
     emu, count = weightmap_ref.image_weight_map2_raster(lab, w0, sigma)
     assert got.shape == emu.shape and np.abs(got - emu).max() <= 1e-12, np.abs(got - emu).max()
     tie = (count >= 2) & (lab == 0)
@@ -121,9 +122,55 @@ def test_weightmap2_reference_vectors_64px_and_512px():
     assert tie < 0.08 and clean > 0.5 and efrac < 0.25, (tie, clean, emax, efrac)
     # float32 maps for the training step: the float64 map rounded once
     from sequitr_amd.weightmap import device_weightmaps2
-    w32 = device_weightmaps2(lab[None], 10., 5., device="cuda:0")
-    w64 = device_weightmaps2(lab[None], 10., 5., device="cuda:0", dtype=torch.float64)
+    w32 = device_weightmaps2(lab[None], 10., 5., device="cuda:0", triangulation="scipy")
+    w64 = device_weightmaps2(lab[None], 10., 5., device="cuda:0", dtype=torch.float64, triangulation="scipy")
     assert w32.dtype == torch.float32 and tuple(w32.shape) == (1, 512, 512, 1) and torch.equal(w32, w64.float())
+
+
+def test_weightmap2_native_triangulation_no_scipy_in_the_path():
+    """Round 3: ImageWeightMap2 with the library's own triangulation (the default path).
+      * the boundary-point kernel equals scipy's morphology (pipeline.py:516-528) bit for bit, also at the tile border;
+      * the device map equals the CPU rasterisation of the SAME native triangulation to 1e-12 (pins the kernels);
+      * against the reference-generated vectors: the native Delaunay triangulation is the reference's wherever the
+        triangulation is unique; among co-circular lattice points Qhull's choice is an artefact of its facet order, so
+        a pixel inside such a quadrilateral can get the other diagonal.  Measured and asserted on the 512x512 vector:
+        mean |dw| <= 0.05 and at most 3 % of the background pixels off by more than 0.25 (range of the map: 1 .. 11);
+        scipy's own joggled run ('QJ') of the same points differs from its default run by mean 0.021 / 1.4 %
+        (profiles/r03_wm2_notes.txt) -- the bound is the tie-breaking, not this implementation."""
+    from sequitr_amd.weightmap import device_weightmaps2
+    from sequitr_amd import ops
+    labs = [G["wm_in_%d" % s] for s in (0, 1, 2)]
+    edge = np.zeros((64, 64), np.float32)
+    edge[0:5, 10:30] = 1
+    edge[30:40, 58:64] = 1
+    edge[61:64, 0:3] = 1                                                   # objects cut by the tile border
+    for lab in labs + [edge]:
+        pts = ops.wm2_boundary_points(dev(lab[None].astype(np.float32))).cpu().numpy()[0]
+        assert np.array_equal(pts.astype(bool), weightmap_ref.boundary_points(lab))
+    big = G["wm_in_512"].astype(np.float32)
+    pts = ops.wm2_boundary_points(dev(big[None])).cpu().numpy()[0]
+    assert np.array_equal(pts.astype(bool), weightmap_ref.boundary_points(big))
+    # kernels pinned: device map == CPU rasterisation of the same (native) triangulation
+    for lab in labs:
+        P = np.column_stack(np.where(weightmap_ref.boundary_points(lab))).astype(np.int32)
+        simp, _ = ops.delaunay2d_batch(torch.from_numpy(P), torch.tensor([0, len(P)], dtype=torch.int64))
+        emu, _ = weightmap_ref.image_weight_map2_raster(lab, 10., 5., vertices=simp.numpy()[:, 1:].reshape(-1, 3, 2))
+        got = device_weightmaps2(lab[None], 10., 5., device="cuda:0", dtype=torch.float64).cpu().numpy()[0]
+        assert np.abs(got - emu).max() <= 1e-12
+    # against the reference-generated vector at the benchmark size
+    got = device_weightmaps2(big[None], 10., 5., device="cuda:0", dtype=torch.float64).cpu().numpy()[0, 128:384, 128:384, 0]
+    bg = big[128:384, 128:384] == 0
+    err = np.abs(got - G["wm2_out_512_centre"].astype(np.float64))[bg]
+    print("native WM2 vs reference: mean %.4f  frac > 0.25: %.4f  frac > 1e-5: %.4f  max %.3f"
+          % (err.mean(), (err > 0.25).mean(), (err > 1e-5).mean(), err.max()))
+    assert err.mean() <= 0.05 and (err > 0.25).mean() <= 0.03 and err.max() <= 10.0 + 1e-6
+    # a batch: every tile equals the tile run alone; tiles with fewer than three boundary points are refused loudly
+    stack = np.stack([big, np.roll(big, 37, axis=1), big[::-1].copy()])
+    wb = device_weightmaps2(stack, 10., 5., device="cuda:0", dtype=torch.float64).cpu().numpy()
+    for k in range(3):
+        assert np.array_equal(wb[k], device_weightmaps2(stack[k:k + 1], 10., 5., device="cuda:0", dtype=torch.float64).cpu().numpy()[0])
+    with pytest.raises(ValueError, match="three boundary points"):
+        device_weightmaps2(np.zeros((1, 64, 64), np.float32), 10., 5., device="cuda:0")
 
 
 def test_create_weightmaps_gpu_methods_write_the_reference_layout(tmp_path):
@@ -144,6 +191,10 @@ def test_create_weightmaps_gpu_methods_write_the_reference_layout(tmp_path):
         if pipe is not None:
             want = np.squeeze(pipe(lab.astype(np.float32)[..., None])).astype(np.float32)
         else:
-            want = weightmap_ref.image_weight_map2_raster(lab.astype(np.float32), 10., 5.)[0][..., 0].astype(np.float32)
+            from sequitr_amd import ops
+            P = np.column_stack(np.where(weightmap_ref.boundary_points(lab))).astype(np.int32)
+            simp, _ = ops.delaunay2d_batch(torch.from_numpy(P), torch.tensor([0, len(P)], dtype=torch.int64))
+            want = weightmap_ref.image_weight_map2_raster(lab.astype(np.float32), 10., 5.,
+                                                          vertices=simp.numpy()[:, 1:].reshape(-1, 3, 2))[0][..., 0].astype(np.float32)
         assert np.abs(got - want).max() <= 1e-6, method
         os.remove(files[0])
