@@ -10,7 +10,7 @@ import torch
 from sequitr_amd import ops_bf16 as ob
 
 D = "cuda:0"
-N = 16
+N = int(os.environ.get("BENCH_N", 16))
 BF = torch.bfloat16
 
 
