@@ -130,6 +130,39 @@ def test_train_job_runs_the_captured_device_resident_step_at_config3_size(tmp_pa
     assert info["ms_per_step"] <= 1.10 * bench_ms, (info["ms_per_step"], bench_ms)
 
 
+def test_train_job_staged_path_equals_the_resident_path(tmp_path, monkeypatch):
+    """SERVER_train's two data paths -- the stack resident in HBM (index gather on the device) and the pinned staging
+    fallback for stacks above params['resident_gib'] -- and its two step forms (captured / eager) feed the same batches
+    to the same step: identical losses, bit for bit, and identical saved weights (dropout off: the mask stream is the
+    only thing a different pass count would move)."""
+    from sequitr_amd import core, utils
+    monkeypatch.setattr(core.TensorflowConfiguration, "MODELDIR", str(tmp_path / "models"))
+    os.mkdir(str(tmp_path / "models"))
+    rng = np.random.default_rng(4)
+    lab = (rng.random((12, 64, 64)) < 0.3).astype(np.uint8)
+    imgs = (lab * 1.5 + rng.standard_normal((12, 64, 64)) * 0.5).astype(np.float32)
+    np.save(str(tmp_path / "im.npy"), imgs)
+    np.save(str(tmp_path / "lab.npy"), lab)
+    runs = {}
+    for tag, extra, opts in (("resident", {}, "{'gpu': 0}"), ("staged", {"resident_gib": 0}, "{'gpu': 0}"),
+                             ("eager", {}, "{'gpu': 0, 'graph': False}")):
+        params = dict({"images": str(tmp_path / "im.npy"), "labels": str(tmp_path / "lab.npy"), "shape": (64, 64),
+                       "num_outputs": 2, "num_epochs": 3, "batch_size": 4, "dropout": 0.0, "filters": (16, 32),
+                       "seed": 1}, **extra)
+        fn = write_job(tmp_path, "JOB_%s.job" % tag, func="SERVER_train", params=repr(params), options=opts)
+        out = str(tmp_path / ("out_" + tag))
+        worker.worker(argparse.Namespace(job=fn, out=out))
+        logs = open(os.path.join(out, [f for f in os.listdir(out) if f.startswith("LOG_")][0])).read()
+        assert "exception" not in logs, logs
+        info = json.load(open(os.path.join(out, "train.json")))
+        assert info["steps"] == 9 and info["resident"] == (tag != "staged") and info["graph"] == (tag != "eager")
+        runs[tag] = (info["losses"], utils.load_model_weights(info["model_dir"]))
+    for tag in ("staged", "eager"):
+        assert runs[tag][0] == runs["resident"][0], tag
+        for k, v in runs["resident"][1].items():
+            assert np.array_equal(v, runs[tag][1][k]), (tag, k)
+
+
 def test_segment_job_writes_centroids(tmp_path):
     """options['centroids']: the step after the hot path (CentroidWriter, sequitr/utils.py:479-578) runs on
     the masks while they are still in HBM; rows equal the reference's scipy loop on the saved masks."""
