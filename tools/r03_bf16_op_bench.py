@@ -7,6 +7,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+from sequitr_amd import _lib
+if os.environ.get("SQ_LIB_PATH"):                               # an experimental build of the library (tools/_exp/...)
+    _lib.LIB_PATH = os.environ["SQ_LIB_PATH"]
 from sequitr_amd import ops_bf16 as ob
 
 D = "cuda:0"
