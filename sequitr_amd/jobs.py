@@ -317,7 +317,7 @@ def SERVER_train(params, options):
             torch.index_select(y_dev, 0, idx_dev, out=sy)
             torch.index_select(w_dev, 0, idx_dev, out=sw)
         else:
-            ih = np.sort(idx_host)
+            ih = np.asarray(idx_host)                            # the permutation's own order: the same batch as the resident path
             sx.copy_(torch.from_numpy(np.ascontiguousarray(x[ih], dtype=np.float32)).pin_memory(), non_blocking=True)
             sy.copy_(torch.from_numpy(np.ascontiguousarray(onehot[ih])).pin_memory(), non_blocking=True)
             if isinstance(wmap, torch.Tensor):
