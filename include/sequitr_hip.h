@@ -231,6 +231,16 @@ int sq_bn_apply_f32(const float *x, const float *scale, const float *shift, floa
 int sq_bn_bwd_f32(const float *x, const float *dy, const float *y_act, int act, const float *mean, const float *var,
                   const float *gamma, float eps, float *dx, float *dgamma, float *dbeta, void *workspace,
                   int64_t npix, int C, void *stream);
+/* The same three passes on bf16 tensors (`batch_norm` in the bf16 training graph, BASELINE configs 3-4; hook
+ * sequitr/networks/unet.py:326-328 + SURVEY.md A.1): elements are widened to f32, statistics accumulate in f64, parameters
+ * and gradients of gamma / beta stay f32, y / dx are rounded to bf16 once.  fold / update_moving are the f32 entry points;
+ * workspace as sq_bn_workspace_f32. */
+int sq_bn_stats_bf16(const void *x, float *mean, float *var, void *workspace, int64_t npix, int C, void *stream);
+int sq_bn_apply_bf16(const void *x, const float *scale, const float *shift, void *y, int64_t npix, int C, int act,
+                     void *stream);
+int sq_bn_bwd_bf16(const void *x, const void *dy, const void *y_act, int act, const float *mean, const float *var,
+                   const float *gamma, float eps, void *dx, float *dgamma, float *dbeta, void *workspace, int64_t npix,
+                   int C, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * GAN side (sequitr/networks/gan.py).  weighted_conv2d / to_image / from_image are

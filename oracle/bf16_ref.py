@@ -44,19 +44,31 @@ class _RndGrad(torch.autograd.Function):
 rnd, rnd_grad = _Rnd.apply, _RndGrad.apply
 
 
-def unet_loss_and_grads_bf16(x_nhwc, onehot, wmap, weights, params=None):
-    params = params or {}
+def _forward(x_nhwc, W, params):
+    """(per-level outputs NCHW, logits NHWC) of the bf16 graph; W: {name: fp64 tensor}."""
     filters = tuple(params.get("filters", (16, 32, 64, 128, 256)))
     bridge = params.get("bridge", "eltwise_mul")
-    W = {k: torch.as_tensor(np.asarray(v)).to(DT).requires_grad_(True) for k, v in weights.items()}
     x = torch.as_tensor(np.asarray(x_nhwc)).to(DT).permute(0, 3, 1, 2)
+    bn = bool(params.get("batch_norm", False))                   # oracle/torch_ref.py unet_loss_and_grads, same branch
+    eps = float(params.get("bn_epsilon", 1e-3))
 
     def conv(t, s, first=False):
         w, b = W[s + "/kernel"], W[s + "/bias"]
         if not first:
             t, w = rnd_grad(t), rnd(w)               # dX is stored as bf16; the filter copy is bf16
-        y = F.relu(F.conv2d(t, w.permute(3, 2, 0, 1), b, padding=1))
-        return rnd(y)
+        z = F.conv2d(t, w.permute(3, 2, 0, 1), b, padding=1)
+        if not bn:
+            return rnd(F.relu(z))
+        # batch_norm: the conv stores z as bf16, the statistics are taken of those bf16 values, act(BN(z)) is rounded
+        # once; the gradient wrt z is stored as bf16 (sq_bn_bwd_bf16)
+        z = rnd_grad(rnd(z))
+        if params.get("bn_moving", False):                         # inference form: the saved moving statistics
+            mu, var = W[s + "/moving_mean"].view(1, -1, 1, 1), W[s + "/moving_variance"].view(1, -1, 1, 1)
+        else:
+            mu = z.mean((0, 2, 3), keepdim=True)
+            var = ((z - mu) ** 2).mean((0, 2, 3), keepdim=True)
+        g, be = W[s + "/gamma"].view(1, -1, 1, 1), W[s + "/beta"].view(1, -1, 1, 1)
+        return rnd(F.relu(g * (z - mu) / torch.sqrt(var + eps) + be))
 
     def block(t, s, first=False):
         t = conv(t, s + "/conv1", first)
@@ -76,6 +88,19 @@ def unet_loss_and_grads_bf16(x_nhwc, onehot, wmap, weights, params=None):
         net.append(block(rnd(merged), s))
     h = rnd_grad(net[-1]).permute(0, 2, 3, 1)
     logits = h @ W["UNet/to_image/kernel"].reshape(filters[0], -1) + W["UNet/to_image/bias"]
+    return net, logits
+
+
+def unet_logits_bf16(x_nhwc, weights, params=None):
+    """Forward only (inference: pass params['bn_moving']=True with batch_norm): logits (N,H,W,classes) ndarray."""
+    with torch.no_grad():
+        W = {k: torch.as_tensor(np.asarray(v)).to(DT) for k, v in weights.items()}
+        return _forward(x_nhwc, W, params or {})[1].numpy()
+
+
+def unet_loss_and_grads_bf16(x_nhwc, onehot, wmap, weights, params=None):
+    W = {k: torch.as_tensor(np.asarray(v)).to(DT).requires_grad_(True) for k, v in weights.items()}
+    net, logits = _forward(x_nhwc, W, params or {})
     y = torch.as_tensor(np.asarray(onehot)).to(DT)
     wm = torch.as_tensor(np.asarray(wmap)).to(DT).reshape(logits.shape[:-1])
     loss = (wm * -(y * F.log_softmax(logits, -1)).sum(-1)).sum() / wm.numel()
@@ -84,4 +109,4 @@ def unet_loss_and_grads_bf16(x_nhwc, onehot, wmap, weights, params=None):
     loss.backward()
     unet_loss_and_grads_bf16.last_net = [(t.detach().permute(0, 2, 3, 1).numpy(), t.grad.permute(0, 2, 3, 1).numpy())
                                          for t in net]
-    return float(loss.detach()), {k: v.grad.numpy() for k, v in W.items()}, logits.detach().numpy()
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in W.items() if v.grad is not None}, logits.detach().numpy()

@@ -69,10 +69,14 @@ SIGNATURES = {
     "sq_gather_odd2x_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sq_bn_workspace_f32": (c_int64, [c_int64, c_int]),
     "sq_bn_stats_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_void_p]),
+    "sq_bn_stats_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_void_p]),
     "sq_bn_fold_f32": (c_int, [c_void_p] * 4 + [c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "sq_bn_update_moving_f32": (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p]),
     "sq_bn_apply_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
+    "sq_bn_apply_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
     "sq_bn_bwd_f32": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 3 + [c_float] + [c_void_p] * 4
+                      + [c_int64, c_int, c_void_p]),
+    "sq_bn_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 3 + [c_float] + [c_void_p] * 4
                       + [c_int64, c_int, c_void_p]),
     "sq_adam_step_dev_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 4 + [c_void_p, c_float, c_void_p]),
     "sq_adam_advance_dev": (c_int, [c_void_p, c_float, c_float, c_float, c_void_p]),

@@ -7,11 +7,38 @@
 //   apply : y = act(fmaf(x, scale[c], shift[c]))
 //   bwd   : d = act'(y) * dy;  dbeta = sum d;  dgamma = sum d * xhat;
 //           dx = gamma * r * (d - (dbeta + xhat * dgamma) / M),  xhat = (x - mean) * r
+//
+// The same kernels on bf16 tensors (round 3: `batch_norm` in the bf16 training graph, BASELINE configs 3-4): elements are
+// read as bf16 and widened, every statistic / parameter / intermediate stays f32 (sums f64), results are rounded to bf16
+// (RNE) once where they are stored -- the rounding points oracle/bf16_ref.py emulates.
 #include "sq_common.h"
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int BN_THREADS = 256;
+
+// four consecutive channels of one pixel in HBM: float4 or four bf16
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+    typedef float4 V;
+    static __device__ __forceinline__ void load(const V *p, int64_t i, float (&o)[4]) {
+        const float4 v = p[i];
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    static __device__ __forceinline__ void store(V *p, int64_t i, const float (&o)[4]) { p[i] = make_float4(o[0], o[1], o[2], o[3]); }
+};
+template <> struct Quad<__bf16> {
+    typedef bf16x4 V;
+    static __device__ __forceinline__ void load(const V *p, int64_t i, float (&o)[4]) {
+        const bf16x4 v = p[i];
+        o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+    }
+    static __device__ __forceinline__ void store(V *p, int64_t i, const float (&o)[4]) {
+        p[i] = (bf16x4){(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+    }
+};
 
 struct BnGeom {
     int cg;      // float4 channel groups per pixel (C / 4)
@@ -25,10 +52,10 @@ __device__ __forceinline__ float bn_dact(float dy, float y, int act) {
 }
 
 // partials layout: [block][2][C] doubles (first moment / second moment, or dbeta / dgamma)
-template <bool BWD>
-__global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const float4 *__restrict__ x,
-                                                               const float4 *__restrict__ dy,
-                                                               const float4 *__restrict__ yact, int act,
+template <bool BWD, typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const typename Quad<T>::V *__restrict__ x,
+                                                               const typename Quad<T>::V *__restrict__ dy,
+                                                               const typename Quad<T>::V *__restrict__ yact, int act,
                                                                const float *__restrict__ mean,
                                                                const float *__restrict__ var, float eps,
                                                                double *__restrict__ partials, int64_t npix, int C,
@@ -46,14 +73,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const float4 *__r
     }
     if (row < g.rows) {
         for (int64_t p = (int64_t)blockIdx.x * g.rows + row; p < npix; p += (int64_t)gridDim.x * g.rows) {
-            const float4 v = x[p * g.cg + c4];
-            const float xv[4] = {v.x, v.y, v.z, v.w};
+            float xv[4];
+            Quad<T>::load(x, p * g.cg + c4, xv);
             if (BWD) {
-                const float4 d4 = dy[p * g.cg + c4];
-                float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+                float dv[4];
+                Quad<T>::load(dy, p * g.cg + c4, dv);
                 if (yact) {
-                    const float4 y4 = yact[p * g.cg + c4];
-                    const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+                    float yv[4];
+                    Quad<T>::load(yact, p * g.cg + c4, yv);
                     for (int j = 0; j < 4; ++j) dv[j] = bn_dact(dv[j], yv[j], act);
                 }
                 for (int j = 0; j < 4; ++j) {
@@ -131,35 +158,36 @@ __global__ void bn_update_moving_kernel(float *__restrict__ mmean, float *__rest
     mvar[c] -= (mvar[c] - var[c] * unbias) * (1.0f - momentum);
 }
 
-__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float4 *__restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const typename Quad<T>::V *__restrict__ x,
                                                               const float *__restrict__ scale,
                                                               const float *__restrict__ shift,
-                                                              float4 *__restrict__ y, int64_t n4, int cg, int act) {
+                                                              typename Quad<T>::V *__restrict__ y, int64_t n4, int cg, int act) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = 4 * (int)(i % cg);
-        const float4 v = x[i];
-        float4 o;
-        o.x = sq_act(fmaf(v.x, scale[c + 0], shift[c + 0]), act);
-        o.y = sq_act(fmaf(v.y, scale[c + 1], shift[c + 1]), act);
-        o.z = sq_act(fmaf(v.z, scale[c + 2], shift[c + 2]), act);
-        o.w = sq_act(fmaf(v.w, scale[c + 3], shift[c + 3]), act);
-        y[i] = o;
+        float v[4], o[4];
+        Quad<T>::load(x, i, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = sq_act(fmaf(v[j], scale[c + j], shift[c + j]), act);
+        Quad<T>::store(y, i, o);
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
-    const float4 *__restrict__ x, const float4 *__restrict__ dy, const float4 *__restrict__ yact, int act,
+    const typename Quad<T>::V *__restrict__ x, const typename Quad<T>::V *__restrict__ dy,
+    const typename Quad<T>::V *__restrict__ yact, int act,
     const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ gamma, float eps,
-    const float *__restrict__ dgamma, const float *__restrict__ dbeta, float4 *__restrict__ dx, int64_t n4, int cg,
+    const float *__restrict__ dgamma, const float *__restrict__ dbeta, typename Quad<T>::V *__restrict__ dx, int64_t n4, int cg,
     float inv_m) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = 4 * (int)(i % cg);
-        const float4 v = x[i], d4 = dy[i];
-        const float xv[4] = {v.x, v.y, v.z, v.w};
-        float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+        float xv[4], dv[4];
+        Quad<T>::load(x, i, xv);
+        Quad<T>::load(dy, i, dv);
         if (yact) {
-            const float4 y4 = yact[i];
-            const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+            float yv[4];
+            Quad<T>::load(yact, i, yv);
             for (int j = 0; j < 4; ++j) dv[j] = bn_dact(dv[j], yv[j], act);
         }
         float o[4];
@@ -168,7 +196,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
             const float xh = (xv[j] - mean[c + j]) * r;
             o[j] = gamma[c + j] * r * (dv[j] - (dbeta[c + j] + xh * dgamma[c + j]) * inv_m);
         }
-        dx[i] = make_float4(o[0], o[1], o[2], o[3]);
+        Quad<T>::store(dx, i, o);
     }
 }
 
@@ -199,23 +227,34 @@ extern "C" int64_t sq_bn_workspace_f32(int64_t npix, int C) {
     return (int64_t)bn_grid(npix, g) * 2 * C * (int64_t)sizeof(double);
 }
 
-extern "C" int sq_bn_stats_f32(const float *x, float *mean, float *var, void *workspace, int64_t npix, int C,
-                               void *stream) {
+template <typename T>
+static int bn_stats_impl(const void *x, float *mean, float *var, void *workspace, int64_t npix, int C, void *stream,
+                         const char *what) {
+    typedef typename Quad<T>::V V;
     BnGeom g;
-    SQ_REQUIRE(x && mean && var && workspace && npix > 0, "sq_bn_stats_f32: bad arguments");
-    SQ_REQUIRE(bn_geom(C, &g), "sq_bn_stats_f32: C=%d must be a multiple of 4, <= 1024", C);
-    SQ_REQUIRE_ALIGNED(x);
-    SQ_REQUIRE((((uintptr_t)workspace) & 7u) == 0, "sq_bn_stats_f32: workspace must be 8-byte aligned");
+    SQ_REQUIRE(x && mean && var && workspace && npix > 0, "%s: bad arguments", what);
+    SQ_REQUIRE(bn_geom(C, &g), "%s: C=%d must be a multiple of 4, <= 1024", what, C);
+    SQ_REQUIRE((((uintptr_t)x) & (sizeof(V) - 1)) == 0, "%s: x is not aligned to %d bytes", what, (int)sizeof(V));
+    SQ_REQUIRE((((uintptr_t)workspace) & 7u) == 0, "%s: workspace must be 8-byte aligned", what);
     const int nblk = bn_grid(npix, g);
-    hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(nblk), dim3(BN_THREADS), 0, SQ_ST(stream),
-                       reinterpret_cast<const float4 *>(x), (const float4 *)nullptr, (const float4 *)nullptr, 0,
+    hipLaunchKernelGGL((bn_reduce_kernel<false, T>), dim3(nblk), dim3(BN_THREADS), 0, SQ_ST(stream),
+                       reinterpret_cast<const V *>(x), (const V *)nullptr, (const V *)nullptr, 0,
                        (const float *)nullptr, (const float *)nullptr, 0.f, reinterpret_cast<double *>(workspace), npix,
                        C, g);
-    int rc = sq_check_launch("sq_bn_stats_f32(reduce)");
+    int rc = sq_check_launch(what);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, SQ_ST(stream),
                        reinterpret_cast<const double *>(workspace), nblk, C, npix, mean, var);
-    return sq_check_launch("sq_bn_stats_f32");
+    return sq_check_launch(what);
+}
+
+extern "C" int sq_bn_stats_f32(const float *x, float *mean, float *var, void *workspace, int64_t npix, int C,
+                               void *stream) {
+    return bn_stats_impl<float>(x, mean, var, workspace, npix, C, stream, "sq_bn_stats_f32");
+}
+extern "C" int sq_bn_stats_bf16(const void *x, float *mean, float *var, void *workspace, int64_t npix, int C,
+                                void *stream) {
+    return bn_stats_impl<__bf16>(x, mean, var, workspace, npix, C, stream, "sq_bn_stats_bf16");
 }
 
 extern "C" int sq_bn_fold_f32(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
@@ -235,47 +274,69 @@ extern "C" int sq_bn_update_moving_f32(float *moving_mean, float *moving_var, co
     return sq_check_launch("sq_bn_update_moving_f32");
 }
 
+template <typename T>
+static int bn_apply_impl(const void *x, const float *scale, const float *shift, void *y, int64_t npix, int C, int act,
+                         void *stream, const char *what) {
+    typedef typename Quad<T>::V V;
+    SQ_REQUIRE(x && scale && shift && y && npix > 0, "%s: bad arguments", what);
+    SQ_REQUIRE(C >= 4 && (C & 3) == 0, "%s: C=%d must be a multiple of 4", what, C);
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "%s: bad activation %d", what, act);
+    SQ_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y)) & (sizeof(V) - 1)) == 0, "%s: tensors not aligned to %d bytes", what, (int)sizeof(V));
+    const int64_t n4 = npix * (C / 4);
+    hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(stream_grid(n4)), dim3(BN_THREADS), 0, SQ_ST(stream),
+                       reinterpret_cast<const V *>(x), scale, shift, reinterpret_cast<V *>(y), n4, C / 4, act);
+    return sq_check_launch(what);
+}
+
 extern "C" int sq_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, int64_t npix, int C,
                                int act, void *stream) {
-    SQ_REQUIRE(x && scale && shift && y && npix > 0, "sq_bn_apply_f32: bad arguments");
-    SQ_REQUIRE(C >= 4 && (C & 3) == 0, "sq_bn_apply_f32: C=%d must be a multiple of 4", C);
-    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_bn_apply_f32: bad activation %d", act);
-    SQ_REQUIRE_ALIGNED(x);
-    SQ_REQUIRE_ALIGNED(y);
+    return bn_apply_impl<float>(x, scale, shift, y, npix, C, act, stream, "sq_bn_apply_f32");
+}
+extern "C" int sq_bn_apply_bf16(const void *x, const float *scale, const float *shift, void *y, int64_t npix, int C,
+                                int act, void *stream) {
+    return bn_apply_impl<__bf16>(x, scale, shift, y, npix, C, act, stream, "sq_bn_apply_bf16");
+}
+
+template <typename T>
+static int bn_bwd_impl(const void *x, const void *dy, const void *y_act, int act, const float *mean, const float *var,
+                       const float *gamma, float eps, void *dx, float *dgamma, float *dbeta, void *workspace, int64_t npix,
+                       int C, void *stream, const char *what) {
+    typedef typename Quad<T>::V V;
+    BnGeom g;
+    SQ_REQUIRE(x && dy && mean && var && gamma && dx && dgamma && dbeta && workspace && npix > 0, "%s: bad arguments", what);
+    SQ_REQUIRE(bn_geom(C, &g), "%s: C=%d must be a multiple of 4, <= 1024", what, C);
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "%s: bad activation %d", what, act);
+    SQ_REQUIRE(act == SQ_ACT_NONE || y_act, "%s: y_act is needed to differentiate the activation", what);
+    SQ_REQUIRE(((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & (sizeof(V) - 1)) == 0,
+               "%s: tensors not aligned to %d bytes", what, (int)sizeof(V));
+    if (act == SQ_ACT_NONE) y_act = nullptr;
+    const int nblk = bn_grid(npix, g);
+    hipLaunchKernelGGL((bn_reduce_kernel<true, T>), dim3(nblk), dim3(BN_THREADS), 0, SQ_ST(stream),
+                       reinterpret_cast<const V *>(x), reinterpret_cast<const V *>(dy), reinterpret_cast<const V *>(y_act), act,
+                       mean, var, eps, reinterpret_cast<double *>(workspace), npix, C, g);
+    int rc = sq_check_launch(what);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, SQ_ST(stream),
+                       reinterpret_cast<const double *>(workspace), nblk, C, var, eps, dgamma, dbeta);
+    rc = sq_check_launch(what);
+    if (rc) return rc;
     const int64_t n4 = npix * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(BN_THREADS), 0, SQ_ST(stream),
-                       reinterpret_cast<const float4 *>(x), scale, shift, reinterpret_cast<float4 *>(y), n4, C / 4, act);
-    return sq_check_launch("sq_bn_apply_f32");
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(stream_grid(n4)), dim3(BN_THREADS), 0, SQ_ST(stream),
+                       reinterpret_cast<const V *>(x), reinterpret_cast<const V *>(dy), reinterpret_cast<const V *>(y_act), act,
+                       mean, var, gamma, eps, dgamma, dbeta, reinterpret_cast<V *>(dx), n4, C / 4,
+                       (float)(1.0 / (double)npix));
+    return sq_check_launch(what);
 }
 
 extern "C" int sq_bn_bwd_f32(const float *x, const float *dy, const float *y_act, int act, const float *mean,
                              const float *var, const float *gamma, float eps, float *dx, float *dgamma, float *dbeta,
                              void *workspace, int64_t npix, int C, void *stream) {
-    BnGeom g;
-    SQ_REQUIRE(x && dy && mean && var && gamma && dx && dgamma && dbeta && workspace && npix > 0,
-               "sq_bn_bwd_f32: bad arguments");
-    SQ_REQUIRE(bn_geom(C, &g), "sq_bn_bwd_f32: C=%d must be a multiple of 4, <= 1024", C);
-    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY, "sq_bn_bwd_f32: bad activation %d", act);
-    SQ_REQUIRE(act == SQ_ACT_NONE || y_act, "sq_bn_bwd_f32: y_act is needed to differentiate the activation");
-    SQ_REQUIRE_ALIGNED(x);
-    SQ_REQUIRE_ALIGNED(dy);
-    SQ_REQUIRE_ALIGNED(dx);
-    if (act == SQ_ACT_NONE) y_act = nullptr;
-    const int nblk = bn_grid(npix, g);
-    hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(nblk), dim3(BN_THREADS), 0, SQ_ST(stream),
-                       reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(dy),
-                       reinterpret_cast<const float4 *>(y_act), act, mean, var, eps,
-                       reinterpret_cast<double *>(workspace), npix, C, g);
-    int rc = sq_check_launch("sq_bn_bwd_f32(reduce)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, SQ_ST(stream),
-                       reinterpret_cast<const double *>(workspace), nblk, C, var, eps, dgamma, dbeta);
-    rc = sq_check_launch("sq_bn_bwd_f32(finish)");
-    if (rc) return rc;
-    const int64_t n4 = npix * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(BN_THREADS), 0, SQ_ST(stream),
-                       reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(dy),
-                       reinterpret_cast<const float4 *>(y_act), act, mean, var, gamma, eps, dgamma, dbeta,
-                       reinterpret_cast<float4 *>(dx), n4, C / 4, (float)(1.0 / (double)npix));
-    return sq_check_launch("sq_bn_bwd_f32");
+    return bn_bwd_impl<float>(x, dy, y_act, act, mean, var, gamma, eps, dx, dgamma, dbeta, workspace, npix, C, stream,
+                              "sq_bn_bwd_f32");
+}
+extern "C" int sq_bn_bwd_bf16(const void *x, const void *dy, const void *y_act, int act, const float *mean,
+                              const float *var, const float *gamma, float eps, void *dx, float *dgamma, float *dbeta,
+                              void *workspace, int64_t npix, int C, void *stream) {
+    return bn_bwd_impl<__bf16>(x, dy, y_act, act, mean, var, gamma, eps, dx, dgamma, dbeta, workspace, npix, C, stream,
+                               "sq_bn_bwd_bf16");
 }

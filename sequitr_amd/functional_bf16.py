@@ -54,7 +54,7 @@ class _ConvFirst(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, dy):
         x, y = ctx.saved_tensors
-        dpre = ob.act_bwd(dy.contiguous(), y, ctx.act)
+        dpre = ob.act_bwd(dy.contiguous(), y, ctx.act) if ops.ACT[ctx.act] else dy.contiguous()   # act None: a BN layer follows
         sw, sb = ctx.sinks
         dw, db = ob.conv3x3_first_wgrad(x, dpre, dw_out=sw, db_out=sb)
         return None, (None if sw is not None else dw), (None if sb is not None else db), None
@@ -443,3 +443,35 @@ class _HeadLoss(torch.autograd.Function):
 
 def conv1x1_head_loss(x, w, bias, onehot, weights, x_single_use=False):
     return _HeadLoss.apply(x, w, bias, onehot, weights, _gate_of(x) if x_single_use else None)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    """y = act(BN(x)) with batch statistics on a bf16 activation (tf.layers.batch_normalization(training=True) between a
+    conv and its ReLU); updates the moving statistics in place.  gamma / beta / statistics f32."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act):
+        mean, var = ob.bn_stats(x)
+        scale, shift = ops.bn_fold(gamma, beta, mean, var, eps)
+        y = ob.bn_apply(x, scale, shift, act)
+        ops.bn_update_moving_(moving_mean, moving_var, mean, var, x.numel() // x.shape[-1], momentum)
+        ctx.save_for_backward(x, y, mean, var, gamma)
+        ctx.eps, ctx.act = eps, act
+        ctx.sinks = (grad_sink(gamma), grad_sink(beta))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, y, mean, var, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta = ob.bn_bwd(x, dy.contiguous(), y, ctx.act, mean, var, gamma, ctx.eps)
+        sg, sb = ctx.sinks
+        if sg is not None:
+            sg.copy_(dgamma)
+        if sb is not None:
+            sb.copy_(dbeta)
+        return dx, (None if sg is not None else dgamma), (None if sb is not None else dbeta), None, None, None, None, None
+
+
+def batch_norm_train(x, gamma, beta, moving_mean, moving_var, eps=ops.BN_EPS, momentum=ops.BN_MOMENTUM, act=None):
+    return _BatchNormTrain.apply(x, gamma, beta, moving_mean, moving_var, float(eps), float(momentum), act)

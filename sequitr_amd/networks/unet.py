@@ -685,8 +685,6 @@ class UNet2DBf16(UNet2D):
         self._skip_boxes = {}
         if not 1 <= self.n_inputs <= 7:
             raise ValueError('the bf16 graph takes an f32 image of 1..7 channels (num_inputs)')
-        if self.batch_norm:
-            raise ValueError('batch_norm is an f32-graph option (the bf16 graph has no BN kernels yet)')
         if any(f % 16 for f in self.filters) or self.bridge_type == 'concat':
             raise ValueError('the bf16 graph needs filter counts that are multiples of 16 and an eltwise bridge')
         k = self.bridge_type
@@ -695,9 +693,22 @@ class UNet2DBf16(UNet2D):
 
     def conv_layer(self, x, filters):
         w, b = self._kernel((3, 3, x.shape[-1], filters)), self._bias(filters)
-        if x.dtype == torch.float32:
-            return FB.conv3x3_first(x, w, b, act='relu')
-        return FB.conv2d(x, w, b, act='relu')
+        act = None if self.batch_norm else 'relu'              # BN sits between the conv and its ReLU
+        z = FB.conv3x3_first(x, w, b, act=act) if x.dtype == torch.float32 else FB.conv2d(x, w, b, act=act)
+        return self.batch_norm_layer(z, act='relu') if self.batch_norm else z
+
+    def batch_norm_layer(self, z, act=None):
+        """UNet2D.batch_norm_layer on a bf16 activation: same variables (gamma, beta, moving_mean, moving_variance in the
+        conv's scope, all f32), statistics in f32 / f64, the result rounded to bf16 once (sq_bn_*_bf16)."""
+        from .. import ops_bf16 as ob
+        n = z.shape[-1]
+        gamma = self.get_variable('gamma', (n,), lambda s: np.ones(s, np.float32))
+        beta = self.get_variable('beta', (n,), lambda s: np.zeros(s, np.float32))
+        mmean = self.get_variable('moving_mean', (n,), lambda s: np.zeros(s, np.float32))
+        mvar = self.get_variable('moving_variance', (n,), lambda s: np.ones(s, np.float32))
+        if self.training:
+            return FB.batch_norm_train(z, gamma, beta, mmean, mvar, self.bn_eps, self.bn_momentum, act=act)
+        return ob.bn_inference(z, gamma, beta, mmean, mvar, self.bn_eps, act=act)
 
     _WIRING = ('build', 'build_loss', 'down_layer', 'up_layer')
 
@@ -714,7 +725,7 @@ class UNet2DBf16(UNet2D):
     def conv_block(self, x, filters):
         """unet.py:265-277.  While neither conv_layer nor dropout_layer is overridden the block is one tape
         entry (FB.conv_block): same forward kernels, backward with the two ReLU gradients fused away."""
-        if not (self.training and self.fuse_block and type(self).conv_layer is UNet2DBf16.conv_layer
+        if not (self.training and self.fuse_block and not self.batch_norm and type(self).conv_layer is UNet2DBf16.conv_layer
                 and type(self).dropout_layer is UNet2DBf16.dropout_layer):
             return UNet2D.conv_block(self, x, filters)
         with self.variable_scope('conv1'):
@@ -734,7 +745,8 @@ class UNet2DBf16(UNet2D):
     def down_layer(self, x, filters, name=None):
         """unet.py:282-296.  Every encoder level but the last is followed by the max pool (unet.py:241-243): its block
         then writes the pooled tensor from conv2's epilogue (FB.conv_block(pool_follows=True)) and pool_layer picks it up."""
-        self._pool_next = (self.training and self.fuse_block and isinstance(name, int) and name < len(self.filters) - 1
+        self._pool_next = (self.training and self.fuse_block and not self.batch_norm and isinstance(name, int)
+                           and name < len(self.filters) - 1
                            and type(self).pool_layer is UNet2DBf16.pool_layer and self._plain_wiring())
         try:
             return UNet.down_layer(self, x, filters, name=name)

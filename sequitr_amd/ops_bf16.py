@@ -526,3 +526,54 @@ def conv3x3_first_wgrad(x, dy, dw_out=None, db_out=None):
     _lib.check(lib.sq_conv3x3_first_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout,
                                                _stream()), "sq_conv3x3_first_wgrad_bf16")
     return dw, db
+
+
+# ---- batch normalisation on bf16 activations (optional `batch_norm` of conv_layer) ----------------------
+def _bn_shape(x):
+    _chk(x, "x")
+    C = x.shape[-1]
+    return x.numel() // C, C
+
+
+def bn_stats(x):
+    """(mean, population variance) per channel of the bf16 NHWC tensor x: f32 results, f64 accumulation."""
+    npix, C = _bn_shape(x)
+    lib = _lib.load()
+    nbytes = lib.sq_bn_workspace_f32(npix, C)
+    if nbytes < 0:
+        raise _lib.SequitrHipError("bn_stats(bf16): unsupported channel count %d" % C)
+    ws = _workspace(nbytes, x.device)
+    mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+    var = torch.empty((C,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.sq_bn_stats_bf16(_ptr(x), _ptr(mean), _ptr(var), _ptr(ws), npix, C, _stream()), "sq_bn_stats_bf16")
+    return mean, var
+
+
+def bn_apply(x, scale, shift, act=None):
+    """y = act(fmaf(x, scale[c], shift[c])) rounded to bf16 (scale / shift f32: ops.bn_fold)."""
+    npix, C = _bn_shape(x)
+    _chk(scale, "scale", dtype=torch.float32), _chk(shift, "shift", dtype=torch.float32)
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().sq_bn_apply_bf16(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), npix, C, ACT[act], _stream()),
+               "sq_bn_apply_bf16")
+    return y
+
+
+def bn_inference(x, gamma, beta, moving_mean, moving_var, eps, act=None):
+    from . import ops
+    scale, shift = ops.bn_fold(gamma, beta, moving_mean, moving_var, eps)
+    return bn_apply(x, scale, shift, act)
+
+
+def bn_bwd(x, dy, y, act, mean, var, gamma, eps):
+    """(dx bf16, dgamma f32, dbeta f32) of y = act(BN_batchstats(x)); y is needed only when act is not None."""
+    npix, C = _bn_shape(x)
+    _chk(dy, "dy")
+    lib = _lib.load()
+    ws = _workspace(lib.sq_bn_workspace_f32(npix, C), x.device)
+    dx = torch.empty_like(x)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+    _lib.check(lib.sq_bn_bwd_bf16(_ptr(x), _ptr(dy), _ptr(y) if ACT[act] else None, ACT[act], _ptr(mean), _ptr(var),
+                                 _ptr(gamma), float(eps), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), npix, C,
+                                 _stream()), "sq_bn_bwd_bf16")
+    return dx, dgamma, dbeta
