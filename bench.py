@@ -1186,7 +1186,7 @@ def gan_line(args, world, rank, dist, dev):
     if rank == 0:
         samples = float(world) * nb * args.steps
         dev_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
-        peak_tf = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        peak_tf = PEAK_BF16_MFMA_TFLOPS if args.dtype in ("bf16", "mixed") else PEAK_F32_MFMA_TFLOPS
         f_mfma = wc.flops / (dev_ms * 1e-3) / 1e12 / peak_tf
         f_hbm = wc.bytes / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
         traffic, src = pmc_step_traffic("gan_" + args.dtype)
@@ -1238,7 +1238,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)       # >= 20 warm-up + >= 100 timed iterations
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16", help="--mode train / gan: compute dtype")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "mixed"], default="bf16", help="--mode train / gan: compute dtype")
     ap.add_argument("--fuse-up", type=int, default=1, help="1 = convT+bridge of up0 inside its first conv (infer mode)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive rate (infer mode)")
     ap.add_argument("--no-side-lines", action="store_true",

@@ -597,6 +597,52 @@ int sq_weightmap2_delaunay_f32(const float *img, const int32_t *simplices, const
                                float *out32, void *workspace, int N, int H, int W, double w0, double sigma, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GAN operators on bf16 FEATURE tensors (BASELINE config 5 with bf16 storage; sequitr/networks/gan.py:44-136, 149-316):
+ * activations and activation gradients are bf16 in HBM, every kernel computes in f32 and rounds once per stored value;
+ * parameters, images (<= 4 channels), the discriminator's outputs and the losses stay f32.  C % 8 == 0 everywhere.
+ *   pixel_norm (gan.py:49-51): fwd; bwd (act != NONE: x is that activation's output and dx also leaves through its
+ *   backward, second rounding kept: == sq_pixelnorm_bwd_bf16(NONE) then sq_act_bwd_bf16, bit for bit); bwd2 as
+ *   sq_pixelnorm_bwd2_f32.
+ *   half_size by averaging / double_size (gan.py:133-136, 189-192): sumpool (scale 0.25 = average pool) and its adjoint
+ *   broadcast (scale 1 = nearest-neighbour up-sampling), H and W are the LARGER tensor's size; *_act_bwd: the
+ *   up-sampled gradient additionally passes the backward of the activation whose output is `gate`.
+ *   to_image / from_image (gan.py:102-125) and their gradients: 1x1 convolutions between an f32 image side with
+ *   <= 4 channels and a bf16 feature side -- smallin (image -> features), smallout (features -> image),
+ *   wgrad1x1_small (m (Ca, C) = scale * sum_p a[p]^T b[p]; a == NULL: per-channel sums of b, from_image's bias gradient;
+ *   asum != NULL: (Ca) per-channel sums of a from the same pass, to_image's bias gradient).
+ *   Weights are f32 row-major (in, out), multiplied by wscale on the fly (equalised learning rate, gan.py:75-79).
+ * ---------------------------------------------------------------------------------------- */
+int sq_pixelnorm_fwd_bf16(const void *x, void *y, int64_t npix, int C, float eps, void *stream);
+int sq_pixelnorm_bwd_bf16(const void *x, const void *dy, void *dx, int64_t npix, int C, float eps, int act, void *stream);
+int sq_pixelnorm_bwd2_bf16(const void *x, const void *g, const void *v, void *dg, void *dx2, int64_t npix, int C, float eps,
+                           void *stream);
+int sq_sumpool2x2_bf16(const void *x, void *y, int N, int H, int W, int C, float scale, void *stream);
+int sq_broadcast2x2_bf16(const void *src, void *dst, int N, int H, int W, int C, float scale, void *stream);
+int sq_broadcast2x2_act_bwd_bf16(const void *src, const void *gate, void *dst, int N, int H, int W, int C, float scale,
+                                 int act, void *stream);
+int sq_act_fwd_bf16(const void *x, void *y, int64_t n, int act, void *stream);
+int sq_conv1x1_smallin_fwd_bf16(const float *x, const float *w, const float *bias, void *y, int64_t npix, int Ca, int C,
+                                float wscale, int act, void *stream);
+int sq_conv1x1_smallout_fwd_bf16(const void *x, const float *w, const float *bias, float *y, int64_t npix, int C, int Co,
+                                 float wscale, int act, void *stream);
+int64_t sq_wgrad1x1_small_workspace_bf16(int64_t npix, int Ca, int C);
+int sq_wgrad1x1_small_bf16(const float *a, const void *b, float *m, float *asum, float *workspace, int64_t npix, int Ca,
+                           int C, float scale, void *stream);
+/* weighted_conv2d (gan.py:61-99) on bf16 tensors: the forward is sq_conv2d_nhwc_fwd_bf16; these are the forms the
+ * mixed (f32 tensor) GAN path has beside it -- the dgrad that leaves through the previous activation's backward
+ * (== dgrad then sq_act_bwd_bf16, same two roundings), the small-image batch addressed as one mosaic (forward, or with
+ * `gate` the gated dgrad), and the weight gradient with the equalised-LR factor in the finish kernel, plain or mosaic.
+ * sq_conv2d_nhwc_wgrad_bf16 and the scaled form take channel counts that are multiples of 8 (8 mod 16: the ragged form). */
+int sq_conv2d_nhwc_dgrad_actgate_bf16(const void *dy, const void *wp_t, const void *gate, int act, void *dx, int N, int H,
+                                      int W, int Cin, int Cout, int K, void *stream);
+int sq_conv2d_nhwc_mosaic_bf16(const void *x, const void *wp, const float *bias, const void *gate, void *y, int Nimg, int h,
+                               int w, int Cin, int Cout, int act, int R, int Cc, void *stream);
+int sq_conv2d_nhwc_wgrad_scaled_bf16(const void *x, const void *dy, float *dw, float *db, float *workspace, int N, int H,
+                                     int W, int Cin, int Cout, int K, float dw_scale, void *stream);
+int sq_conv2d_nhwc_wgrad_mosaic_bf16(const void *x, const void *dy, float *dw, float *db, float *workspace, int Nimg, int h,
+                                     int w, int Cin, int Cout, int R, int Cc, float dw_scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Tile front end: raw single-channel camera frames in HBM (OctopusData .dat memmap,
  * sequitr/dataio/octopus.py:231-245) -> ImageNorm (sequitr/pipeline.py:350-356) -> network tiles, and the
  * tile masks back to full-frame masks.

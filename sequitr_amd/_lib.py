@@ -144,6 +144,21 @@ SIGNATURES = {
     "sq_conv1x1_head_wce_bwd_bf16": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, c_float, c_void_p]),
     "sq_act_dropout_bwd_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_float, c_int, c_void_p]),
     "sq_conv2d_nhwc_dgrad_relu_bf16": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    "sq_pixelnorm_fwd_bf16": (c_int, [c_void_p] * 2 + [c_int64, c_int, c_float, c_void_p]),
+    "sq_pixelnorm_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_float, c_int, c_void_p]),
+    "sq_pixelnorm_bwd2_bf16": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_float, c_void_p]),
+    "sq_sumpool2x2_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_float, c_void_p]),
+    "sq_broadcast2x2_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_float, c_void_p]),
+    "sq_broadcast2x2_act_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float, c_int, c_void_p]),
+    "sq_act_fwd_bf16": (c_int, [c_void_p] * 2 + [c_int64, c_int, c_void_p]),
+    "sq_conv1x1_smallin_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_float, c_int, c_void_p]),
+    "sq_conv1x1_smallout_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_float, c_int, c_void_p]),
+    "sq_wgrad1x1_small_workspace_bf16": (c_int64, [c_int64, c_int, c_int]),
+    "sq_wgrad1x1_small_bf16": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_float, c_void_p]),
+    "sq_conv2d_nhwc_dgrad_actgate_bf16": (c_int, [c_void_p] * 3 + [c_int, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "sq_conv2d_nhwc_mosaic_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "sq_conv2d_nhwc_wgrad_scaled_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),
+    "sq_conv2d_nhwc_wgrad_mosaic_bf16": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_float, c_void_p]),
     "sq_act_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
     "sq_bridge_fwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
     "sq_bridge_bwd_bf16": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_void_p]),

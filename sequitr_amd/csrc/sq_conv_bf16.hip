@@ -61,6 +61,7 @@ struct SqDropEpi {
     // of the tensor itself -- 1/16 of its bytes
     unsigned char *mask = nullptr;
     const float *gate_f32 = nullptr;                            // FORM_GF (f32 tensors): (N,H,W,Cout) activation output, slope in gscale
+    int gate_slope = 0;                                         // FORM_GB (bf16 tensors): `gate` is an activation output, slope in gscale
     // MOS (f32 tensors): the image the kernel tiles is a MOSAIC of mos_n small images (mos_h x mos_w, cells of pitch
     // h+1 / w+1 in a grid mos_cc wide, a zero row / column after every image standing in for the SAME padding --
     // sq_mosaic_pack_f32's layout) that is never materialised: loads, the gate and the stores address the compact
@@ -184,7 +185,9 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
 //   3 MK: sign mask of the output written beside it (mask)  4 MG: gate read from such a mask instead of a tensor
 //   5 GF: f32 tensors (the GAN's mixed form): the result leaves through the backward of the activation whose output
 //         `gate_f32` is -- dx = gate > 0 ? v : v * gscale -- the act_bwd pass that followed this dgrad
-enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4, FORM_GF = 5 };
+//   6 GB: the same on bf16 tensors (the GAN's bf16-storage form): t = bf16(v), dx = gate > 0 ? t : bf16(t * gscale) -- the two
+//         roundings of the dgrad -> sq_act_bwd_bf16 pair it replaces
+enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4, FORM_GF = 5, FORM_GB = 6 };
 template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN, bool MOS = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const TIO *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     using C = CfgB<BN, KS, KC>;
     constexpr int NR = BN / 16, PAD = KS / 2;
     constexpr bool JN = FORM == FORM_JN, PL = FORM == FORM_PL, MK = FORM == FORM_MK, MG = FORM == FORM_MG;
-    constexpr bool GF = FORM == FORM_GF;
+    constexpr bool GF = FORM == FORM_GF, GB = FORM == FORM_GB;
     constexpr bool F32IO = sizeof(TIO) == 4;                    // f32 activations in HBM, bf16 in LDS
     constexpr int ES = (int)sizeof(TIO), XV = F32IO ? 2 : 1;    // 16-byte loads per 8-channel LDS item
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         y, 0, (int)(io_pixels * Cout * ES), 0x00020000);
     // dgrad fused with the upstream ReLU's backward: outputs pass only where gate (N,H,W,Cout) > 0
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16 *>(gate), 0, gate ? (int)((size_t)N * H * W * Cout * 2) : 0, 0x00020000);
+        const_cast<__bf16 *>(gate), 0, gate ? (int)(io_pixels * Cout * 2) : 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
         drop.mask, 0, ((MK || MG) && drop.mask) ? (int)((size_t)N * H * W * Cout / 8) : 0, 0x00020000);
@@ -532,9 +535,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (mbits[r] >> j) & 1u ? (__bf16)((float)o[j] * drop.gscale) : (__bf16)0.f;
                 } else if (gate) {
+                    if constexpr (GB) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)         // bf16(o * 1.0f) == o: the plain ReLU gate costs no rounding
-                        o[j] = (float)gv[r][j] > 0.f ? (__bf16)((float)o[j] * drop.gscale) : (__bf16)0.f;
+                        for (int j = 0; j < 4; ++j) o[j] = (float)gv[r][j] > 0.f ? o[j] : (__bf16)((float)o[j] * drop.gscale);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)     // bf16(o * 1.0f) == o: the plain ReLU gate costs no rounding
+                            o[j] = (float)gv[r][j] > 0.f ? (__bf16)((float)o[j] * drop.gscale) : (__bf16)0.f;
+                    }
                 }
                 if (drop.thr) {
                     const unsigned k4 = sq_dropout_keep4(dkey, offs[r] >> 3, drop.thr);    // quad index (offsets are in bytes)
@@ -707,6 +715,12 @@ int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int
             return drop.gate_f32 ? launch<BN, KS, KC, TIO, FORM_GF, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop)
                                  : launch<BN, KS, KC, TIO, FORM_PLAIN, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
         if (drop.gate_f32) return launch<BN, KS, KC, TIO, FORM_GF>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+    }
+    if constexpr (FORM == FORM_PLAIN && !MOS && sizeof(TIO) == 2) {
+        if (drop.mos_h && KS == 3)
+            return drop.gate_slope ? launch<BN, KS, KC, TIO, FORM_GB, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop)
+                                   : launch<BN, KS, KC, TIO, FORM_PLAIN, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+        if (drop.gate_slope) return launch<BN, KS, KC, TIO, FORM_GB>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
     }
     if constexpr (FORM == FORM_PLAIN && KS == 3 && sizeof(TIO) == 2) {
         if (drop.j_g) return launch<BN, KS, KC, TIO, FORM_JN>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
@@ -926,6 +940,39 @@ extern "C" int sq_conv2d_nhwc_mixed_mosaic_f32(const float *x, const void *wp, c
 extern "C" int sq_conv2d_nhwc_fwd_bf16(const void *x, const void *wp, const float *bias, void *y, int N, int H,
                                        int W, int Cin, int Cout, int K, int act, void *stream) {
     return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, K, act, stream, nullptr);
+}
+
+// dgrad of a conv on bf16 tensors whose input was the output `gate` of a leaky-ReLU / ReLU (the GAN's conv -> leaky -> conv
+// chains under bf16 storage): sq_conv2d_nhwc_fwd_bf16 on dY with the dgrad pack followed by sq_act_bwd_bf16, in one kernel,
+// same two roundings, same bits
+extern "C" int sq_conv2d_nhwc_dgrad_actgate_bf16(const void *dy, const void *wp_t, const void *gate, int act, void *dx, int N,
+                                                 int H, int W, int Cin, int Cout, int K, void *stream) {
+    SQ_REQUIRE(gate, "sq_conv2d_nhwc_dgrad_actgate_bf16: null gate");
+    SQ_REQUIRE(act == SQ_ACT_RELU || act == SQ_ACT_LEAKY, "sq_conv2d_nhwc_dgrad_actgate_bf16: activation %d has no gate", act);
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    d.gate_slope = 1;
+    d.gscale = act == SQ_ACT_LEAKY ? 0.2f : 0.0f;
+    return conv_fwd_bf16_impl(dy, wp_t, nullptr, dx, N, H, W, Cin, Cout, K, SQ_ACT_NONE, stream, gate, d);
+}
+
+// sq_conv2d_nhwc_mixed_mosaic_f32 on bf16 tensors: a batch of small images (Nimg, h, w, C) convolved as one mosaic image of
+// R x Cc cells that is never built.  gate == NULL: plain forward (bias / act apply); gate != NULL: the act-gated dgrad above.
+extern "C" int sq_conv2d_nhwc_mosaic_bf16(const void *x, const void *wp, const float *bias, const void *gate, void *y, int Nimg,
+                                          int h, int w, int Cin, int Cout, int act, int R, int Cc, void *stream) {
+    SQ_REQUIRE(Nimg > 0 && h > 0 && w > 0 && R > 0 && Cc > 0 && (int64_t)R * Cc >= Nimg,
+               "sq_conv2d_nhwc_mosaic_bf16: need R * Cc >= Nimg (Nimg=%d R=%d Cc=%d)", Nimg, R, Cc);
+    SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY && (!gate || act != SQ_ACT_NONE), "sq_conv2d_nhwc_mosaic_bf16: bad activation %d", act);
+    const int H = R * (h + 1), W = Cc * (w + 1);
+    SQ_REQUIRE(h <= 8 && w <= 8 && H < (1 << 13) && W < (1 << 13), "sq_conv2d_nhwc_mosaic_bf16: images up to 8 x 8, mosaic < 8192");
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    d.mos_h = h; d.mos_w = w; d.mos_cc = Cc; d.mos_n = Nimg;
+    d.mos_mh = (65536u + (unsigned)h) / (unsigned)(h + 1);      // ceil(2^16 / (h+1))
+    d.mos_mw = (65536u + (unsigned)w) / (unsigned)(w + 1);
+    if (gate) {
+        d.gate_slope = 1;
+        d.gscale = act == SQ_ACT_LEAKY ? 0.2f : 0.0f;
+    }
+    return conv_fwd_bf16_impl(x, wp, gate ? nullptr : bias, y, 1, H, W, Cin, Cout, 3, gate ? (int)SQ_ACT_NONE : act, stream, gate, d);
 }
 
 // conv + bias + act + dropout in one kernel (training): y = dropout(act(conv(x))) with the counter-hash mask of

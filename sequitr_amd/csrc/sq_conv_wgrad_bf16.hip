@@ -84,7 +84,9 @@ struct SqMos {
     unsigned mh = 0, mw = 0;                                    // ceil(2^16 / (h+1)), ceil(2^16 / (w+1))
 };
 
-template <int KS, int NI, int NO, int PF, typename TIO, bool MOS = false>
+// RAG: Cin and / or Cout is 8 mod 16 (the GAN's 256 x 256 level): the last 16-channel plane of that operand is half
+// empty -- its upper 8 channels load as zeros and the finish kernel drops their rows / columns
+template <int KS, int NI, int NO, int PF, typename TIO, bool MOS = false, bool RAG = false>
 __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf16_kernel(
     const TIO *__restrict__ x, const TIO *__restrict__ dy, float *__restrict__ partials, int N, int H,
     int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block, SqMos mos) {
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
     unsigned char *xs = smem, *ys = smem + C::XS_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kg = lane >> 4, q = li >> 2, p = li & 3;
-    const int nco = Cout / C::CO;
+    const int nco = (Cout + C::CO - 1) / C::CO;
     const int ci0 = (blockIdx.y / nco) * C::CI, co0 = (blockIdx.y % nco) * C::CO;
     const int t_begin = blockIdx.x * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
 
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
                 off = (unsigned)((pc * Cin + ci0 + ((tid + sl * 256) % (2 * NI)) * 8) * ES);
             } else {
                 inb = (unsigned)(y0 - PAD + py) < (unsigned)H && (unsigned)(x0 - PAD + px) < (unsigned)W;
+                if constexpr (RAG) inb = inb && ci0 + ((tid + sl * 256) % (2 * NI)) * 8 < Cin;
                 off = inb ? (unsigned)(xbase + xrel[sl]) : OOB;
             }
 #pragma unroll
@@ -166,6 +169,7 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
                 off = (unsigned)((pc * Cout + co0 + rem * 8) * ES);
             } else {
                 inb = (y0 + py) < H && (x0 + px) < W;
+                if constexpr (RAG) inb = inb && co0 + rem * 8 < Cout;
                 off = inb ? (unsigned)(ybase + ((py * W + px) * Cout + rem * 8) * ES) : OOB;
             }
 #pragma unroll
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float
                                                                       int ct) {
     using C = WB<KS, NI, NO>;
     __shared__ float red[4][256];
-    const int nco = Cout / C::CO, npairs = (Cin / C::CI) * nco;
+    const int nco = (Cout + C::CO - 1) / C::CO, npairs = ((Cin + C::CI - 1) / C::CI) * nco;
     const int total = npairs * C::RED_FLOATS;
     const int OUT = 256 / G;
     const int ol = threadIdx.x % OUT, g = threadIdx.x / OUT;
@@ -350,6 +354,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float
     const int pair = live ? j / C::RED_FLOATS : 0, r = live ? j % C::RED_FLOATS : 0, row = r / C::CO, col = r % C::CO;
     const int co = (pair % nco) * C::CO + col;
     const bool bias_row = row == C::NTAP * C::CI;
+    // ragged channel counts (8 mod 16): rows / columns past the tensor are zeros of the padding, not gradients
+    const bool inside = co < Cout && (bias_row || (pair / nco) * C::CI + row % C::CI < Cin);
     // transpose conv (ct > 0): db[c] = ((q0 + q1) + q2) + q3 over the sub-pixel columns q * ct + c; the lanes of
     // column c (q = 0) reduce the other three columns as well
     const bool fold = ct > 0 && live && bias_row && pair / nco == 0 && co < ct;
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float
         }
         __syncthreads();
     }
-    if (g != 0 || !live) return;
+    if (g != 0 || !live || !inside) return;
     const float s = red[0][threadIdx.x];
     if (!bias_row) {
         const int tap = row / C::CI, ci = (pair / nco) * C::CI + row % C::CI;
@@ -389,7 +395,7 @@ template <int KS, int NI, int NO>
 void plan(int N, int H, int W, int Cin, int Cout, int *gx, int *tpb, int64_t *ws_floats) {
     using C = WB<KS, NI, NO>;
     const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * N;
-    const int npairs = (Cin / C::CI) * (Cout / C::CO);
+    const int npairs = ((Cin + C::CI - 1) / C::CI) * ((Cout + C::CO - 1) / C::CO);
     int want = (512 + npairs - 1) / npairs;
     if (want < 1) want = 1;
     int t = (ntiles + want - 1) / want;
@@ -402,7 +408,7 @@ void plan(int N, int H, int W, int Cin, int Cout, int *gx, int *tpb, int64_t *ws
 template <int KS, int NI, int NO>
 int finish(float *ws, float *dw, float *db, int gx, int Cin, int Cout, hipStream_t st) {
     using C = WB<KS, NI, NO>;
-    const int npairs = (Cin / C::CI) * (Cout / C::CO);
+    const int npairs = ((Cin + C::CI - 1) / C::CI) * ((Cout + C::CO - 1) / C::CO);
     int G = sq_group_size(gx);
     if (G > 16) G = 16;                                         // >= 16 consecutive floats (64 B) per load of a group
     const int64_t total = (int64_t)npairs * C::RED_FLOATS;
@@ -413,12 +419,12 @@ int finish(float *ws, float *dw, float *db, int gx, int Cin, int Cout, hipStream
 }
 
 // the mosaic form (f32 tensors, 3x3): same plan, same finish; X / dY are the compact small-image tensors
-template <int KS, int NI, int NO, int PF>
-int launch_mos(const float *x, const float *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin, int Cout,
+template <int KS, int NI, int NO, int PF, typename TIO>
+int launch_mos(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin, int Cout,
                hipStream_t st) {
     using C = WB<KS, NI, NO>;
     static bool attr_set = false;
-    auto kern = conv_wgrad_bf16_kernel<KS, NI, NO, PF, float, true>;
+    auto kern = conv_wgrad_bf16_kernel<KS, NI, NO, PF, TIO, true>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
@@ -448,8 +454,8 @@ int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, 
     constexpr int acc_regs = C::NTAP * NI * NO * 4, set_regs = (C::XSLOTS + C::YSLOTS) * 4 * (int)(sizeof(TIO) / 2);
     constexpr int budget = (wgrad_occ<KS, NI, NO>() == 1 ? 300 : SQ_WGRAD_BUDGET2) - acc_regs - 40;
     constexpr int PF = budget / set_regs >= 4 ? 4 : (budget / set_regs >= 3 ? 3 : (budget / set_regs >= 2 ? 2 : 1));
-    if constexpr (sizeof(TIO) == 4 && KS == 3) {
-        if (t_mos.h) return launch_mos<KS, NI, NO, PF>(x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
+    if constexpr (KS == 3) {
+        if (t_mos.h) return launch_mos<KS, NI, NO, PF, TIO>(x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
     }
     auto kern = conv_wgrad_bf16_kernel<KS, NI, NO, PF, TIO>;
     if (!attr_set) {
@@ -472,6 +478,34 @@ int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, 
     return finish<KS, NI, NO>(ws, dw, db, gx, Cin, Cout, st);
 }
 
+
+// ragged channel counts (Cin or Cout = 8 mod 16): 16 x 16 channel blocks, the half-empty plane masked in the loader
+template <int KS, typename TIO>
+int launch_rag(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin, int Cout,
+               hipStream_t st) {
+    using C = WB<KS, 1, 1>;
+    static bool attr_set = false;
+    constexpr int PF = sizeof(TIO) == 4 ? 2 : 4;
+    auto kern = conv_wgrad_bf16_kernel<KS, 1, 1, PF, TIO, false, true>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess) {
+            sq_set_error("conv_wgrad_bf16: cannot reserve %d bytes of LDS", C::LDS_BYTES);
+            return SQ_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    int gx, tpb;
+    int64_t wsf;
+    plan<KS, 1, 1>(N, H, W, Cin, Cout, &gx, &tpb, &wsf);
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int npairs = ((Cin + 15) / 16) * ((Cout + 15) / 16);
+    hipLaunchKernelGGL(kern, dim3(gx, npairs), dim3(256), C::LDS_BYTES, st, x, dy, ws, N, H, W, Cin, Cout, tiles_x, tiles_y,
+                       tiles_x * tiles_y * N, tpb, SqMos{});
+    int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_bf16(ragged)");
+    if (rc) return rc;
+    return finish<KS, 1, 1>(ws, dw, db, gx, Cin, Cout, st);
+}
 
 // SQ_WGRAD_BF16_NARROW=1: 16 x 16 channel blocks everywhere (A/B switch for the wider blocks);
 // SQ_WGRAD_BF16_MAX="ni,no": upper bound on the block shape (tuning experiments)
@@ -530,6 +564,7 @@ int64_t plan_floats(int N, int H, int W, int Cin, int Cout, int K) {
     int gx, tpb;
     int64_t wsf = 0;
 #define SQ_PLAN_CALL(KS_, NI_, NO_) (plan<KS_, NI_, NO_>(N, H, W, Cin, Cout, &gx, &tpb, &wsf), wsf)
+    if (Cin % 16 || Cout % 16) return K == 3 ? SQ_PLAN_CALL(3, 1, 1) : SQ_PLAN_CALL(1, 1, 1);
     const bool wide = !narrow_blocks();
     int mi_, mo_;
     max_shape(&mi_, &mo_);
@@ -565,6 +600,9 @@ int launch_f(const float *x, const float *dy, float *dw, float *db, float *ws, i
 
 int launch_any(const __bf16 *x, const __bf16 *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin,
                int Cout, int K, hipStream_t st) {
+    if (Cin % 16 || Cout % 16)
+        return K == 3 ? launch_rag<3, __bf16>(x, dy, dw, db, ws, N, H, W, Cin, Cout, st)
+                      : launch_rag<1, __bf16>(x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
     SQ_WGRAD_BF16_DISPATCH(launch_b, x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
 }
 int launch_any_mixed(const float *x, const float *dy, float *dw, float *db, float *ws, int N, int H, int W, int Cin,
@@ -573,7 +611,9 @@ int launch_any_mixed(const float *x, const float *dy, float *dw, float *db, floa
 }
 
 bool ok_shape(int N, int H, int W, int Cin, int Cout, int K, int elem_bytes = 2) {
-    return N > 0 && H > 0 && W > 0 && (K == 1 || K == 3) && Cin > 0 && Cin % 16 == 0 && Cout > 0 && Cout % 16 == 0 &&
+    // bf16 tensors: channel counts that are 8 mod 16 run the ragged form; the mixed (f32 tensor) entries keep % 16
+    const int m = elem_bytes == 2 ? 8 : 16;
+    return N > 0 && H > 0 && W > 0 && (K == 1 || K == 3) && Cin > 0 && Cin % m == 0 && Cout > 0 && Cout % m == 0 &&
            (size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * elem_bytes < ((size_t)1 << 31);
 }
 
@@ -589,7 +629,9 @@ extern "C" int sq_conv2d_nhwc_wgrad_bf16(const void *x, const void *dy, float *d
                                          int N, int H, int W, int Cin, int Cout, int K, void *stream) {
     SQ_REQUIRE(x && dy && dw && workspace, "sq_conv2d_nhwc_wgrad_bf16: null pointer");
     SQ_REQUIRE(ok_shape(N, H, W, Cin, Cout, K),
-               "sq_conv2d_nhwc_wgrad_bf16: unsupported shape Cin=%d Cout=%d K=%d (both %% 16, K 1|3, < 2 GiB)", Cin, Cout, K);
+               "sq_conv2d_nhwc_wgrad_bf16: unsupported shape Cin=%d Cout=%d K=%d (both %% 8, K 1|3, < 2 GiB)", Cin, Cout, K);
+    SQ_REQUIRE(!(t_mos.h || t_convT_cout) || (Cin % 16 == 0 && Cout % 16 == 0),
+               "sq_conv2d_nhwc_wgrad_bf16: the mosaic / transpose-conv forms need channel counts that are multiples of 16");
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(dy); SQ_REQUIRE_ALIGNED(workspace);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *yb = reinterpret_cast<const __bf16 *>(dy);
@@ -654,5 +696,32 @@ extern "C" int sq_conv2d_nhwc_wgrad_scaled_mixed_f32(const float *x, const float
     t_dw_scale = dw_scale;
     const int rc = sq_conv2d_nhwc_wgrad_mixed_f32(x, dy, dw, db, workspace, N, H, W, Cin, Cout, K, stream);
     t_dw_scale = 1.0f;
+    return rc;
+}
+
+// the two GAN forms above on bf16 tensors (bf16 storage, config 5): dW times dw_scale in the finish kernel ...
+extern "C" int sq_conv2d_nhwc_wgrad_scaled_bf16(const void *x, const void *dy, float *dw, float *db, float *workspace, int N,
+                                                int H, int W, int Cin, int Cout, int K, float dw_scale, void *stream) {
+    t_dw_scale = dw_scale;
+    const int rc = sq_conv2d_nhwc_wgrad_bf16(x, dy, dw, db, workspace, N, H, W, Cin, Cout, K, stream);
+    t_dw_scale = 1.0f;
+    return rc;
+}
+
+// ... and the batch of small images addressed as one mosaic (3x3; Cin, Cout % 16 == 0).
+// Workspace: sq_conv2d_nhwc_wgrad_workspace_bf16(1, R*(h+1), Cc*(w+1), Cin, Cout, 3).
+extern "C" int sq_conv2d_nhwc_wgrad_mosaic_bf16(const void *x, const void *dy, float *dw, float *db, float *workspace, int Nimg,
+                                                int h, int w, int Cin, int Cout, int R, int Cc, float dw_scale, void *stream) {
+    SQ_REQUIRE(Nimg > 0 && h > 0 && w > 0 && h <= 8 && w <= 8 && R > 0 && Cc > 0 && (int64_t)R * Cc >= Nimg,
+               "sq_conv2d_nhwc_wgrad_mosaic_bf16: images up to 8 x 8, R * Cc >= Nimg (Nimg=%d R=%d Cc=%d)", Nimg, R, Cc);
+    const int H = R * (h + 1), W = Cc * (w + 1);
+    SQ_REQUIRE(H < (1 << 13) && W < (1 << 13), "sq_conv2d_nhwc_wgrad_mosaic_bf16: mosaic < 8192");
+    t_mos.h = h; t_mos.w = w; t_mos.cc = Cc; t_mos.n = Nimg;
+    t_mos.mh = (65536u + (unsigned)h) / (unsigned)(h + 1);
+    t_mos.mw = (65536u + (unsigned)w) / (unsigned)(w + 1);
+    t_dw_scale = dw_scale;
+    const int rc = sq_conv2d_nhwc_wgrad_bf16(x, dy, dw, db, workspace, 1, H, W, Cin, Cout, 3, stream);
+    t_dw_scale = 1.0f;
+    t_mos = SqMos{};
     return rc;
 }

@@ -38,18 +38,31 @@ __global__ __launch_bounds__(256) void dense_partial_kernel(const float *__restr
 #pragma unroll
     for (int m = 0; m < DM; ++m) acc[m] = 0.f;
     if (n < N) {
-        for (int kq = 0; kq < DK / 4; ++kq) {
-            const int k = k0 + 4 * kq;
-            float wv[4];
+        // 16 weights (four k-quads) of this column are in flight while the previous 16 are multiplied: loading four at a
+        // time inside the loop exposed an HBM round trip per quad (40 us for 7 us of arithmetic)
+        constexpr int WB = 16;
+        float wn[WB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wv[j] = (k + j < K) ? w[(size_t)(k + j) * N + n] * wscale : 0.f;
+        for (int j = 0; j < WB; ++j) wn[j] = (k0 + j < K) ? w[(size_t)(k0 + j) * N + n] : 0.f;
+#pragma unroll 1
+        for (int kb = 0; kb < DK; kb += WB) {
+            float wc[WB];
 #pragma unroll
-            for (int m = 0; m < DM; ++m) {
-                const float4 xv = xs[kq][m];
-                acc[m] = fmaf(wv[0], xv.x, acc[m]);
-                acc[m] = fmaf(wv[1], xv.y, acc[m]);
-                acc[m] = fmaf(wv[2], xv.z, acc[m]);
-                acc[m] = fmaf(wv[3], xv.w, acc[m]);
+            for (int j = 0; j < WB; ++j) wc[j] = wn[j] * wscale;
+            if (kb + WB < DK) {
+#pragma unroll
+                for (int j = 0; j < WB; ++j) wn[j] = (k0 + kb + WB + j < K) ? w[(size_t)(k0 + kb + WB + j) * N + n] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < WB / 4; ++q) {
+#pragma unroll
+                for (int m = 0; m < DM; ++m) {
+                    const float4 xv = xs[kb / 4 + q][m];
+                    acc[m] = fmaf(wc[4 * q + 0], xv.x, acc[m]);
+                    acc[m] = fmaf(wc[4 * q + 1], xv.y, acc[m]);
+                    acc[m] = fmaf(wc[4 * q + 2], xv.z, acc[m]);
+                    acc[m] = fmaf(wc[4 * q + 3], xv.w, acc[m]);
+                }
             }
         }
 #pragma unroll
@@ -58,15 +71,36 @@ __global__ __launch_bounds__(256) void dense_partial_kernel(const float *__restr
     }
 }
 
+// G thread groups per block: group g adds slices g, g + G, ... in order (four loads in flight), a fixed LDS tree folds the
+// groups; threads of a group walk consecutive outputs (coalesced rows of 256 / G floats).  One thread walking all S slices
+// was a chain of S dependent round trips (31 us for S = 129).
 __global__ __launch_bounds__(256) void dense_finish_kernel(const float *__restrict__ part, const float *__restrict__ bias,
-                                                           float *__restrict__ y, int S, int M, int N, int act) {
+                                                           float *__restrict__ y, int S, int M, int N, int act, int G) {
+    __shared__ float red[256];
     const int64_t total = (int64_t)M * N;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        float v = 0.f;
-        for (int s = 0; s < S; ++s) v += part[(size_t)s * total + i];
-        if (bias) v += bias[i % N];
-        y[i] = sq_act(v, act);
+    const int OUT = 256 / G, ol = threadIdx.x % OUT, g = threadIdx.x / OUT;
+    const int64_t i = (int64_t)blockIdx.x * OUT + ol;
+    float s = 0.f;
+    if (i < total) {
+        const float *p = part + i;
+        int b = g;
+        for (; b + 3 * G < S; b += 4 * G) {
+            const float v0 = p[(size_t)b * total], v1 = p[(size_t)(b + G) * total], v2 = p[(size_t)(b + 2 * G) * total],
+                        v3 = p[(size_t)(b + 3 * G) * total];
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; b < S; b += G) s += p[(size_t)b * total];
     }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = G >> 1; m > 0; m >>= 1) {
+        if (g < m) red[threadIdx.x] += red[threadIdx.x + m * OUT];
+        __syncthreads();
+    }
+    if (g != 0 || i >= total) return;
+    float v = red[threadIdx.x];
+    if (bias) v += bias[i % N];
+    y[i] = sq_act(v, act);
 }
 
 }  // namespace
@@ -89,8 +123,9 @@ extern "C" int sq_dense_fwd_f32(const float *x, const float *w, const float *bia
     hipLaunchKernelGGL(dense_partial_kernel, grid, dim3(256), 0, st, x, w, workspace, M, K, N, wscale);
     int rc = sq_check_launch("sq_dense_fwd_f32(partial)");
     if (rc) return rc;
-    int64_t nb = ((int64_t)M * N + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(dense_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, workspace, bias, y, S, M, N, act);
+    int G = sq_group_size(S);
+    if (G > 8) G = 8;                                           // >= 32 consecutive floats per load row
+    const int64_t nb = ((int64_t)M * N + 256 / G - 1) / (256 / G);
+    hipLaunchKernelGGL(dense_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, workspace, bias, y, S, M, N, act, G);
     return sq_check_launch("sq_dense_fwd_f32");
 }

@@ -320,6 +320,23 @@ def conv1x1_head(x, w, bias=None):
     return _Head.apply(x, w, bias)
 
 
+class _Cast(torch.autograd.Function):
+    """storage cast float32 <-> bfloat16 (linear: its derivative is the cast back, to any order)"""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return ops.cast(x.contiguous(), dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _Cast.apply(dy, ctx.src), None
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else _Cast.apply(x, dtype)
+
+
 # ---------------------------------------------------------------------------------------------
 # pixel norm (gan.py:49-51), up to second order
 # ---------------------------------------------------------------------------------------------

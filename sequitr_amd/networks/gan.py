@@ -109,6 +109,7 @@ def minibatch_stdev(x, groups=1):
     constant feature map (N,4,4,1): one workgroup per minibatch (sq_mbstd_map_*_f32, differentiable twice).
     groups > 1: x is `groups` minibatches stacked along the batch axis, each gets its own statistic
     (the reference evaluates the discriminator once per minibatch; see _build_network)."""
+    x = F.cast(x, torch.float32)          # bf16 storage: the statistic (32 x 16 x 512 values) is taken of the f32 copy
     return F.mbstd_map(x, groups, 16).reshape(x.shape[0], 4, 4, 1)
 
 
@@ -131,7 +132,7 @@ def discriminator_network(x, filters, groups=1):
         mbstd = minibatch_stdev(x, groups)
         conv = weighted_conv2d(inputs=x, filters=filters[-1], kernel_size=[3, 3],
                                activation=k_leaky_relu_alpha, name='conv', norm=False)
-        conv = torch.cat([conv, mbstd], dim=-1)
+        conv = torch.cat([F.cast(conv, torch.float32), mbstd], dim=-1)   # the dense head is f32 (bf16 storage ends here)
         pool_flat = conv.reshape(-1, 4 * 4 * (filters[-1] + 1))
         hidden = dense(pool_flat, filters[-1], activation=k_leaky_relu_alpha, name='dense')
         logits = dense(hidden, 1, name='logits')
@@ -145,6 +146,8 @@ def generator_network(z, filters, start_shape=(4, 4)):
         num_units = int(np.prod(initial_shape))
         d = dense(pixel_norm(z), num_units, activation=k_leaky_relu_alpha, name='dense1')
         reshaped = pixel_norm(d.reshape((-1,) + initial_shape))
+        if ops.STORE_BF16:                                      # bf16 storage starts at the first feature map
+            reshaped = F.cast(reshaped, torch.bfloat16)
         conv0 = weighted_conv2d(inputs=reshaped, filters=filters[0], kernel_size=[3, 3],
                                 activation=k_leaky_relu_alpha, name='conv', norm=True)
     conv_layers = [conv0]
@@ -232,7 +235,8 @@ class GenerativeAdverserialNetwork(object):
     params: num_outputs, batch_size, repeat_batch, num_levels, num_epochs_per_level, start_size,
     training_data (``.npy`` (N,H,W,C) stack; None -> synthetic tiles), learning_rate; new keys:
     device, seed, num_batches_per_epoch (when the data is synthetic), dtype ('f32' default: exact-f32 MFMA
-    convolutions; 'bf16': the f32 graph with bf16-multiply / f32-accumulate convolutions, BASELINE config 5),
+    convolutions; 'bf16': BASELINE config 5 -- bf16-multiply / f32-accumulate convolutions AND bf16 storage of every
+    feature map and feature-map gradient, f32 parameters / images / losses; 'mixed': the bf16 multiplies behind f32 tensors),
     graph (default False: True replays the solver steps as hipGraphs), batch_d (default True: the discriminator sees
     the generated and the real minibatch as one stacked batch, each with its own minibatch statistic)."""
 
@@ -258,8 +262,8 @@ class GenerativeAdverserialNetwork(object):
         self._plan = None
         self._capture_stream = None
         self.dtype = params.get('dtype', 'f32')
-        if self.dtype not in ('f32', 'bf16'):
-            raise ValueError("dtype must be 'f32' or 'bf16', got %r" % (self.dtype,))
+        if self.dtype not in ('f32', 'bf16', 'mixed'):
+            raise ValueError("dtype must be 'f32', 'bf16' or 'mixed', got %r" % (self.dtype,))
         dev = params.get('device', None)
         self.device = torch.device(dev) if dev is not None else torch.device('cuda', torch.cuda.current_device())
         if self.device.type != 'cuda':
@@ -373,7 +377,7 @@ class GenerativeAdverserialNetwork(object):
     def _pack_filters(self):
         """dtype 'bf16': every bf16 filter pack of the solver step (forward + dgrad form of each equalised-LR conv
         kernel) in one launch; the packs stay valid until the step's Adam update (ops.FilterPackPlan)."""
-        if self.dtype != 'bf16' or self.store.flat is None:
+        if self.dtype == 'f32' or self.store.flat is None:
             return
         if self._plan is None:
             named = []
@@ -449,7 +453,7 @@ class GenerativeAdverserialNetwork(object):
 
     def precision(self):
         """context for everything this network launches (forward AND backward): `with net.precision(): ...`"""
-        return ops.mixed_precision(self.dtype == 'bf16')
+        return ops.mixed_precision(self.dtype != 'f32', store_bf16=self.dtype == 'bf16')
 
     @property
     def last_losses(self):

@@ -89,23 +89,36 @@ MOSAIC_IN_KERNEL = os.environ.get("SQ_MOSAIC_IN_KERNEL", "1") != "0"   # A/B: mo
 # flag is set, conv2d / conv2d_dgrad / conv2d_wgrad route every layer the mixed kernels take (Cin % 8, Cout % 4;
 # wgrad: both % 16) to them; image-side 1x1 convs (to_image / from_image / class heads) and dense stay f32.
 MIXED = False
+# bf16 STORAGE on top of the bf16 multiplies (the GAN's dtype 'bf16'): feature tensors (C % 8 == 0) are bf16 in HBM, image
+# tensors (<= 4 channels) stay f32.  The flag only decides what an image-side 1x1 conv emits; everything downstream
+# dispatches on the tensor dtype (ops_gan_bf16.py).
+STORE_BF16 = False
+_BF16 = torch.bfloat16
+
+
+def _gb():
+    from . import ops_gan_bf16
+    return ops_gan_bf16
 
 
 class mixed_precision:
     """`with ops.mixed_precision():` -- bf16-multiply convolutions for everything launched inside, including a
-    backward pass run inside the block (the GAN's `dtype='bf16'`, BASELINE config 5)."""
+    backward pass run inside the block (the GAN's `dtype='mixed'`); store_bf16=True additionally keeps the feature
+    tensors in bf16 (`dtype='bf16'`, BASELINE config 5)."""
 
-    def __init__(self, on=True):
+    def __init__(self, on=True, store_bf16=False):
         self.on = bool(on)
+        self.store = bool(store_bf16) and self.on
 
     def __enter__(self):
-        global MIXED
-        self.prev, MIXED = MIXED, self.on
+        global MIXED, STORE_BF16
+        self.prev, MIXED = (MIXED, STORE_BF16), self.on
+        STORE_BF16 = self.store
         return self
 
     def __exit__(self, *exc):
-        global MIXED
-        MIXED = self.prev
+        global MIXED, STORE_BF16
+        MIXED, STORE_BF16 = self.prev
         if not MIXED:
             _PACKS.clear()
         return False
@@ -240,6 +253,8 @@ def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None, _dgrad=False):
     Batches of small images (H, W <= 8) run as one mosaic image (3x3) or as a flat pixel strip (1x1):
     same fmaf chain per output, far fewer and fuller 16x16 tiles.
     _dgrad (internal): `w` is the filter (K,K,Cout,Cin) of the forward conv whose input gradient this is."""
+    if out is None and (x.dtype == _BF16 or STORE_BF16) and _gb().takes(x, w, _dgrad):
+        return _gb().conv2d(x, w, bias, act, wscale, _dgrad)
     _chk(x, "x", ndim=4), _chk(w, "w", ndim=4)
     N, H, W, Cin = x.shape
     if _dgrad:
@@ -314,6 +329,8 @@ def maxpool2x2(x, out=None):
 
 
 def avgpool2x2(x, out=None):
+    if x.dtype == _BF16 and out is None:
+        return _gb().sumpool2x2(x, 0.25)
     return _pool(x, "sq_avgpool2x2_fwd_f32", out)
 
 
@@ -379,6 +396,8 @@ def argmax_u8(logits):
 
 
 def pixelnorm(x, eps=1e-8, out=None):
+    if x.dtype == _BF16 and out is None:
+        return _gb().pixelnorm(x, eps)
     _chk(x, "x")
     C = x.shape[-1]
     y = _out(out, x.shape, x)
@@ -598,6 +617,8 @@ def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None, dw_scale=1.
 
 
 def act_bwd(dy, y, act):
+    if dy.dtype == _BF16:
+        return _gb().act_bwd(dy, y, act)
     _chk(dy, "dy"), _chk(y, "y")
     if ACT[act] == 0:
         return dy
@@ -618,6 +639,8 @@ def maxpool2x2_bwd(x, dy):
 
 def broadcast2x2(src, scale=1.0):
     """(N,h,w,C) -> (N,2h,2w,C), every source pixel copied (x scale) to its 2x2 patch."""
+    if src.dtype == _BF16:
+        return _gb().broadcast2x2(src, scale)
     _chk(src, "src", ndim=4)
     N, h, w, C = src.shape
     dst = torch.empty((N, 2 * h, 2 * w, C), dtype=torch.float32, device=src.device)
@@ -629,6 +652,8 @@ def broadcast2x2(src, scale=1.0):
 
 def broadcast2x2_act_bwd(src, gate, scale, act):
     """scale * 2x nearest up-sampling of src, passed through the backward of the activation whose output is `gate`"""
+    if src.dtype == _BF16:
+        return _gb().broadcast2x2_act_bwd(src, gate, scale, act)
     _chk(src, "src", ndim=4), _chk(gate, "gate", ndim=4)
     N, h, w, C = src.shape
     if tuple(gate.shape) != (N, 2 * h, 2 * w, C):
@@ -641,6 +666,8 @@ def broadcast2x2_act_bwd(src, gate, scale, act):
 
 def sumpool2x2(x, scale=1.0):
     """scale * (sum of every 2x2 patch); any channel count."""
+    if x.dtype == _BF16:
+        return _gb().sumpool2x2(x, scale)
     _chk(x, "x", ndim=4)
     N, H, W, C = x.shape
     y = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
@@ -736,6 +763,8 @@ def axpy_(y, x, alpha=1.0):
 # ----------------------------------------------------------------------------------------------
 def pixelnorm_bwd(x, dy, eps=1e-8, act=None):
     """dx of pixel_norm; act: x is the output of that activation and its backward is applied in the same pass"""
+    if x.dtype == _BF16:
+        return _gb().pixelnorm_bwd(x, dy, eps, act)
     _chk(x, "x"), _chk(dy, "dy")
     C = x.shape[-1]
     dx = torch.empty_like(x)
@@ -751,6 +780,8 @@ def pixelnorm_bwd(x, dy, eps=1e-8, act=None):
 
 def pixelnorm_bwd2(x, g, v, eps=1e-8):
     """second-order: (dL/dg, dL/dx) of dx = pixelnorm_bwd(x, g) given v = dL/d(dx)."""
+    if x.dtype == _BF16:
+        return _gb().pixelnorm_bwd2(x, g, v, eps)
     _chk(x, "x"), _chk(g, "g"), _chk(v, "v")
     C = x.shape[-1]
     dg, dx2 = torch.empty_like(x), torch.empty_like(x)
@@ -801,7 +832,14 @@ def scale(x, s, one_minus=False):
     return y
 
 
+def cast(x, dtype):
+    """float32 <-> bfloat16 copy (the GAN's two storage boundaries)"""
+    return _gb().cast(x, dtype)
+
+
 def act_fwd(x, act):
+    if x.dtype == _BF16:
+        return _gb().act_fwd(x, act)
     _chk(x, "x")
     if ACT[act] == 0:
         return x
@@ -894,6 +932,8 @@ def wgan_losses_bwd(Dz, Dx, gn2, g_dloss, g_gloss):
 
 def wgrad1x1_small(a, b):
     """(Ca,Cb) = sum_p a[p,:]^T b[p,:]; a (...,Ca<=4), b (...,Cb%4==0) over the same pixels."""
+    if b.dtype == _BF16:
+        return _gb().wgrad1x1_small(a, b)
     _chk(a, "a"), _chk(b, "b")
     Ca, Cb = a.shape[-1], b.shape[-1]
     npix = a.numel() // Ca
@@ -935,6 +975,8 @@ def conv_dgrad_actgate(dy, w, wscale, gate, act):
     """conv_dgrad_raw followed by act_bwd(., gate, act) in one kernel -- or None where that form does not exist (f32
     precision, small-image mosaics, odd channel counts): the caller then runs the two ops."""
     K, _, Cin, Cout = w.shape                                   # forward filter: the dgrad maps Cout -> Cin channels
+    if dy.dtype == _BF16:
+        return _gb().conv_dgrad_actgate(dy, w, wscale, gate, act)
     N, H, W, C = dy.shape
     if not (MIXED and ACT[act] and C == Cout and Cout % 8 == 0 and Cin % 4 == 0):
         return None
@@ -963,6 +1005,8 @@ def conv_dgrad_actgate(dy, w, wscale, gate, act):
 def conv_wgrad_raw(x, dy, K, want_bias=False, dw_out=None, db_out=None, dw_scale=1.0):
     """(dW (K,K,Cin,Cout) * dw_scale, db or None) for every channel mix the GAN / U-Net graphs use; the factor rides
     in the finish kernel on the MFMA paths and is one extra multiply kernel on the small image-side 1x1 forms."""
+    if x.dtype == _BF16 or dy.dtype == _BF16:
+        return _gb().conv_wgrad(x, dy, K, want_bias, dw_out, db_out, dw_scale)
     Cin, Cout = x.shape[-1], dy.shape[-1]
     N, H, W = x.shape[0], x.shape[1], x.shape[2]
     lib = _lib.load()

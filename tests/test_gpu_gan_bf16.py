@@ -1,0 +1,254 @@
+"""GPU: the progressive GAN's bf16-STORAGE forms (dtype 'bf16', BASELINE config 5): every feature map and feature-map
+gradient is a bf16 tensor in HBM, parameters / images / losses are f32 (sequitr_amd/ops_gan_bf16.py, csrc/sq_gan_bf16.hip).
+
+Kernel level: each op against fp64 arithmetic on the SAME (already bf16-rounded) operands -- the result must be the fp64
+value rounded once (1 bf16 ulp allowed at rounding ties); fused forms (activation gates) against the two stored passes
+they replace, bit for bit.  Network level: losses and parameter gradients of one WGAN-GP step against oracle/torch_gan_ref.py
+(fp64) beside the f32-storage 'mixed' form, whose convolutions round the same operands to bf16."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_gan_ref as ref
+from sequitr_amd import functional as F
+from sequitr_amd import ops
+from sequitr_amd import ops_gan_bf16 as gb
+from sequitr_amd.networks import gan
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rb(rng, shape, scale=1.0, shift=0.0):
+    """bf16-representable random tensor on the GPU and its fp64 copy"""
+    t = torch.as_tensor(rng.standard_normal(shape) * scale + shift, dtype=torch.float32).to(BF)
+    return t.cuda(), t.double()
+
+
+def one_ulp(got, ref64, what, min_same=0.97):
+    assert got.dtype == BF, what
+    g = got.float().cpu().double()
+    r = ref64.to(BF).double()
+    bad = (g - ref64).abs() > torch.clamp(r.abs(), min=1e-30) * 2.0 ** -7 + 1e-7
+    assert not bad.any(), "%s: %d values off by more than one bf16 ulp" % (what, int(bad.sum()))
+    same = (g == r).double().mean().item()
+    assert same > min_same, "%s: only %.4f bit-identical" % (what, same)
+
+
+def leaky_gate(t64, g64, slope):
+    """the stored two-rounding gate: t = bf16 value; gate > 0 ? t : bf16(t * slope)"""
+    return torch.where(g64 > 0, t64, (t64.float() * np.float32(slope)).to(BF).double())
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 5, 8), (3, 4, 4, 16), (2, 3, 7, 32), (1, 5, 5, 64), (2, 4, 4, 128), (1, 4, 4, 512)])
+def test_pixelnorm_bf16_all_orders(shape):
+    rng = np.random.default_rng(sum(shape))
+    xg, x = rb(rng, shape)
+    gg, g = rb(rng, shape)
+    vg, v = rb(rng, shape)
+    C, eps = shape[-1], 1e-8
+    xt, gt = x.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    y = xt * torch.rsqrt((xt * xt).mean(-1, keepdim=True) + eps)
+    one_ulp(ops.pixelnorm(xg, eps), y.detach(), "pixel_norm")
+    (dx,) = torch.autograd.grad(y, xt, gt, create_graph=True)
+    one_ulp(ops.pixelnorm_bwd(xg, gg, eps), dx.detach(), "pixel_norm backward", 0.95)
+    ddg, ddx = torch.autograd.grad(dx, [gt, xt], v)
+    dg2, dx2 = ops.pixelnorm_bwd2(xg, gg, vg, eps)
+    one_ulp(dg2, ddg, "pixel_norm 2nd order d/dg", 0.95)
+    # dx2 is a sum of four terms that cancel: error relative to the tensor's scale, not to each value
+    err = (dx2.float().cpu().double() - ddx).abs().max().item()
+    assert err <= 2.0 ** -7 * ddx.abs().max().item(), ("pixel_norm 2nd order d/dx", err)
+    # gate form == backward, stored, then act_bwd, stored
+    for act, slope in (("leaky", 0.2), ("relu", 0.0)):
+        fused = ops.pixelnorm_bwd(xg, gg, eps, act=act)
+        unfused = ops.act_bwd(ops.pixelnorm_bwd(xg, gg, eps), xg, act)
+        assert torch.equal(fused, unfused), act
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 6, 8), (3, 4, 4, 24), (1, 16, 16, 64)])
+def test_pool_and_broadcast_bf16(shape):
+    rng = np.random.default_rng(sum(shape) + 1)
+    xg, x = rb(rng, shape)
+    N, H, W, C = shape
+    p = x.reshape(N, H // 2, 2, W // 2, 2, C)
+    want = ((p[:, :, 0, :, 0] + p[:, :, 0, :, 1]) + (p[:, :, 1, :, 0] + p[:, :, 1, :, 1])) * 0.25
+    one_ulp(ops.avgpool2x2(xg), want, "average pool")
+    one_ulp(ops.sumpool2x2(xg, 1.0), want * 4, "sum pool")
+    sg, s = rb(rng, (N, H // 2, W // 2, C))
+    up = s.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    assert torch.equal(ops.broadcast2x2(sg, 1.0).float().cpu().double(), up)            # a copy: exact
+    one_ulp(ops.broadcast2x2(sg, 0.25), up * 0.25, "scaled broadcast")
+    for act in ("leaky", "relu"):
+        fused = ops.broadcast2x2_act_bwd(sg, xg, 0.25, act)
+        assert torch.equal(fused, ops.act_bwd(ops.broadcast2x2(sg, 0.25), xg, act)), act
+    # adjoint pair through autograd (what the discriminator's down-sampling and its backward use)
+    xa = xg.clone().requires_grad_(True)
+    ya = F.avgpool2x2(xa)
+    (ga,) = torch.autograd.grad(ya, xa, sg)
+    assert ga.dtype == BF and torch.equal(ga, ops.broadcast2x2(sg, 0.25))
+    leak = ops.act_fwd(xg, "leaky")
+    one_ulp(leak, torch.where(x > 0, x, x.float().mul(np.float32(0.2)).double()), "leaky forward")
+
+
+@pytest.mark.parametrize("C,Ci", [(8, 2), (16, 2), (64, 1), (512, 2), (32, 4)])
+def test_image_side_convolutions_bf16(C, Ci):
+    """from_image (f32 image -> bf16 features), to_image (features -> image) and their weight gradients"""
+    rng = np.random.default_rng(C + Ci)
+    N, H, W = 2, 8, 8
+    img = torch.as_tensor(rng.standard_normal((N, H, W, Ci)), dtype=torch.float32)
+    w_in = torch.as_tensor(rng.standard_normal((1, 1, Ci, C)), dtype=torch.float32)
+    b_in = torch.as_tensor(rng.standard_normal(C) * 0.1, dtype=torch.float32)
+    ws = float(np.sqrt(np.float32(2.0 / C)))
+    with ops.mixed_precision(True, store_bf16=True):
+        y = ops.conv2d(img.cuda(), w_in.cuda(), b_in.cuda(), act="leaky", wscale=ws)
+    pre = img.double().reshape(-1, Ci) @ (w_in.reshape(Ci, C) * np.float32(ws)).double() + b_in.double()
+    want = torch.where(pre > 0, pre, 0.2 * pre).reshape(N, H, W, C)
+    assert y.dtype == BF
+    err = (y.float().cpu().double() - want).abs()
+    assert (err <= want.abs() * 2.0 ** -7 + 1e-6).all()
+    fg, f = rb(rng, (N, H, W, C))
+    w_out = torch.as_tensor(rng.standard_normal((1, 1, C, Ci)), dtype=torch.float32)
+    b_out = torch.as_tensor(rng.standard_normal(Ci) * 0.1, dtype=torch.float32)
+    z = ops.conv2d(fg, w_out.cuda(), b_out.cuda(), act=None, wscale=ws)
+    wantz = (f.reshape(-1, C) @ (w_out.reshape(C, Ci) * np.float32(ws)).double() + b_out.double()).reshape(N, H, W, Ci)
+    assert z.dtype == torch.float32
+    assert np.allclose(z.cpu().numpy(), wantz.numpy(), rtol=2e-5, atol=2e-5 * float(wantz.abs().max()))
+    # dgrad forms: the same two kernels with the transposed matrix
+    with ops.mixed_precision(True, store_bf16=True):
+        dxf = ops.conv_dgrad_raw(img.cuda(), w_out.cuda(), ws)          # d(to_image input): image grad -> features
+    wantd = (img.double().reshape(-1, Ci) @ (w_out.reshape(C, Ci) * np.float32(ws)).double().t()).reshape(N, H, W, C)
+    assert dxf.dtype == BF and ((dxf.float().cpu().double() - wantd).abs() <= wantd.abs() * 2.0 ** -7 + 1e-6).all()
+    dimg = ops.conv_dgrad_raw(fg, w_in.cuda(), ws)                     # d(from_image input): features grad -> image
+    wanti = (f.reshape(-1, C) @ (w_in.reshape(Ci, C) * np.float32(ws)).double().t()).reshape(N, H, W, Ci)
+    assert dimg.dtype == torch.float32
+    assert np.allclose(dimg.cpu().numpy(), wanti.numpy(), rtol=2e-5, atol=2e-5 * float(wanti.abs().max()))
+    # weight / bias gradients
+    dw, db = ops.conv_wgrad_raw(img.cuda(), fg, 1, want_bias=True, dw_scale=ws)
+    assert np.allclose(dw.cpu().numpy().reshape(Ci, C), (img.double().reshape(-1, Ci).t() @ f.reshape(-1, C)).numpy() * ws,
+                       rtol=1e-5, atol=1e-4)
+    assert np.allclose(db.cpu().numpy(), f.reshape(-1, C).sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    dw2, db2 = ops.conv_wgrad_raw(fg, img.cuda(), 1, want_bias=True, dw_scale=ws)
+    assert np.allclose(dw2.cpu().numpy().reshape(C, Ci), (f.reshape(-1, C).t() @ img.double().reshape(-1, Ci)).numpy() * ws,
+                       rtol=1e-5, atol=1e-4)
+    assert np.allclose(db2.cpu().numpy(), img.double().reshape(-1, Ci).sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    assert tuple(dw.shape) == (1, 1, Ci, C) and tuple(dw2.shape) == (1, 1, C, Ci)
+
+
+def _conv_ref(x64, w, ws, bias=None, act=None):
+    """fp64 conv of bf16-valued x with the bf16-rounded scaled filter (what the MFMA kernels multiply)"""
+    wq = (w * np.float32(ws)).to(BF).double()
+    y = torch.nn.functional.conv2d(x64.permute(0, 3, 1, 2), wq.permute(3, 2, 0, 1), None if bias is None else bias.double(),
+                                   padding=w.shape[0] // 2).permute(0, 2, 3, 1)
+    return torch.where(y > 0, y, 0.2 * y) if act == "leaky" else y
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,K", [(6, 4, 4, 32, 16, 3), (5, 8, 8, 16, 32, 3), (2, 16, 16, 8, 16, 3),
+                                              (2, 16, 16, 16, 8, 3), (1, 32, 32, 8, 8, 3), (4, 4, 4, 64, 32, 1)])
+def test_weighted_conv_bf16_forward_dgrad_gate_and_wgrad(N, H, W, Cin, Cout, K, monkeypatch):
+    """3x3 / 1x1 feature convolutions on bf16 tensors: small-image batches through the mosaic addressing, 8-channel
+    sides through the ragged weight-gradient form"""
+    rng = np.random.default_rng(N * 1000 + H + Cin + Cout)
+    xg, x = rb(rng, (N, H, W, Cin))
+    w = torch.as_tensor(rng.standard_normal((K, K, Cin, Cout)), dtype=torch.float32)
+    b = torch.as_tensor(rng.standard_normal(Cout) * 0.1, dtype=torch.float32)
+    ws = float(np.sqrt(np.float32(2.0 / (K * K * Cout))))
+    wd, bd = w.cuda(), b.cuda()
+    y = ops.conv2d(xg, wd, bd, act="leaky", wscale=ws)
+    one_ulp(y, _conv_ref(x, w, ws, b, "leaky"), "forward", 0.95)
+    if W < 16:                                                  # the same bits without the mosaic / strip views
+        monkeypatch.setattr(ops, "USE_MOSAIC", False)
+        assert torch.equal(y, ops.conv2d(xg, wd, bd, act="leaky", wscale=ws))
+        monkeypatch.setattr(ops, "USE_MOSAIC", True)
+    dyg, dy = rb(rng, (N, H, W, Cout))
+    dx = ops.conv_dgrad_raw(dyg, wd, ws)
+    wt = torch.flip(w, (0, 1)).permute(0, 1, 3, 2).contiguous()
+    one_ulp(dx, _conv_ref(dy, wt, ws), "dgrad", 0.95)
+    fused = ops.conv_dgrad_actgate(dyg, wd, ws, xg, "leaky")
+    if fused is not None:
+        assert torch.equal(fused, ops.act_bwd(dx, xg, "leaky"))
+    else:
+        assert K == 1 and W < 16                                # the flat 1x1 strip has no gated form
+    dw, db = ops.conv_wgrad_raw(xg, dyg, K, want_bias=True, dw_scale=ws)
+    xp = torch.nn.functional.pad(x, (0, 0, K // 2, K // 2, K // 2, K // 2))
+    want = torch.stack([torch.stack([(xp[:, ky:ky + H, kx:kx + W].reshape(-1, Cin).t() @ dy.reshape(-1, Cout))
+                                     for kx in range(K)]) for ky in range(K)]) * ws
+    scale = float(want.abs().max())
+    assert np.abs(dw.cpu().numpy() - want.numpy()).max() <= 2e-5 * scale + 1e-6
+    assert np.allclose(db.cpu().numpy(), dy.reshape(-1, Cout).sum(0).numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("level,alpha", [(0, 1.0), (2, 0.4), (2, 1.0)])
+def test_losses_and_gradients_bf16_storage_vs_fp64_and_mixed(level, alpha):
+    """One WGAN-GP evaluation (losses, penalty through the second-order pass, parameter gradients of both networks) with
+    bf16 storage against fp64, beside the 'mixed' form.  bf16 storage adds one rounding per stored feature value and
+    gradient value (2^-9 relative each) on top of the operand roundings the mixed form already has: the bound is the
+    mixed form's error plus a storage term, stated per quantity."""
+    from tests.test_gpu_gan import make_gan, dev
+    rng = np.random.default_rng(2)
+    res = {}
+    z = rng.standard_normal((4, 1, 1, 512)).astype(np.float32)
+    r = rng.random(4).astype(np.float32)
+    x = None
+    for dtype in ("mixed", "bf16"):
+        g = make_gan(dtype=dtype)
+        g.set_level(level)
+        if x is None:
+            x = rng.standard_normal((4,) + g.get_size(level) + (2,)).astype(np.float32)
+        with g.precision():
+            _, d_loss, g_loss = g._build_network(dev(x), dev(z), alpha, r=dev(r))
+            d_vars, g_vars = g.get_training_variables(level)
+            dg = torch.autograd.grad(d_loss, [v for _, v in d_vars], retain_graph=True, allow_unused=True)
+            gg = torch.autograd.grad(g_loss, [v for _, v in g_vars], allow_unused=True)
+        assert all(t.dtype == torch.float32 for t in dg + gg if t is not None)
+        res[dtype] = (d_loss.item(), g_loss.item(), [t.cpu().numpy() for t in dg], [t.cpu().numpy() for t in gg])
+    W = ref.to_torch(g.store.state_dict())
+    _, rd, rg = ref.losses(torch.as_tensor(x, dtype=torch.float64), torch.as_tensor(z, dtype=torch.float64), alpha,
+                           torch.as_tensor(r, dtype=torch.float64), W, g.filters, level)
+    rdg = torch.autograd.grad(rd, [W[n] for n, _ in d_vars], retain_graph=True, allow_unused=True)
+    rgg = torch.autograd.grad(rg, [W[n] for n, _ in g_vars], allow_unused=True)
+    truth = [t.numpy() for t in rdg + rgg]
+    names = [n for n, _ in d_vars + g_vars]
+
+    def rel(a, t):
+        return float(np.linalg.norm((a.astype(np.float64) - t).ravel()) / max(np.linalg.norm(t.ravel()), 1e-30))
+    # measured (tools/r03_gan_bf16_err.py, seed 2): mean gradient error vs fp64  mixed 0.106 / 0.064 / 0.241,
+    # bf16 storage 0.146 / 0.091 / 0.239 -- at random initialisation the penalty's second-order pass through ten
+    # leaky-ReLU / pixel-norm layers turns the 2^-9 operand roundings the mixed form already has into 6-24 % of the
+    # gradient; storage adds at most half as much again.  The f32 form is at 1e-4 (tests/test_gpu_gan.py).
+    dm, gm = res["mixed"][0], res["mixed"][1]
+    db_, gb_ = res["bf16"][0], res["bf16"][1]
+    assert abs(db_ - rd.item()) <= 2.0 * abs(dm - rd.item()) + 0.02 * max(1.0, abs(rd.item())), (db_, dm, rd.item())
+    assert abs(gb_ - rg.item()) <= 2.0 * abs(gm - rg.item()) + 0.02 * max(1.0, abs(rg.item())), (gb_, gm, rg.item())
+    em = [rel(a, t) for a, t in zip(res["mixed"][2] + res["mixed"][3], truth)]
+    eb = [rel(a, t) for a, t in zip(res["bf16"][2] + res["bf16"][3], truth)]
+    for n, m, b_ in zip(names, em, eb):                         # norm-wise error of every parameter gradient: within 2.5 x the
+        assert b_ <= 2.5 * max(m, np.mean(em)) + 0.05, (n, m, b_)   # larger of its own mixed error and the mixed form's typical one
+    assert np.mean(eb) <= 1.6 * np.mean(em) + 0.01, (np.mean(em), np.mean(eb))
+
+
+def test_storage_boundaries_and_dtypes():
+    """where bf16 starts and ends: generator latent block and discriminator output block are f32, every feature map between
+    them bf16, images / logits f32; no framework cast kernel is needed (the autograd engine would insert one silently if
+    a backward returned the wrong dtype -- checked here on the gradient dtypes of the leaves that can see it)"""
+    from tests.test_gpu_gan import make_gan, dev
+    g = make_gan(dtype="bf16")
+    g.set_level(2)
+    rng = np.random.default_rng(0)
+    z = dev(rng.standard_normal((4, 1, 1, 512)).astype(np.float32))
+    x = dev(rng.standard_normal((4, 16, 16, 2)).astype(np.float32)).requires_grad_(True)
+    with g.precision():
+        outs, last = g.generator(z, g.filters[:3])
+        layers, logits = g.discriminator(x, g.filters[:3][::-1])
+        assert all(o.dtype == torch.float32 for o in outs) and logits.dtype == torch.float32
+        assert all(t.dtype == BF for t in layers)
+        (gx,) = torch.autograd.grad(logits.sum(), x, create_graph=True)
+        assert gx.dtype == torch.float32
+        pen = F.dot_per_sample(gx, gx).sum()
+        grads = torch.autograd.grad(pen, [v for _, v in g.discriminator_training_variables(2)], allow_unused=True)
+    assert all(t is None or (t.dtype == torch.float32 and torch.isfinite(t).all()) for t in grads)
+    with torch.no_grad():                                       # outside the precision context the same weights run in f32
+        _, logits32 = g.discriminator(x.detach(), g.filters[:3][::-1])
+    assert logits32.dtype == torch.float32
+    assert np.allclose(logits.detach().cpu().numpy(), logits32.cpu().numpy(), rtol=0.05, atol=0.05)
+    img = g.predict(latent=np.ones((2, 1, 1, 512), np.float32))
+    assert img.dtype == torch.float32 and tuple(img.shape) == (2, 16, 16, 2)
