@@ -317,17 +317,22 @@ __global__ __launch_bounds__(256) void wgrad1x1_small_bf16_kernel(const float *_
 #pragma unroll
         for (int c = 0; c < CA; ++c)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red[threadIdx.x * (CA * 8) + c * 8 + j] = acc[c][j];
+            for (int j = 0; j < 8; ++j) red[(c * 8 + j) * 256 + threadIdx.x] = acc[c][j];
+        // fold the pixel lanes with a fixed tree (pl is a power of two; thread = tp * gpp + tg): one thread adding all pl lanes
+        // of its channel group was 4096 serial LDS reads per block at C = 8 -- most of this kernel's time
+        for (int st = pl >> 1; st > 0; st >>= 1) {
+            __syncthreads();
+            if (tp < st) {
+#pragma unroll
+                for (int e = 0; e < CA * 8; ++e) red[e * 256 + threadIdx.x] += red[e * 256 + threadIdx.x + st * gpp];
+            }
+        }
         __syncthreads();
         if (tp == 0 && gq < c8n) {
 #pragma unroll
             for (int c = 0; c < CA; ++c)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float s = 0.f;
-                    for (int k = 0; k < pl; ++k) s += red[(k * gpp + tg) * (CA * 8) + c * 8 + j];
-                    out[c * C + gq * 8 + j] = s;
-                }
+                for (int j = 0; j < 8; ++j) out[c * C + gq * 8 + j] = red[(c * 8 + j) * 256 + tg];
         }
         __syncthreads();
     }
