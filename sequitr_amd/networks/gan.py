@@ -139,8 +139,10 @@ def discriminator_network(x, filters, groups=1):
     return conv_layers, logits.reshape(-1)
 
 
-def generator_network(z, filters, start_shape=(4, 4)):
-    """gan.py:246-316.  Returns (list of per-level images, last image)."""
+def generator_network(z, filters, start_shape=(4, 4), levels=None):
+    """gan.py:246-316.  Returns (list of per-level images, last image).  levels: the entries of that list the caller will
+    read (None = all): a TF-1 session evaluates only the to_image ops a fetch depends on, so the training step, which
+    reads the last two images (gan.py:665-694), never ran the other five; here the others are None."""
     with variable_scope('latent'):
         initial_shape = tuple(start_shape) + (filters[0],)
         num_units = int(np.prod(initial_shape))
@@ -161,8 +163,10 @@ def generator_network(z, filters, start_shape=(4, 4)):
             conv_layers.append(conv2)
     outputs = []
     with variable_scope("to_image"):
+        last = len(conv_layers) - 1
         for l, conv in enumerate(conv_layers):
-            output = to_image(conv, filters=2, n=l)
+            wanted = levels is None or l == last or l in levels or (l - len(conv_layers)) in levels
+            output = to_image(conv, filters=2, n=l) if wanted else None
             outputs.append(output)
     return outputs, output
 
@@ -398,7 +402,7 @@ class GenerativeAdverserialNetwork(object):
         """Forward of gan.py:665-714 up to the three discriminator inputs."""
         num_layers = self.current_level
         filters = self.filters[:(num_layers + 1)]
-        g_layers, Gz_raw = self.generator(Z, filters)
+        g_layers, Gz_raw = self.generator(Z, filters, **({'levels': (-2, -1)} if self._default_g else {}))
         if tuple(X.shape[1:3]) != tuple(self.current_size):
             raise ValueError('X must already be at the current size %s (bilinear resize of the real '
                              'data is host-side IO, gan.py:682-684)' % (self.current_size,))
@@ -687,7 +691,7 @@ class GenerativeAdverserialNetwork(object):
         level = self.num_levels - 1 if level is None else level
         z = torch.as_tensor(np.asarray(latent), dtype=torch.float32).to(self.device).reshape(-1, 1, 1, 512)
         with torch.no_grad(), self.precision():
-            _, out = self.generator(z, self.filters[:(level + 1)])
+            _, out = self.generator(z, self.filters[:(level + 1)], **({'levels': (-1,)} if self._default_g else {}))
         return out
 
 
