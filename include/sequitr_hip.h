@@ -631,12 +631,15 @@ int sq_wgrad1x1_small_bf16(const float *a, const void *b, float *m, float *asum,
 /* weighted_conv2d (gan.py:61-99) on bf16 tensors: the forward is sq_conv2d_nhwc_fwd_bf16; these are the forms the
  * mixed (f32 tensor) GAN path has beside it -- the dgrad that leaves through the previous activation's backward
  * (== dgrad then sq_act_bwd_bf16, same two roundings), the small-image batch addressed as one mosaic (forward, or with
- * `gate` the gated dgrad), and the weight gradient with the equalised-LR factor in the finish kernel, plain or mosaic.
+ * `gate` the gated dgrad; with a workspace the reduction over input channels is split over the grid where the launch would
+ * otherwise be a handful of blocks, slices added in order by a finish kernel), and the weight gradient with the equalised-LR
+ * factor in the finish kernel, plain or mosaic.
  * sq_conv2d_nhwc_wgrad_bf16 and the scaled form take channel counts that are multiples of 8 (8 mod 16: the ragged form). */
 int sq_conv2d_nhwc_dgrad_actgate_bf16(const void *dy, const void *wp_t, const void *gate, int act, void *dx, int N, int H,
                                       int W, int Cin, int Cout, int K, void *stream);
 int sq_conv2d_nhwc_mosaic_bf16(const void *x, const void *wp, const float *bias, const void *gate, void *y, int Nimg, int h,
-                               int w, int Cin, int Cout, int act, int R, int Cc, void *stream);
+                               int w, int Cin, int Cout, int act, int R, int Cc, float *workspace, int64_t workspace_bytes,
+                               void *stream);
 int sq_conv2d_nhwc_wgrad_scaled_bf16(const void *x, const void *dy, float *dw, float *db, float *workspace, int N, int H,
                                      int W, int Cin, int Cout, int K, float dw_scale, void *stream);
 int sq_conv2d_nhwc_wgrad_mosaic_bf16(const void *x, const void *dy, float *dw, float *db, float *workspace, int Nimg, int h,

@@ -62,6 +62,11 @@ struct SqDropEpi {
     unsigned char *mask = nullptr;
     const float *gate_f32 = nullptr;                            // FORM_GF (f32 tensors): (N,H,W,Cout) activation output, slope in gscale
     int gate_slope = 0;                                         // FORM_GB (bf16 tensors): `gate` is an activation output, slope in gscale
+    // FORM_SK (bf16 tensors, mosaic): the reduction over the input-channel chunks is split over gridDim.z blocks; block z
+    // multiplies chunks [z, z + 1) * sk_chunks and stores its raw f32 accumulators to sk_ws[z][pixel][cout] -- bias, activation,
+    // gate and the bf16 rounding happen in conv_splitk_finish_bf16_kernel, which adds the slices in order
+    float *sk_ws = nullptr;
+    int sk_chunks = 0;
     // MOS (f32 tensors): the image the kernel tiles is a MOSAIC of mos_n small images (mos_h x mos_w, cells of pitch
     // h+1 / w+1 in a grid mos_cc wide, a zero row / column after every image standing in for the SAME padding --
     // sq_mosaic_pack_f32's layout) that is never materialised: loads, the gate and the stores address the compact
@@ -187,7 +192,9 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
 //         `gate_f32` is -- dx = gate > 0 ? v : v * gscale -- the act_bwd pass that followed this dgrad
 //   6 GB: the same on bf16 tensors (the GAN's bf16-storage form): t = bf16(v), dx = gate > 0 ? t : bf16(t * gscale) -- the two
 //         roundings of the dgrad -> sq_act_bwd_bf16 pair it replaces
-enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4, FORM_GF = 5, FORM_GB = 6 };
+//   7 SK: split-K partial sums (SqDropEpi::sk_ws): the small-image levels of the GAN are 4 - 8 mosaic tiles x Cout / 16 blocks,
+//         each walking all 16 channel chunks alone (one block per CU at best, 22 - 28 us of exposed round trips)
+enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4, FORM_GF = 5, FORM_GB = 6, FORM_SK = 7 };
 template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN, bool MOS = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const TIO *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     using C = CfgB<BN, KS, KC>;
     constexpr int NR = BN / 16, PAD = KS / 2;
     constexpr bool JN = FORM == FORM_JN, PL = FORM == FORM_PL, MK = FORM == FORM_MK, MG = FORM == FORM_MG;
-    constexpr bool GF = FORM == FORM_GF, GB = FORM == FORM_GB;
+    constexpr bool GF = FORM == FORM_GF, GB = FORM == FORM_GB, SK = FORM == FORM_SK;
     constexpr bool F32IO = sizeof(TIO) == 4;                    // f32 activations in HBM, bf16 in LDS
     constexpr int ES = (int)sizeof(TIO), XV = F32IO ? 2 : 1;    // 16-byte loads per 8-channel LDS item
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -210,7 +217,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const int t_begin = vb * tiles_per_block;
     const int t_end = min(t_begin + tiles_per_block, ntiles);
     if (t_begin >= t_end) return;
-    const int nchunk = Cin / KC;
+    const int nchunk_all = Cin / KC;
+    const int nchunk = SK ? drop.sk_chunks : nchunk_all;        // chunks this block reduces over ...
+    const int chunk0 = SK ? (int)blockIdx.z * drop.sk_chunks : 0;   // ... starting here
     const int nitems = (t_end - t_begin) * nchunk;
     const bool restage_w = nchunk > 1;
 
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<TIO *>(x), 0, (int)(io_pixels * Cin * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16 *>(wp), 0, (int)((size_t)nchunk * Cout * C::KP * 2), 0x00020000);
+        const_cast<__bf16 *>(wp), 0, (int)((size_t)nchunk_all * Cout * C::KP * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
         y, 0, (int)(io_pixels * Cout * ES), 0x00020000);
     // dgrad fused with the upstream ReLU's backward: outputs pass only where gate (N,H,W,Cout) > 0
@@ -258,7 +267,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         wrel[sl] = (idx < C::WITEMS && n0 + row < Cout) ? (((n0 + row) * C::KP) + q * 8) * 2 : (int)OOB;
     }
 
-    auto issue = [&](int tile, int chunk, bool want_w) {
+    auto issue = [&](int tile, int lchunk, bool want_w) {
+        const int chunk = lchunk + chunk0;                      // lchunk counts within this block's share of the reduction
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW - PAD, y0 = ty * TH - PAD;
         const int base = (((n * H + y0) * W + x0) * Cin + chunk * KC) * ES;
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
             bool inb;
             unsigned off;
             if constexpr (MOS) {
-                if (chunk == 0) xpix[sl] = xrel[sl] != (int)OOB ? mos_pixel(y0 + xpy[sl], x0 + xpx[sl]) : -1;
+                if (lchunk == 0) xpix[sl] = xrel[sl] != (int)OOB ? mos_pixel(y0 + xpy[sl], x0 + xpx[sl]) : -1;
                 const int px = xpix[sl];                        // items of a tile are issued chunk 0 first
                 inb = px >= 0;
                 off = (unsigned)((px * Cin + chunk * KC) * ES + xrel[sl]);
@@ -470,6 +480,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                     const bool ok = gy < H && gx < W && co < Cout;
                     offs[r] = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * ES) : OOB;
                 }
+            }
+            if constexpr (SK) {                                 // raw f32 partial sums of this block's chunk range
+                const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    drop.sk_ws + (size_t)blockIdx.z * io_pixels * Cout, 0, (int)(io_pixels * Cout * 4), 0x00020000);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 o = make_float4(acc[r][nb][0], acc[r][nb][1], acc[r][nb][2], acc[r][nb][3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
+                        __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), krsrc,
+                        offs[r] == OOB ? OOB : offs[r] * (4 / ES), 0, 0);
+                    acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                continue;
             }
             if constexpr (F32IO) {                              // f32 store of the f32 accumulators; no dropout
                 float4 gq[4];
@@ -717,6 +740,8 @@ int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int
         if (drop.gate_f32) return launch<BN, KS, KC, TIO, FORM_GF>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
     }
     if constexpr (FORM == FORM_PLAIN && !MOS && sizeof(TIO) == 2) {
+        if (drop.mos_h && KS == 3 && drop.sk_ws)
+            return launch<BN, KS, KC, TIO, FORM_SK, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
         if (drop.mos_h && KS == 3)
             return drop.gate_slope ? launch<BN, KS, KC, TIO, FORM_GB, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop)
                                    : launch<BN, KS, KC, TIO, FORM_PLAIN, true>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
@@ -755,7 +780,8 @@ int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int
     int tpb = (ntiles + want - 1) / want;
     if (tpb < 1) tpb = 1;
     const int gx = (ntiles + tpb - 1) / tpb;
-    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), C::LDS_BYTES, st, x, wp, bias, y, N, H, W, Cin, Cout, act,
+    const int gz = FORM == FORM_SK ? (Cin / KC) / drop.sk_chunks : 1;
+    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), C::LDS_BYTES, st, x, wp, bias, y, N, H, W, Cin, Cout, act,
                        tiles_x, tiles_y, ntiles, tpb, gate, drop);
     return sq_check_launch("sq_conv2d_nhwc_fwd_bf16");
 }
@@ -775,6 +801,39 @@ int dispatch_bn(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N
 }
 
 inline int kc_for(int Cin) { return Cin % 32 == 0 ? 32 : (Cin % 16 == 0 ? 16 : 8); }
+
+// split-K finish: y[p][c] = bf16(act(sum_s ws[s][p][c] + bias[c])), slices added in order; gate != NULL: the result is the gated
+// dgrad instead (no bias / act): t = bf16(sum), y = gate > 0 ? t : bf16(t * slope) -- FORM_GB's two roundings
+__global__ __launch_bounds__(256) void conv_splitk_finish_bf16_kernel(const float4 *__restrict__ ws, int S, int64_t n4, int C4,
+                                                                       const float *__restrict__ bias, int act,
+                                                                       const bf16x4 *__restrict__ gate, float slope,
+                                                                       bf16x4 *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v = ws[i];
+        for (int s2 = 1; s2 < S; ++s2) {
+            const float4 u = ws[(size_t)s2 * n4 + i];
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        bf16x4 o;
+        if (gate) {
+            const bf16x4 g = gate[i];
+            const float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const __bf16 tb = (__bf16)t[j];
+                o[j] = (float)g[j] > 0.f ? tb : (__bf16)((float)tb * slope);
+            }
+        } else {
+            const int c = (int)(i % C4) * 4;
+            const float4 b = bias ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            o[0] = (__bf16)sq_act(v.x + b.x, act);
+            o[1] = (__bf16)sq_act(v.y + b.y, act);
+            o[2] = (__bf16)sq_act(v.z + b.z, act);
+            o[3] = (__bf16)sq_act(v.w + b.w, act);
+        }
+        y[i] = o;
+    }
+}
 
 template <typename TIO>
 int dispatch_kc(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int H, int W, int Cin, int Cout, int K,
@@ -957,8 +1016,13 @@ extern "C" int sq_conv2d_nhwc_dgrad_actgate_bf16(const void *dy, const void *wp_
 
 // sq_conv2d_nhwc_mixed_mosaic_f32 on bf16 tensors: a batch of small images (Nimg, h, w, C) convolved as one mosaic image of
 // R x Cc cells that is never built.  gate == NULL: plain forward (bias / act apply); gate != NULL: the act-gated dgrad above.
+// workspace (may be NULL) / workspace_bytes: room for split-K partial sums.  Where the launch would leave most of the chip idle
+// (few mosaic tiles x Cout / 16 blocks, each walking every input-channel chunk alone) and the workspace holds S >= 2 slices of
+// Nimg*h*w*Cout floats, the reduction is split S ways over the grid and a finish kernel adds the slices in order: same value
+// to f32 rounding (another summation order than the unsplit kernel), run-to-run identical.
 extern "C" int sq_conv2d_nhwc_mosaic_bf16(const void *x, const void *wp, const float *bias, const void *gate, void *y, int Nimg,
-                                          int h, int w, int Cin, int Cout, int act, int R, int Cc, void *stream) {
+                                          int h, int w, int Cin, int Cout, int act, int R, int Cc, float *workspace,
+                                          int64_t workspace_bytes, void *stream) {
     SQ_REQUIRE(Nimg > 0 && h > 0 && w > 0 && R > 0 && Cc > 0 && (int64_t)R * Cc >= Nimg,
                "sq_conv2d_nhwc_mosaic_bf16: need R * Cc >= Nimg (Nimg=%d R=%d Cc=%d)", Nimg, R, Cc);
     SQ_REQUIRE(act >= SQ_ACT_NONE && act <= SQ_ACT_LEAKY && (!gate || act != SQ_ACT_NONE), "sq_conv2d_nhwc_mosaic_bf16: bad activation %d", act);
@@ -972,7 +1036,29 @@ extern "C" int sq_conv2d_nhwc_mosaic_bf16(const void *x, const void *wp, const f
         d.gate_slope = 1;
         d.gscale = act == SQ_ACT_LEAKY ? 0.2f : 0.0f;
     }
-    return conv_fwd_bf16_impl(x, wp, gate ? nullptr : bias, y, 1, H, W, Cin, Cout, 3, gate ? (int)SQ_ACT_NONE : act, stream, gate, d);
+    // split-K: blocks the unsplit launch would have (16-channel blocks once narrowed) vs the chip
+    const int nchunk = Cin / kc_for(Cin);
+    const int64_t blocks = (int64_t)((H + TH - 1) / TH) * ((W + TW - 1) / TW) * ((Cout + 15) / 16);
+    const int64_t slice = (int64_t)Nimg * h * w * Cout * 4;
+    int S = 1;
+    static const int sk_on = [] { const char *e = getenv("SQ_CONV_SPLITK"); return e ? atoi(e) : 1; }();
+    if (sk_on && workspace && Cout % 4 == 0 && blocks < 256 && nchunk >= 4)
+        while (S < 8 && nchunk % (2 * S) == 0 && nchunk / (2 * S) >= 2 && blocks * S < 512 && slice * 2 * S <= workspace_bytes) S *= 2;
+    if (S == 1)
+        return conv_fwd_bf16_impl(x, wp, gate ? nullptr : bias, y, 1, H, W, Cin, Cout, 3, gate ? (int)SQ_ACT_NONE : act, stream, gate, d);
+    SQ_REQUIRE_ALIGNED(workspace);
+    SQ_REQUIRE(slice * S < ((int64_t)1 << 31), "sq_conv2d_nhwc_mosaic_bf16: split-K workspace too large");
+    d.sk_ws = workspace;
+    d.sk_chunks = nchunk / S;
+    int rc = conv_fwd_bf16_impl(x, wp, nullptr, y, 1, H, W, Cin, Cout, 3, SQ_ACT_NONE, stream, nullptr, d);
+    if (rc) return rc;
+    const int64_t n4 = slice / 16;
+    int64_t nb = (n4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(conv_splitk_finish_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4 *>(workspace), S, n4, Cout / 4, gate ? nullptr : bias, gate ? (int)SQ_ACT_NONE : act,
+                       reinterpret_cast<const bf16x4 *>(gate), d.gscale, reinterpret_cast<bf16x4 *>(y));
+    return sq_check_launch("sq_conv2d_nhwc_mosaic_bf16(split-K finish)");
 }
 
 // conv + bias + act + dropout in one kernel (training): y = dropout(act(conv(x))) with the counter-hash mask of

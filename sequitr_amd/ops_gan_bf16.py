@@ -175,6 +175,16 @@ def takes(x, w, dgrad=False):
     return K == 1 and Cin <= 4 and Cout % 8 == 0 and x.shape[1] >= 2 and x.shape[2] >= 2
 
 
+SPLITK_SLICES = 8          # room for this many f32 slices of a small-image conv's output (sq_conv2d_nhwc_mosaic_bf16 picks S <= 8)
+
+
+def _splitk_workspace(npix, Cout, device):
+    nbytes = SPLITK_SLICES * npix * Cout * 4
+    if nbytes > (64 << 20):                                     # only the small levels (4x4 / 8x8 images) are ever split
+        return None, 0
+    return _workspace(nbytes, device), nbytes
+
+
 def conv2d(x, w, bias=None, act=None, wscale=1.0, dgrad=False):
     """weighted_conv2d on bf16 features / to_image / from_image (gan.py:61-125): KxK SAME conv + bias + activation.
     x (N,H,W,Cin); w (K,K,Cin,Cout) f32 HWIO, or with dgrad the filter (K,K,Cout,Cin) of the forward conv whose input
@@ -219,8 +229,10 @@ def conv2d(x, w, bias=None, act=None, wscale=1.0, dgrad=False):
         if plan is not None:
             wp = ops._packed_filter(w, K, Cin, Cout, wscale, dgrad)
             y = torch.empty((N, H, W, Cout), dtype=BF16, device=x.device)
+            ws, nbytes = _splitk_workspace(npix, Cout, x.device)
             _lib.check(lib.sq_conv2d_nhwc_mosaic_bf16(_ptr(x), _ptr(wp), _ptr(bias), None, _ptr(y), N, H, W, Cin, Cout,
-                                                     ACT[act], plan[0], plan[1], _stream()), "sq_conv2d_nhwc_mosaic_bf16")
+                                                     ACT[act], plan[0], plan[1], _ptr(ws), nbytes, _stream()),
+                       "sq_conv2d_nhwc_mosaic_bf16")
             return y
     wp = ops._packed_filter(w, K, Cin, Cout, wscale, dgrad)
     y = torch.empty((N, H, W, Cout), dtype=BF16, device=x.device)
@@ -246,8 +258,9 @@ def conv_dgrad_actgate(dy, w, wscale, gate, act):
             return None
         wp = ops._packed_filter(w, K, Cout, Cin, wscale, True)
         dx = torch.empty((N, H, W, Cin), dtype=BF16, device=dy.device)
+        ws, nbytes = _splitk_workspace(N * H * W, Cin, dy.device)
         _lib.check(lib.sq_conv2d_nhwc_mosaic_bf16(_ptr(dy), _ptr(wp), None, _ptr(gate), _ptr(dx), N, H, W, Cout, Cin, ACT[act],
-                                                 plan[0], plan[1], _stream()), "sq_conv2d_nhwc_mosaic_bf16")
+                                                 plan[0], plan[1], _ptr(ws), nbytes, _stream()), "sq_conv2d_nhwc_mosaic_bf16")
         return dx
     wp = ops._packed_filter(w, K, Cout, Cin, wscale, True)
     dx = torch.empty((N, H, W, Cin), dtype=BF16, device=dy.device)
