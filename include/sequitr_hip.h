@@ -645,6 +645,24 @@ int sq_conv2d_nhwc_wgrad_scaled_bf16(const void *x, const void *dy, float *dw, f
 int sq_conv2d_nhwc_wgrad_mosaic_bf16(const void *x, const void *dy, float *dw, float *db, float *workspace, int Nimg, int h,
                                      int w, int Cin, int Cout, int R, int Cc, float dw_scale, void *stream);
 
+/* Weight gradients of SEVERAL layers in one launch (+ one finish launch) per kernel block shape: the deep layers of a
+ * training step are each a ~37 us launch for ~10 us of matrix work (ramp-up and the cross-wave reduction run with the chip
+ * idle, and every one of a layer's ~512 blocks ends with a cross-wave reduction); sharing one grid the layers are cut into a
+ * quarter as many, longer blocks.  Every item is what sq_conv2d_nhwc_wgrad_scaled_bf16 (convT_cout == 0) or
+ * sq_convT2x2s2_wgrad_bf16 (convT_cout > 0: K = 1, Cout = 4 * convT_cout, dW (2,2,convT_cout,Cin)) computes, to f32 rounding
+ * (the same products; more of them summed per block, fewer block partials in the fixed-order finish); run-to-run identical.
+ * bf16 X (N,H,W,Cin) and dY (N,H,W,Cout), Cin % 16 == Cout % 16 == 0, db may be NULL.  The caller keeps X and dY alive until
+ * the launch has run. */
+typedef struct sq_wgrad_item {
+    const void *x, *dy;
+    float *dw, *db;
+    int32_t N, H, W, Cin, Cout, K;
+    int32_t convT_cout;
+    float dw_scale;
+} sq_wgrad_item;
+int64_t sq_conv2d_nhwc_wgrad_group_workspace_bf16(const sq_wgrad_item *items, int n);
+int sq_conv2d_nhwc_wgrad_group_bf16(const sq_wgrad_item *items, int n, float *workspace, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Tile front end: raw single-channel camera frames in HBM (OctopusData .dat memmap,
  * sequitr/dataio/octopus.py:231-245) -> ImageNorm (sequitr/pipeline.py:350-356) -> network tiles, and the

@@ -12,6 +12,13 @@ LIB_PATH = os.path.join(_HERE, "_build", "libsequitr_hip.so")
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
+
+class WgradItem(ctypes.Structure):
+    """sq_wgrad_item of include/sequitr_hip.h"""
+    _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("db", c_void_p),
+                ("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("Cin", ctypes.c_int32),
+                ("Cout", ctypes.c_int32), ("K", ctypes.c_int32), ("convT_cout", ctypes.c_int32), ("dw_scale", c_float)]
+
 # name -> (restype, argtypes); must list every symbol include/sequitr_hip.h declares
 SIGNATURES = {
     "sq_version": (c_int, []),
@@ -159,6 +166,8 @@ SIGNATURES = {
     "sq_conv2d_nhwc_mosaic_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_int64, c_void_p]),
     "sq_conv2d_nhwc_wgrad_scaled_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),
     "sq_conv2d_nhwc_wgrad_mosaic_bf16": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_float, c_void_p]),
+    "sq_conv2d_nhwc_wgrad_group_workspace_bf16": (c_int64, [c_void_p, c_int]),
+    "sq_conv2d_nhwc_wgrad_group_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "sq_act_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
     "sq_bridge_fwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
     "sq_bridge_bwd_bf16": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_void_p]),

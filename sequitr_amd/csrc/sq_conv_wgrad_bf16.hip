@@ -17,7 +17,9 @@
 // TIO = float ("mixed"): X and dY are f32 tensors, rounded to bf16 (RNE) while they are staged into LDS --
 // the weight gradient of sq_conv2d_nhwc_fwd_mixed_f32 (f32 graph, bf16 multiply, f32 accumulate).
 #include "sq_common.h"
+#include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 #ifndef SQ_WGRAD_OCC1_ABOVE
 #define SQ_WGRAD_OCC1_ABOVE 18      // accumulator blocks above which a shape is built for one block per CU
@@ -86,10 +88,12 @@ struct SqMos {
 
 // RAG: Cin and / or Cout is 8 mod 16 (the GAN's 256 x 256 level): the last 16-channel plane of that operand is half
 // empty -- its upper 8 channels load as zeros and the finish kernel drops their rows / columns
-template <int KS, int NI, int NO, int PF, typename TIO, bool MOS = false, bool RAG = false>
-__global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf16_kernel(
+// The kernel body, shared by the one-layer kernel and the grouped kernel below: (bx, by) = this block's position in the
+// layer's own (tile range, channel-block pair) grid of gy pairs.
+template <int KS, int NI, int NO, int PF, typename TIO, bool MOS, bool RAG>
+__device__ __forceinline__ void conv_wgrad_bf16_body(
     const TIO *__restrict__ x, const TIO *__restrict__ dy, float *__restrict__ partials, int N, int H,
-    int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block, SqMos mos) {
+    int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block, const SqMos &mos, int bx, int by, int gy) {
     using C = WB<KS, NI, NO>;
     constexpr int PAD = KS / 2;
     constexpr int ES = (int)sizeof(TIO), XV = ES == 4 ? 2 : 1;  // 16-byte loads per 8-channel LDS item
@@ -98,8 +102,8 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kg = lane >> 4, q = li >> 2, p = li & 3;
     const int nco = (Cout + C::CO - 1) / C::CO;
-    const int ci0 = (blockIdx.y / nco) * C::CI, co0 = (blockIdx.y % nco) * C::CO;
-    const int t_begin = blockIdx.x * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
+    const int ci0 = (by / nco) * C::CI, co0 = (by % nco) * C::CO;
+    const int t_begin = bx * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
 
     const size_t io_pixels = MOS ? (size_t)mos.n * mos.h * mos.w : (size_t)N * H * W;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -310,8 +314,43 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
         }
         __syncthreads();
     }
-    float *out = partials + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * C::RED_FLOATS;
+    float *out = partials + ((size_t)bx * gy + by) * C::RED_FLOATS;
     for (int i = tid; i < C::RED_FLOATS; i += 256) out[i] = red[i];
+}
+
+template <int KS, int NI, int NO, int PF, typename TIO, bool MOS = false, bool RAG = false>
+__global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf16_kernel(
+    const TIO *__restrict__ x, const TIO *__restrict__ dy, float *__restrict__ partials, int N, int H,
+    int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block, SqMos mos) {
+    conv_wgrad_bf16_body<KS, NI, NO, PF, TIO, MOS, RAG>(x, dy, partials, N, H, W, Cin, Cout, tiles_x, tiles_y, ntiles,
+                                                        tiles_per_block, mos, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// Several layers' weight gradients in ONE launch: the deep layers of a training step are 13 launches of ~37 us each for
+// ~10 us of matrix work -- ramp-up (the first tiles' round trips) and the cross-wave reduction at the end run with the chip
+// otherwise idle.  Queued behind each other in one grid, one layer's ramp and tail overlap the next layer's tiles.  Every
+// block finds its layer by its index (blocks of layer e: first[e] .. first[e+1]-1, pair-major) and runs the body above with
+// that layer's arguments: same partials, same finish order, same bits as the one-layer launches.
+constexpr int GROUP_MAX = 16;
+struct SqWgradGroup {
+    int n;
+    int first[GROUP_MAX + 1];
+    const void *x[GROUP_MAX], *dy[GROUP_MAX];
+    float *partials[GROUP_MAX];
+    int N[GROUP_MAX], H[GROUP_MAX], W[GROUP_MAX], Cin[GROUP_MAX], Cout[GROUP_MAX], tiles_x[GROUP_MAX], tiles_y[GROUP_MAX],
+        tpb[GROUP_MAX], gx[GROUP_MAX];
+};
+template <int KS, int NI, int NO, int PF, typename TIO>
+__global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf16_group_kernel(const SqWgradGroup g) {
+    using C = WB<KS, NI, NO>;
+    int e = 0;
+    while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;
+    const int local = (int)blockIdx.x - g.first[e], gx = g.gx[e];
+    const int gy = (g.Cin[e] / C::CI) * (g.Cout[e] / C::CO);
+    conv_wgrad_bf16_body<KS, NI, NO, PF, TIO, false, false>(
+        reinterpret_cast<const TIO *>(g.x[e]), reinterpret_cast<const TIO *>(g.dy[e]), g.partials[e], g.N[e], g.H[e], g.W[e],
+        g.Cin[e], g.Cout[e], g.tiles_x[e], g.tiles_y[e], g.tiles_x[e] * g.tiles_y[e] * g.N[e], g.tpb[e], SqMos{}, local % gx,
+        local / gx, gy);
 }
 
 // factor the finish kernel applies to dW (not db): set by the *_scaled_* entry points around their dispatch, 1 otherwise
@@ -326,17 +365,15 @@ thread_local int t_convT_cout = 0;
 // blocks g, g + G, ... in order, then a fixed LDS tree folds the groups -- every load is a full run of consecutive
 // floats (the earlier version walked dW order with the group along the lanes: 4 useful bytes per 128-byte line).
 template <int KS, int NI, int NO>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float *__restrict__ partials,
-                                                                      float *__restrict__ dw, float *__restrict__ db,
-                                                                      int nblk, int Cin, int Cout, int G, float dw_scale,
-                                                                      int ct) {
+__device__ __forceinline__ void conv_wgrad_bf16_finish_body(const float *__restrict__ partials, float *__restrict__ dw,
+                                                            float *__restrict__ db, int nblk, int Cin, int Cout, int G,
+                                                            float dw_scale, int ct, int bx, float (*red)[256]) {
     using C = WB<KS, NI, NO>;
-    __shared__ float red[4][256];
     const int nco = (Cout + C::CO - 1) / C::CO, npairs = ((Cin + C::CI - 1) / C::CI) * nco;
     const int total = npairs * C::RED_FLOATS;
     const int OUT = 256 / G;
     const int ol = threadIdx.x % OUT, g = threadIdx.x / OUT;
-    const int j = blockIdx.x * OUT + ol;
+    const int j = bx * OUT + ol;
     const size_t stride = (size_t)npairs * C::RED_FLOATS;
     auto column = [&](int jj) {                                 // this group's share of element jj, in block order
         float s = 0.f;
@@ -389,6 +426,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float
         if (!ct) db[co] = s;
         else if (fold) db[co] = ((s + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
     }
+}
+
+template <int KS, int NI, int NO>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_kernel(const float *__restrict__ partials,
+                                                                      float *__restrict__ dw, float *__restrict__ db,
+                                                                      int nblk, int Cin, int Cout, int G, float dw_scale,
+                                                                      int ct) {
+    __shared__ float red[4][256];
+    conv_wgrad_bf16_finish_body<KS, NI, NO>(partials, dw, db, nblk, Cin, Cout, G, dw_scale, ct, (int)blockIdx.x, red);
+}
+
+// the finish passes of a group of layers in one launch (blocks of layer e: first[e] .. first[e+1]-1)
+struct SqWgradFinishGroup {
+    int n;
+    int first[GROUP_MAX + 1];
+    const float *partials[GROUP_MAX];
+    float *dw[GROUP_MAX], *db[GROUP_MAX];
+    int nblk[GROUP_MAX], Cin[GROUP_MAX], Cout[GROUP_MAX], G[GROUP_MAX], ct[GROUP_MAX];
+    float dw_scale[GROUP_MAX];
+};
+template <int KS, int NI, int NO>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_group_kernel(const SqWgradFinishGroup g) {
+    __shared__ float red[4][256];
+    int e = 0;
+    while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;
+    conv_wgrad_bf16_finish_body<KS, NI, NO>(g.partials[e], g.dw[e], g.db[e], g.nblk[e], g.Cin[e], g.Cout[e], g.G[e], g.dw_scale[e],
+                                            g.ct[e], (int)blockIdx.x - g.first[e], red);
 }
 
 template <int KS, int NI, int NO>
@@ -610,6 +674,115 @@ int launch_any_mixed(const float *x, const float *dy, float *dw, float *db, floa
     SQ_WGRAD_BF16_DISPATCH(launch_f, x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
 }
 
+// block shape (ni, no) of a layer: the choice SQ_WGRAD_BF16_DISPATCH makes
+inline void shape_for(int K, int Cin, int Cout, int *ni, int *no) {
+    const bool wide = !narrow_blocks();
+    int mi_, mo_;
+    max_shape(&mi_, &mo_);
+    const bool i2 = wide && mi_ >= 2 && Cin % 32 == 0, o2 = wide && mo_ >= 2 && Cout % 32 == 0,
+               o4 = wide && mo_ >= 4 && Cout % 64 == 0;
+    *ni = 1, *no = 1;
+    if (K == 3) {
+        const int k3_ = k3_shape();
+        if (k3_ == 14 && Cout % 64 == 0) { *no = 4; return; }
+        if (k3_ == 22 && Cin % 32 == 0 && Cout % 32 == 0) { *ni = 2, *no = 2; return; }
+        if (k3_ == 12 && Cout % 32 == 0) { *no = 2; return; }
+        if (i2) { *ni = 2; return; }
+        if (o2) { *no = 2; return; }
+        return;
+    }
+    if (i2 && o4) { *ni = 2, *no = 4; return; }
+    if (i2 && o2) { *ni = 2, *no = 2; return; }
+    if (i2) { *ni = 2; return; }
+    if (o2) { *no = 2; return; }
+}
+
+template <int KS, int NI, int NO>
+constexpr int pf_bf16() {
+    using C = WB<KS, NI, NO>;
+    constexpr int acc_regs = C::NTAP * NI * NO * 4, set_regs = (C::XSLOTS + C::YSLOTS) * 4;
+    constexpr int budget = (wgrad_occ<KS, NI, NO>() == 1 ? 300 : SQ_WGRAD_BUDGET2) - acc_regs - 40;
+    return budget / set_regs >= 4 ? 4 : (budget / set_regs >= 3 ? 3 : (budget / set_regs >= 2 ? 2 : 1));
+}
+
+// one grouped main launch + one grouped finish launch for items [0, n) (n <= GROUP_MAX), all of block shape <KS, NI, NO>
+template <int KS, int NI, int NO>
+int launch_group(const sq_wgrad_item *const *items, int n, float *ws, hipStream_t st) {
+    using C = WB<KS, NI, NO>;
+    constexpr int PF = pf_bf16<KS, NI, NO>();
+    static bool attr_set = false;
+    auto kern = conv_wgrad_bf16_group_kernel<KS, NI, NO, PF, __bf16>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess) {
+            sq_set_error("conv_wgrad_bf16(group): cannot reserve %d bytes of LDS", C::LDS_BYTES);
+            return SQ_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    SqWgradGroup g;
+    SqWgradFinishGroup f;
+    g.n = f.n = n;
+    int blocks = 0, fblocks = 0;
+    float *wp = ws;
+    // Tiles per block: a layer launched alone is cut into ~512 blocks to fill the chip, and every block pays the cross-wave
+    // reduction and an 18 KB partial at its end -- the "fixed cost" of these launches.  Sharing the grid, the layers fill the
+    // chip together, so each is cut into a quarter as many, four times longer blocks (measured on one box, 13 + 4 layers of the
+    // training step: own plans 3.10 ms, / 2: 3.00, / 4: 2.95, / 8: 3.03; an equal-work split into ~1500 blocks that gave the
+    // four transpose-conv layers 1500 blocks instead of 512: 3.29).  SQ_WGRAD_GROUP_SHRINK overrides the divisor.
+    static const int shrink_env = [] { const char *e = getenv("SQ_WGRAD_GROUP_SHRINK"); return e ? atoi(e) : 0; }();
+    const int shrink = shrink_env > 0 ? shrink_env : (n < 4 ? n : 4);
+    for (int e = 0; e < n; ++e) {
+        const sq_wgrad_item &it = *items[e];
+        int gx, tpb;
+        int64_t wsf;
+        plan<KS, NI, NO>(it.N, it.H, it.W, it.Cin, it.Cout, &gx, &tpb, &wsf);
+        const int npairs = (it.Cin / C::CI) * (it.Cout / C::CO);
+        static const int dbg = [] { const char *e = getenv("SQ_WGRAD_GROUP_DEBUG"); return e ? atoi(e) : 0; }();
+        if (shrink > 1) {
+            const int ntl = ((it.W + TW - 1) / TW) * ((it.H + TH - 1) / TH) * it.N;
+            int g2 = gx / shrink;
+            if (g2 < 1) g2 = 1;
+            tpb = (ntl + g2 - 1) / g2;
+            gx = (ntl + tpb - 1) / tpb;
+        }
+        if (dbg) fprintf(stderr, "group<%d,%d,%d> item %d/%d: N=%d H=%d W=%d Cin=%d Cout=%d npairs=%d tpb=%d gx=%d\n", KS, NI, NO, e, n,
+                         it.N, it.H, it.W, it.Cin, it.Cout, npairs, tpb, gx);
+        g.first[e] = blocks;
+        g.x[e] = it.x; g.dy[e] = it.dy; g.partials[e] = wp;
+        g.N[e] = it.N; g.H[e] = it.H; g.W[e] = it.W; g.Cin[e] = it.Cin; g.Cout[e] = it.Cout;
+        g.tiles_x[e] = (it.W + TW - 1) / TW; g.tiles_y[e] = (it.H + TH - 1) / TH;
+        g.tpb[e] = tpb; g.gx[e] = gx;
+        blocks += gx * npairs;
+        int G = sq_group_size(gx);
+        if (G > 16) G = 16;
+        const int64_t total = (int64_t)npairs * C::RED_FLOATS;
+        const int OUT = 256 / G;
+        f.first[e] = fblocks;
+        f.partials[e] = wp; f.dw[e] = it.dw; f.db[e] = it.db;
+        f.nblk[e] = gx; f.Cin[e] = it.Cin; f.Cout[e] = it.Cout; f.G[e] = G; f.dw_scale[e] = it.dw_scale;
+        f.ct[e] = KS == 1 ? it.convT_cout : 0;
+        fblocks += (int)((total + OUT - 1) / OUT);
+        wp += wsf;
+    }
+    g.first[n] = blocks;
+    f.first[n] = fblocks;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), C::LDS_BYTES, st, g);
+    int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_group_bf16");
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv_wgrad_bf16_finish_group_kernel<KS, NI, NO>), dim3(fblocks), dim3(256), 0, st, f);
+    return sq_check_launch("sq_conv2d_nhwc_wgrad_group_bf16(finish)");
+}
+
+int launch_group_any(int K, int ni, int no, const sq_wgrad_item *const *items, int n, float *ws, hipStream_t st) {
+#define SQ_G(K_, I_, O_) if (K == K_ && ni == I_ && no == O_) return launch_group<K_, I_, O_>(items, n, ws, st)
+    SQ_G(3, 1, 4); SQ_G(3, 2, 2); SQ_G(3, 1, 2); SQ_G(3, 2, 1); SQ_G(3, 1, 1);
+    SQ_G(1, 2, 4); SQ_G(1, 2, 2); SQ_G(1, 2, 1); SQ_G(1, 1, 2); SQ_G(1, 1, 1);
+#undef SQ_G
+    sq_set_error("sq_conv2d_nhwc_wgrad_group_bf16: no kernel for K=%d blocks %dx%d", K, ni, no);
+    return SQ_EINVAL;
+}
+
 bool ok_shape(int N, int H, int W, int Cin, int Cout, int K, int elem_bytes = 2) {
     // bf16 tensors: channel counts that are 8 mod 16 run the ragged form; the mixed (f32 tensor) entries keep % 16
     const int m = elem_bytes == 2 ? 8 : 16;
@@ -724,4 +897,55 @@ extern "C" int sq_conv2d_nhwc_wgrad_mosaic_bf16(const void *x, const void *dy, f
     t_dw_scale = 1.0f;
     t_mos = SqMos{};
     return rc;
+}
+
+// ---- several layers in one launch (sq_wgrad_item, include/sequitr_hip.h) ----------------------------------------------------
+static bool group_item_ok(const sq_wgrad_item &it) {
+    return it.x && it.dy && it.dw && ok_shape(it.N, it.H, it.W, it.Cin, it.Cout, it.K) && it.Cin % 16 == 0 && it.Cout % 16 == 0 &&
+           (it.convT_cout == 0 || (it.K == 1 && it.convT_cout * 4 == it.Cout));
+}
+
+extern "C" int64_t sq_conv2d_nhwc_wgrad_group_workspace_bf16(const sq_wgrad_item *items, int n) {
+    if (!items || n <= 0) return -1;
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!group_item_ok(items[i])) return -1;
+        total += plan_floats(items[i].N, items[i].H, items[i].W, items[i].Cin, items[i].Cout, items[i].K) * 4;
+    }
+    return total;
+}
+
+// dW / db of n layers (bf16 X and dY, channel counts multiples of 16) with one main launch and one finish launch per block
+// shape among them: each layer's result is bit-identical to sq_conv2d_nhwc_wgrad_scaled_bf16 / sq_convT2x2s2_wgrad_bf16 on it.
+// workspace: sq_conv2d_nhwc_wgrad_group_workspace_bf16(items, n) bytes.
+extern "C" int sq_conv2d_nhwc_wgrad_group_bf16(const sq_wgrad_item *items, int n, float *workspace, void *stream) {
+    SQ_REQUIRE(items && n > 0 && workspace, "sq_conv2d_nhwc_wgrad_group_bf16: null pointer / no items");
+    SQ_REQUIRE_ALIGNED(workspace);
+    for (int i = 0; i < n; ++i) {
+        SQ_REQUIRE(group_item_ok(items[i]), "sq_conv2d_nhwc_wgrad_group_bf16: item %d: Cin=%d Cout=%d K=%d (both %% 16, K 1|3, < 2 GiB)", i,
+                   items[i].Cin, items[i].Cout, items[i].K);
+        SQ_REQUIRE_ALIGNED(items[i].x); SQ_REQUIRE_ALIGNED(items[i].dy);
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // buckets by (K, ni, no), GROUP_MAX items per launch.  Launches of one stream run in order, so every bucket lays its
+    // partials out from the start of the workspace (the previous bucket's finish pass has read its own by then).
+    std::vector<char> done(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        int ni, no;
+        shape_for(items[i].K, items[i].Cin, items[i].Cout, &ni, &no);
+        const sq_wgrad_item *bucket[GROUP_MAX];
+        int nb = 0;
+        for (int j = i; j < n && nb < GROUP_MAX; ++j) {
+            if (done[j]) continue;
+            int nj, oj;
+            shape_for(items[j].K, items[j].Cin, items[j].Cout, &nj, &oj);
+            if (items[j].K != items[i].K || nj != ni || oj != no) continue;
+            bucket[nb++] = &items[j];
+            done[j] = 1;
+        }
+        const int rc = launch_group_any(items[i].K, ni, no, bucket, nb, workspace, st);
+        if (rc) return rc;
+    }
+    return SQ_OK;
 }

@@ -190,11 +190,77 @@ def conv3x3_first(x, w, bias, act="relu"):
     return y
 
 
+# ---- weight gradients of several layers in one launch -------------------------------------------------------------------
+import os as _os
+
+WGRAD_GROUP_MAX_ELEMS = int(_os.environ.get("SQ_WGRAD_GROUP", str(1 << 31)))    # 0: off; layers with fewer X elements defer (default: all)
+_QUEUE = [None]                 # a module slot, not thread-local: the autograd engine runs backward on its own thread
+
+
+class WgradQueue(object):
+    """Collects the weight-gradient work of a backward pass -- (x, dY, destination sinks) of every layer small enough that
+    x.numel() < WGRAD_GROUP_MAX_ELEMS (default: every layer; deep-only measured 0.5 % slower) --
+    and runs it as ONE grouped launch + one grouped finish launch per kernel shape (sq_conv2d_nhwc_wgrad_group_bf16).
+    Same kernel body per layer; each layer is cut into fewer, longer blocks than when launched alone, so the f32 sums are
+    grouped differently (equal to f32 rounding, run-to-run identical).  Only layers whose gradients go straight to a sink
+    are deferred."""
+
+    def __init__(self, max_elems=None):
+        self.max_elems = WGRAD_GROUP_MAX_ELEMS if max_elems is None else int(max_elems)
+        self.items, self.keep = [], []
+
+    def takes(self, x, Cin, Cout, dw_out):
+        return (self.max_elems > 0 and dw_out is not None and Cin % 16 == 0 and Cout % 16 == 0
+                and x.numel() < self.max_elems)
+
+    def push(self, x, dy, K, dw, db, convT_cout=0, dw_scale=1.0):
+        N, H, W, Cin = x.shape
+        self.items.append((_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), N, H, W, Cin, dy.shape[3], K, convT_cout, float(dw_scale)))
+        self.keep.append((x, dy, dw, db))                       # alive until the launch has been enqueued
+
+    def flush(self):
+        n = len(self.items)
+        if not n:
+            return
+        arr = (_lib.WgradItem * n)()
+        for i, it in enumerate(self.items):
+            (arr[i].x, arr[i].dy, arr[i].dw, arr[i].db, arr[i].N, arr[i].H, arr[i].W, arr[i].Cin, arr[i].Cout, arr[i].K,
+             arr[i].convT_cout, arr[i].dw_scale) = it
+        lib = _lib.load()
+        nbytes = lib.sq_conv2d_nhwc_wgrad_group_workspace_bf16(arr, n)
+        if nbytes < 0:
+            raise _lib.SequitrHipError("WgradQueue: an item the grouped kernel does not take")
+        ws = _workspace(nbytes, self.keep[0][0].device)
+        _lib.check(lib.sq_conv2d_nhwc_wgrad_group_bf16(arr, n, _ptr(ws), _stream()), "sq_conv2d_nhwc_wgrad_group_bf16")
+        self.items, self.keep = [], []
+
+
+class deferred_wgrads(object):
+    """`with ob.deferred_wgrads(): loss.backward()` -- the queue is flushed on the way out (inside a capture: captured)"""
+
+    def __init__(self, max_elems=None):
+        self.q = WgradQueue(max_elems)
+
+    def __enter__(self):
+        self.prev, _QUEUE[0] = _QUEUE[0], self.q
+        return self.q
+
+    def __exit__(self, et, ev, tb):
+        _QUEUE[0] = self.prev
+        if et is None:
+            self.q.flush()
+        return False
+
+
 def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None):
     """(dW (K,K,Cin,Cout) f32, db f32 or None) from bf16 X and bf16 dY."""
     _chk(x, "x", ndim=4), _chk(dy, "dy", ndim=4)
     N, H, W, Cin = x.shape
     Cout = dy.shape[3]
+    q = _QUEUE[0]
+    if q is not None and q.takes(x, Cin, Cout, dw_out) and (db_out is not None or not want_bias):
+        q.push(x, dy, K, dw_out, db_out if want_bias else None)
+        return dw_out, (db_out if want_bias else None)
     lib = _lib.load()
     nbytes = lib.sq_conv2d_nhwc_wgrad_workspace_bf16(N, H, W, Cin, Cout, K)
     if nbytes < 0:
@@ -214,6 +280,10 @@ def convT_wgrad(x, g, Cout, want_bias=True, dw_out=None, db_out=None):
     N, H, W, Cin = x.shape
     if tuple(g.shape) != (N, H, W, 4 * Cout):
         raise ValueError("convT_wgrad: g must be %s" % ((N, H, W, 4 * Cout),))
+    q = _QUEUE[0]
+    if q is not None and q.takes(x, Cin, 4 * Cout, dw_out) and (db_out is not None or not want_bias):
+        q.push(x, g, 1, dw_out, db_out if want_bias else None, convT_cout=Cout)
+        return dw_out, (db_out if want_bias else None)
     lib = _lib.load()
     nbytes = lib.sq_conv2d_nhwc_wgrad_workspace_bf16(N, H, W, Cin, 4 * Cout, 1)
     if nbytes < 0:

@@ -116,7 +116,12 @@ class UNetTrainer(object):
                 loss = self.net.build_loss(x, onehot, weights)  # bf16 graph: head + loss as one tape entry
             else:
                 loss = F.weighted_softmax_cross_entropy(self.net.build(x), onehot, weights)
-            loss.backward()
+            if self.pack_plan is not None:                      # the bf16 graph
+                from . import ops_bf16 as ob
+                with ob.deferred_wgrads():                      # the deep layers' weight gradients: one grouped launch
+                    loss.backward()
+            else:
+                loss.backward()
         self.drop_salt.add_(1)                                  # next pass, next masks (captured with the pass)
         self.last_loss = loss.detach()
         return self.last_loss

@@ -544,3 +544,45 @@ def test_mask_gate_gives_the_same_step(monkeypatch):
     assert out[0][0] == out[1][0]
     for k in out[1][1]:
         assert np.array_equal(out[0][1][k], out[1][1][k]), k
+
+
+def test_grouped_weight_gradients_equal_the_single_launches():
+    """ob.deferred_wgrads(): the weight gradients of several layers from ONE grouped launch (+ one finish launch) per kernel
+    shape (sq_conv2d_nhwc_wgrad_group_bf16) against the one-layer launches: the same products, each layer cut into fewer,
+    longer blocks -- equal to f32 rounding of sums of ~1e5 terms, and run-to-run identical.  3x3 layers of three block shapes,
+    a 1x1 layer and a transpose-conv layer in one queue."""
+    from sequitr_amd import ops_bf16 as ob
+    rng = np.random.default_rng(21)
+    shapes = [(2, 32, 32, 32, 32, 3), (2, 16, 16, 64, 64, 3), (1, 32, 48, 16, 32, 3), (2, 16, 16, 128, 128, 3),
+              (2, 32, 32, 16, 16, 3), (1, 16, 16, 64, 32, 1), (2, 8, 8, 256, 256, 3)]
+    layers = []
+    for (N, H, W, Cin, Cout, K) in shapes:
+        x = dev(rng.standard_normal((N, H, W, Cin)).astype(np.float32), torch.bfloat16)
+        dy = dev(rng.standard_normal((N, H, W, Cout)).astype(np.float32), torch.bfloat16)
+        layers.append((x, dy, K))
+    xt = dev(rng.standard_normal((2, 16, 16, 64)).astype(np.float32), torch.bfloat16)
+    gt = dev(rng.standard_normal((2, 16, 16, 4 * 32)).astype(np.float32), torch.bfloat16)
+    single = [ob.conv2d_wgrad(x, dy, K, want_bias=True) for x, dy, K in layers]
+    single_t = ob.convT_wgrad(xt, gt, 32, want_bias=True)
+
+    def grouped():
+        outs = [(torch.zeros((K, K, x.shape[3], dy.shape[3]), device="cuda"), torch.zeros((dy.shape[3],), device="cuda"))
+                for x, dy, K in layers]
+        out_t = (torch.zeros((2, 2, 32, 64), device="cuda"), torch.zeros((32,), device="cuda"))
+        with ob.deferred_wgrads() as q:
+            for (x, dy, K), (dw, db) in zip(layers, outs):
+                r = ob.conv2d_wgrad(x, dy, K, want_bias=True, dw_out=dw, db_out=db)
+                assert r[0] is dw and r[1] is db
+            ob.convT_wgrad(xt, gt, 32, want_bias=True, dw_out=out_t[0], db_out=out_t[1])
+            assert len(q.items) == len(layers) + 1 and float(outs[0][0].abs().max()) == 0.0     # nothing has run yet
+        return outs, out_t
+    (outs, out_t), (outs2, out_t2) = grouped(), grouped()
+    for (dw, db), (rw, rb), (dw2, db2) in zip(outs + [out_t], single + [single_t], outs2 + [out_t2]):
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+        scale = float(rw.abs().max())
+        assert float((dw - rw).abs().max()) <= 2e-6 * scale * np.sqrt(1e3) and float((db - rb).abs().max()) <= 1e-4 * float(rb.abs().max()) + 1e-4
+    # a layer launched through a queue of ONE keeps its own plan: bit-identical to the single launch
+    dw1, db1 = torch.zeros_like(single[0][0]), torch.zeros_like(single[0][1])
+    with ob.deferred_wgrads():
+        ob.conv2d_wgrad(layers[0][0], layers[0][1], 3, want_bias=True, dw_out=dw1, db_out=db1)
+    assert torch.equal(dw1, single[0][0]) and torch.equal(db1, single[0][1])
