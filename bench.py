@@ -1083,11 +1083,25 @@ class WorkCounter(object):
                     return out
                 return counted
             setattr(self.ops, name, make(name, fn))
+        # weight gradients queued for a grouped launch (ops_bf16.WgradQueue) never pass through an ops.* call: count them
+        # where they are queued -- 2 x pixels x K x K x Cin x Cout flops, the bytes of X, dY and the gradients written
+        from sequitr_amd import ops_bf16 as ob
+        self._push = ob.WgradQueue.push
+        counter = self
+
+        def push(q, x, dy, K, dw, db, *a, **kw):
+            counter.calls += 1
+            counter.flops += 2.0 * (x.numel() // x.shape[-1]) * K * K * x.shape[-1] * dy.shape[-1]
+            counter.bytes += counter._tbytes([x, dy, dw, db])
+            return counter._push(q, x, dy, K, dw, db, *a, **kw)
+        ob.WgradQueue.push = push
         return self
 
     def __exit__(self, *exc):
         for name, fn in self.orig.items():
             setattr(self.ops, name, fn)
+        from sequitr_amd import ops_bf16 as ob
+        ob.WgradQueue.push = self._push
 
 
 def cpu_baseline_gan(level=6, nb=2):

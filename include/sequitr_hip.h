@@ -651,14 +651,19 @@ int sq_conv2d_nhwc_wgrad_mosaic_bf16(const void *x, const void *dy, float *dw, f
  * quarter as many, longer blocks.  Every item is what sq_conv2d_nhwc_wgrad_scaled_bf16 (convT_cout == 0) or
  * sq_convT2x2s2_wgrad_bf16 (convT_cout > 0: K = 1, Cout = 4 * convT_cout, dW (2,2,convT_cout,Cin)) computes, to f32 rounding
  * (the same products; more of them summed per block, fewer block partials in the fixed-order finish); run-to-run identical.
- * bf16 X (N,H,W,Cin) and dY (N,H,W,Cout), Cin % 16 == Cout % 16 == 0, db may be NULL.  The caller keeps X and dY alive until
- * the launch has run. */
+ * bf16 X (N,H,W,Cin) and dY (N,H,W,Cout), channel counts multiples of 16 (plain items: of 8, the ragged form), db may be NULL.  accumulate: bit 0 -- dW is ADDED to
+ * the contents of dw, bit 1 -- db to the contents of db (a parameter used by several passes of one step: the first item
+ * writes, the later ones accumulate; items naming the same destination run in item order, in separate launches).
+ * The caller keeps X and dY alive until the launch has run. */
 typedef struct sq_wgrad_item {
     const void *x, *dy;
     float *dw, *db;
     int32_t N, H, W, Cin, Cout, K;
     int32_t convT_cout;
     float dw_scale;
+    int32_t accumulate;
+    int32_t mosaic_R, mosaic_Cc;   /* > 0: X / dY are N small images (H, W <= 8) taken as one mosaic of R x Cc cells (K = 3) */
+    int32_t reserved;
 } sq_wgrad_item;
 int64_t sq_conv2d_nhwc_wgrad_group_workspace_bf16(const sq_wgrad_item *items, int n);
 int sq_conv2d_nhwc_wgrad_group_bf16(const sq_wgrad_item *items, int n, float *workspace, void *stream);

@@ -17,7 +17,9 @@ class WgradItem(ctypes.Structure):
     """sq_wgrad_item of include/sequitr_hip.h"""
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("db", c_void_p),
                 ("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("Cin", ctypes.c_int32),
-                ("Cout", ctypes.c_int32), ("K", ctypes.c_int32), ("convT_cout", ctypes.c_int32), ("dw_scale", c_float)]
+                ("Cout", ctypes.c_int32), ("K", ctypes.c_int32), ("convT_cout", ctypes.c_int32), ("dw_scale", c_float),
+                ("accumulate", ctypes.c_int32), ("mosaic_R", ctypes.c_int32), ("mosaic_Cc", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 # name -> (restype, argtypes); must list every symbol include/sequitr_hip.h declares
 SIGNATURES = {

@@ -339,17 +339,18 @@ struct SqWgradGroup {
     float *partials[GROUP_MAX];
     int N[GROUP_MAX], H[GROUP_MAX], W[GROUP_MAX], Cin[GROUP_MAX], Cout[GROUP_MAX], tiles_x[GROUP_MAX], tiles_y[GROUP_MAX],
         tpb[GROUP_MAX], gx[GROUP_MAX];
+    SqMos mos[GROUP_MAX];                                       // MOS groups: N, H, W are the mosaic's (1, R (h+1), Cc (w+1))
 };
-template <int KS, int NI, int NO, int PF, typename TIO>
+template <int KS, int NI, int NO, int PF, typename TIO, bool MOS = false, bool RAG = false>
 __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf16_group_kernel(const SqWgradGroup g) {
     using C = WB<KS, NI, NO>;
     int e = 0;
     while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;
     const int local = (int)blockIdx.x - g.first[e], gx = g.gx[e];
-    const int gy = (g.Cin[e] / C::CI) * (g.Cout[e] / C::CO);
-    conv_wgrad_bf16_body<KS, NI, NO, PF, TIO, false, false>(
+    const int gy = ((g.Cin[e] + C::CI - 1) / C::CI) * ((g.Cout[e] + C::CO - 1) / C::CO);
+    conv_wgrad_bf16_body<KS, NI, NO, PF, TIO, MOS, RAG>(
         reinterpret_cast<const TIO *>(g.x[e]), reinterpret_cast<const TIO *>(g.dy[e]), g.partials[e], g.N[e], g.H[e], g.W[e],
-        g.Cin[e], g.Cout[e], g.tiles_x[e], g.tiles_y[e], g.tiles_x[e] * g.tiles_y[e] * g.N[e], g.tpb[e], SqMos{}, local % gx,
+        g.Cin[e], g.Cout[e], g.tiles_x[e], g.tiles_y[e], g.tiles_x[e] * g.tiles_y[e] * g.N[e], g.tpb[e], g.mos[e], local % gx,
         local / gx, gy);
 }
 
@@ -367,7 +368,8 @@ thread_local int t_convT_cout = 0;
 template <int KS, int NI, int NO>
 __device__ __forceinline__ void conv_wgrad_bf16_finish_body(const float *__restrict__ partials, float *__restrict__ dw,
                                                             float *__restrict__ db, int nblk, int Cin, int Cout, int G,
-                                                            float dw_scale, int ct, int bx, float (*red)[256]) {
+                                                            float dw_scale, int ct, int bx, float (*red)[256], int acc = 0) {
+    // acc: bit 0 -- dW is added to what dw holds (a further contribution to a parameter's gradient), bit 1 -- the same for db
     using C = WB<KS, NI, NO>;
     const int nco = (Cout + C::CO - 1) / C::CO, npairs = ((Cin + C::CI - 1) / C::CI) * nco;
     const int total = npairs * C::RED_FLOATS;
@@ -421,10 +423,14 @@ __device__ __forceinline__ void conv_wgrad_bf16_finish_body(const float *__restr
         const int tap = row / C::CI, ci = (pair / nco) * C::CI + row % C::CI;
         // ct: dW of the transpose conv, (2,2,ct,Cin), from column q * ct + c of its space-to-depth form
         const size_t o = ct ? (size_t)co * Cin + ci : ((size_t)tap * Cin + ci) * Cout + co;
-        dw[o] = dw_scale == 1.0f ? s : s * dw_scale;            // the equalised-LR factor of gan.py:79, one f32 multiply
+        const float v = dw_scale == 1.0f ? s : s * dw_scale;    // the equalised-LR factor of gan.py:79, one f32 multiply
+        dw[o] = (acc & 1) ? dw[o] + v : v;
     } else if (db && pair / nco == 0) {                         // the bias row is taken from the ci-block 0 pairs
-        if (!ct) db[co] = s;
-        else if (fold) db[co] = ((s + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        if (!ct) db[co] = (acc & 2) ? db[co] + s : s;
+        else if (fold) {
+            const float v = ((s + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+            db[co] = (acc & 2) ? db[co] + v : v;
+        }
     }
 }
 
@@ -443,7 +449,7 @@ struct SqWgradFinishGroup {
     int first[GROUP_MAX + 1];
     const float *partials[GROUP_MAX];
     float *dw[GROUP_MAX], *db[GROUP_MAX];
-    int nblk[GROUP_MAX], Cin[GROUP_MAX], Cout[GROUP_MAX], G[GROUP_MAX], ct[GROUP_MAX];
+    int nblk[GROUP_MAX], Cin[GROUP_MAX], Cout[GROUP_MAX], G[GROUP_MAX], ct[GROUP_MAX], acc[GROUP_MAX];
     float dw_scale[GROUP_MAX];
 };
 template <int KS, int NI, int NO>
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_group_kernel(const
     int e = 0;
     while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;
     conv_wgrad_bf16_finish_body<KS, NI, NO>(g.partials[e], g.dw[e], g.db[e], g.nblk[e], g.Cin[e], g.Cout[e], g.G[e], g.dw_scale[e],
-                                            g.ct[e], (int)blockIdx.x - g.first[e], red);
+                                            g.ct[e], (int)blockIdx.x - g.first[e], red, g.acc[e]);
 }
 
 template <int KS, int NI, int NO>
@@ -706,12 +712,18 @@ constexpr int pf_bf16() {
 }
 
 // one grouped main launch + one grouped finish launch for items [0, n) (n <= GROUP_MAX), all of block shape <KS, NI, NO>
-template <int KS, int NI, int NO>
+// geometry the kernel tiles: the tensor itself, or the mosaic of its small images
+inline void item_geom(const sq_wgrad_item &it, int *N, int *H, int *W) {
+    if (it.mosaic_R > 0) { *N = 1; *H = it.mosaic_R * (it.H + 1); *W = it.mosaic_Cc * (it.W + 1); }
+    else { *N = it.N; *H = it.H; *W = it.W; }
+}
+
+template <int KS, int NI, int NO, bool MOS = false, bool RAG = false>
 int launch_group(const sq_wgrad_item *const *items, int n, float *ws, hipStream_t st) {
     using C = WB<KS, NI, NO>;
     constexpr int PF = pf_bf16<KS, NI, NO>();
     static bool attr_set = false;
-    auto kern = conv_wgrad_bf16_group_kernel<KS, NI, NO, PF, __bf16>;
+    auto kern = conv_wgrad_bf16_group_kernel<KS, NI, NO, PF, __bf16, MOS, RAG>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
@@ -734,24 +746,31 @@ int launch_group(const sq_wgrad_item *const *items, int n, float *ws, hipStream_
     const int shrink = shrink_env > 0 ? shrink_env : (n < 4 ? n : 4);
     for (int e = 0; e < n; ++e) {
         const sq_wgrad_item &it = *items[e];
-        int gx, tpb;
+        int gx, tpb, gN, gH, gW;
         int64_t wsf;
-        plan<KS, NI, NO>(it.N, it.H, it.W, it.Cin, it.Cout, &gx, &tpb, &wsf);
-        const int npairs = (it.Cin / C::CI) * (it.Cout / C::CO);
+        item_geom(it, &gN, &gH, &gW);
+        plan<KS, NI, NO>(gN, gH, gW, it.Cin, it.Cout, &gx, &tpb, &wsf);
+        const int npairs = ((it.Cin + C::CI - 1) / C::CI) * ((it.Cout + C::CO - 1) / C::CO);
         static const int dbg = [] { const char *e = getenv("SQ_WGRAD_GROUP_DEBUG"); return e ? atoi(e) : 0; }();
         if (shrink > 1) {
-            const int ntl = ((it.W + TW - 1) / TW) * ((it.H + TH - 1) / TH) * it.N;
+            const int ntl = ((gW + TW - 1) / TW) * ((gH + TH - 1) / TH) * gN;
             int g2 = gx / shrink;
             if (g2 < 1) g2 = 1;
             tpb = (ntl + g2 - 1) / g2;
             gx = (ntl + tpb - 1) / tpb;
         }
-        if (dbg) fprintf(stderr, "group<%d,%d,%d> item %d/%d: N=%d H=%d W=%d Cin=%d Cout=%d npairs=%d tpb=%d gx=%d\n", KS, NI, NO, e, n,
-                         it.N, it.H, it.W, it.Cin, it.Cout, npairs, tpb, gx);
+        if (dbg) fprintf(stderr, "group<%d,%d,%d,%d,%d> item %d/%d: N=%d H=%d W=%d Cin=%d Cout=%d npairs=%d tpb=%d gx=%d acc=%d\n", KS, NI, NO,
+                         (int)MOS, (int)RAG, e, n, gN, gH, gW, it.Cin, it.Cout, npairs, tpb, gx, it.accumulate);
         g.first[e] = blocks;
         g.x[e] = it.x; g.dy[e] = it.dy; g.partials[e] = wp;
-        g.N[e] = it.N; g.H[e] = it.H; g.W[e] = it.W; g.Cin[e] = it.Cin; g.Cout[e] = it.Cout;
-        g.tiles_x[e] = (it.W + TW - 1) / TW; g.tiles_y[e] = (it.H + TH - 1) / TH;
+        g.N[e] = gN; g.H[e] = gH; g.W[e] = gW; g.Cin[e] = it.Cin; g.Cout[e] = it.Cout;
+        g.tiles_x[e] = (gW + TW - 1) / TW; g.tiles_y[e] = (gH + TH - 1) / TH;
+        g.mos[e] = SqMos{};
+        if (MOS) {
+            g.mos[e].h = it.H; g.mos[e].w = it.W; g.mos[e].cc = it.mosaic_Cc; g.mos[e].n = it.N;
+            g.mos[e].mh = (65536u + (unsigned)it.H) / (unsigned)(it.H + 1);
+            g.mos[e].mw = (65536u + (unsigned)it.W) / (unsigned)(it.W + 1);
+        }
         g.tpb[e] = tpb; g.gx[e] = gx;
         blocks += gx * npairs;
         int G = sq_group_size(gx);
@@ -762,6 +781,7 @@ int launch_group(const sq_wgrad_item *const *items, int n, float *ws, hipStream_
         f.partials[e] = wp; f.dw[e] = it.dw; f.db[e] = it.db;
         f.nblk[e] = gx; f.Cin[e] = it.Cin; f.Cout[e] = it.Cout; f.G[e] = G; f.dw_scale[e] = it.dw_scale;
         f.ct[e] = KS == 1 ? it.convT_cout : 0;
+        f.acc[e] = it.accumulate;
         fblocks += (int)((total + OUT - 1) / OUT);
         wp += wsf;
     }
@@ -774,7 +794,14 @@ int launch_group(const sq_wgrad_item *const *items, int n, float *ws, hipStream_
     return sq_check_launch("sq_conv2d_nhwc_wgrad_group_bf16(finish)");
 }
 
-int launch_group_any(int K, int ni, int no, const sq_wgrad_item *const *items, int n, float *ws, hipStream_t st) {
+int launch_group_any(int K, int ni, int no, int kind, const sq_wgrad_item *const *items, int n, float *ws, hipStream_t st) {
+    if (kind == 2)                                              // ragged channel counts: 16 x 16 channel blocks
+        return K == 3 ? launch_group<3, 1, 1, false, true>(items, n, ws, st) : launch_group<1, 1, 1, false, true>(items, n, ws, st);
+    if (kind == 1) {                                            // small-image mosaics (3x3)
+#define SQ_GM(I_, O_) if (ni == I_ && no == O_) return launch_group<3, I_, O_, true>(items, n, ws, st)
+        SQ_GM(1, 4); SQ_GM(2, 2); SQ_GM(1, 2); SQ_GM(2, 1); SQ_GM(1, 1);
+#undef SQ_GM
+    }
 #define SQ_G(K_, I_, O_) if (K == K_ && ni == I_ && no == O_) return launch_group<K_, I_, O_>(items, n, ws, st)
     SQ_G(3, 1, 4); SQ_G(3, 2, 2); SQ_G(3, 1, 2); SQ_G(3, 2, 1); SQ_G(3, 1, 1);
     SQ_G(1, 2, 4); SQ_G(1, 2, 2); SQ_G(1, 2, 1); SQ_G(1, 1, 2); SQ_G(1, 1, 1);
@@ -900,9 +927,25 @@ extern "C" int sq_conv2d_nhwc_wgrad_mosaic_bf16(const void *x, const void *dy, f
 }
 
 // ---- several layers in one launch (sq_wgrad_item, include/sequitr_hip.h) ----------------------------------------------------
+static int item_kind(const sq_wgrad_item &it) { return it.mosaic_R > 0 ? 1 : ((it.Cin % 16 || it.Cout % 16) ? 2 : 0); }
+static void item_shape(const sq_wgrad_item &it, int *ni, int *no) {
+    if (item_kind(it) == 2) { *ni = *no = 1; return; }
+    shape_for(it.K, it.Cin, it.Cout, ni, no);
+}
+static int64_t item_floats(const sq_wgrad_item &it) {
+    int N, H, W;
+    item_geom(it, &N, &H, &W);
+    return plan_floats(N, H, W, it.Cin, it.Cout, it.K);
+}
 static bool group_item_ok(const sq_wgrad_item &it) {
-    return it.x && it.dy && it.dw && ok_shape(it.N, it.H, it.W, it.Cin, it.Cout, it.K) && it.Cin % 16 == 0 && it.Cout % 16 == 0 &&
-           (it.convT_cout == 0 || (it.K == 1 && it.convT_cout * 4 == it.Cout));
+    int N, H, W;
+    item_geom(it, &N, &H, &W);
+    if (!(it.x && it.dy && it.dw && ok_shape(N, H, W, it.Cin, it.Cout, it.K))) return false;
+    if (it.mosaic_R > 0)                                        // images up to 8 x 8, 3x3, full 16-channel blocks
+        return it.K == 3 && it.H <= 8 && it.W <= 8 && it.mosaic_Cc > 0 && (int64_t)it.mosaic_R * it.mosaic_Cc >= it.N &&
+               H < (1 << 13) && W < (1 << 13) && it.Cin % 16 == 0 && it.Cout % 16 == 0 && it.convT_cout == 0;
+    if (it.Cin % 16 || it.Cout % 16) return it.convT_cout == 0;
+    return it.convT_cout == 0 || (it.K == 1 && it.convT_cout * 4 == it.Cout);
 }
 
 extern "C" int64_t sq_conv2d_nhwc_wgrad_group_workspace_bf16(const sq_wgrad_item *items, int n) {
@@ -910,7 +953,7 @@ extern "C" int64_t sq_conv2d_nhwc_wgrad_group_workspace_bf16(const sq_wgrad_item
     int64_t total = 0;
     for (int i = 0; i < n; ++i) {
         if (!group_item_ok(items[i])) return -1;
-        total += plan_floats(items[i].N, items[i].H, items[i].W, items[i].Cin, items[i].Cout, items[i].K) * 4;
+        total += item_floats(items[i]) * 4;
     }
     return total;
 }
@@ -922,7 +965,7 @@ extern "C" int sq_conv2d_nhwc_wgrad_group_bf16(const sq_wgrad_item *items, int n
     SQ_REQUIRE(items && n > 0 && workspace, "sq_conv2d_nhwc_wgrad_group_bf16: null pointer / no items");
     SQ_REQUIRE_ALIGNED(workspace);
     for (int i = 0; i < n; ++i) {
-        SQ_REQUIRE(group_item_ok(items[i]), "sq_conv2d_nhwc_wgrad_group_bf16: item %d: Cin=%d Cout=%d K=%d (both %% 16, K 1|3, < 2 GiB)", i,
+        SQ_REQUIRE(group_item_ok(items[i]), "sq_conv2d_nhwc_wgrad_group_bf16: item %d: Cin=%d Cout=%d K=%d (both %% 8, K 1|3, < 2 GiB; mosaic / convT: %% 16)", i,
                    items[i].Cin, items[i].Cout, items[i].K);
         SQ_REQUIRE_ALIGNED(items[i].x); SQ_REQUIRE_ALIGNED(items[i].dy);
     }
@@ -933,18 +976,27 @@ extern "C" int sq_conv2d_nhwc_wgrad_group_bf16(const sq_wgrad_item *items, int n
     for (int i = 0; i < n; ++i) {
         if (done[i]) continue;
         int ni, no;
-        shape_for(items[i].K, items[i].Cin, items[i].Cout, &ni, &no);
+        item_shape(items[i], &ni, &no);
+        const int kind = item_kind(items[i]);
         const sq_wgrad_item *bucket[GROUP_MAX];
         int nb = 0;
         for (int j = i; j < n && nb < GROUP_MAX; ++j) {
             if (done[j]) continue;
             int nj, oj;
-            shape_for(items[j].K, items[j].Cin, items[j].Cout, &nj, &oj);
-            if (items[j].K != items[i].K || nj != ni || oj != no) continue;
+            item_shape(items[j], &nj, &oj);
+            if (items[j].K != items[i].K || nj != ni || oj != no || item_kind(items[j]) != kind) continue;
+            // two contributions to one gradient never share a launch (their finish blocks would race): the later one waits
+            // for the next round of this shape -- rounds run in item order, so "write, then accumulate" stays in order
+            bool clash = false;
+            for (int b2 = 0; b2 < nb && !clash; ++b2)
+                clash = bucket[b2]->dw == items[j].dw || (items[j].db && bucket[b2]->db == items[j].db);
+            for (int j2 = i; j2 < j && !clash; ++j2)              // ... nor overtake an earlier one that is still waiting
+                clash = !done[j2] && (items[j2].dw == items[j].dw || (items[j].db && items[j2].db == items[j].db));
+            if (clash) continue;
             bucket[nb++] = &items[j];
             done[j] = 1;
         }
-        const int rc = launch_group_any(items[i].K, ni, no, bucket, nb, workspace, st);
+        const int rc = launch_group_any(items[i].K, ni, no, kind, bucket, nb, workspace, st);
         if (rc) return rc;
     }
     return SQ_OK;

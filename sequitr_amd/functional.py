@@ -50,6 +50,60 @@ class grads_wanted(object):
         return False
 
 
+# Gradient sinks of a first-order pass through graphs in which a parameter is used SEVERAL times (the GAN's discriminator step:
+# D(Gz | X), D(mix) and the penalty's second-order terms all contribute to every discriminator weight).  While
+# `with grad_sinks({id(param): float32 view}):` and an ops_bf16.WgradQueue are active, a bf16 3x3 / 1x1 conv's weight-gradient
+# work is queued with that view as its destination (first contribution writes, later ones accumulate) and autograd gets None:
+# the step's ~50 weight-gradient launches + finishes + ~40 framework adds become a few grouped launches (WgradQueue.flush).
+_SINKS = None
+
+
+class grad_sinks(object):
+    def __init__(self, mapping):
+        self.map, self.touched = mapping, set()
+
+    def __enter__(self):
+        global _SINKS
+        self.prev, _SINKS = _SINKS, self
+        return self
+
+    def __exit__(self, *exc):
+        global _SINKS
+        _SINKS = self.prev
+        return False
+
+
+def _sink_wgrad(x, dy, K, wscale, w_id, bias_id=None, want_bias=False):
+    """queue dW (+ db) of a conv for the grouped launch, destination = the parameters' sinks; False: not applicable here"""
+    sk = _SINKS
+    if sk is None or torch.is_grad_enabled() or x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or x.dim() != 4:
+        return False
+    from . import ops_bf16 as ob
+    q = ob._QUEUE[0]
+    sw = sk.map.get(w_id)
+    if q is None or q.max_elems <= 0 or sw is None:
+        return False
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    if Cin % 8 or Cout % 8:
+        return False
+    mosaic = None
+    if ops.USE_MOSAIC and W < 16 and N * H > 1:                 # small-image levels: as one mosaic (3x3), or their own launches
+        mosaic = ops._mosaic_plan(N, H, W) if (K == 3 and Cin % 16 == 0 and Cout % 16 == 0) else None
+        if mosaic is None:
+            return False
+    sb = None
+    if want_bias:
+        sb = sk.map.get(bias_id)
+        if sb is None:
+            return False
+    q.push(x.contiguous(), dy.contiguous(), K, sw, sb, dw_scale=wscale, mosaic=mosaic)
+    sk.touched.add(w_id)
+    if sb is not None:
+        sk.touched.add(bias_id)
+    return True
+
+
 def _pid(t):
     """identity of the PARAMETER behind t: layers hand views of their variables to the ops (bias.view(-1), the
     (1,1,Cin,Cout) form of a dense kernel); the id is taken at forward time, when the variable is certainly alive"""
@@ -95,7 +149,9 @@ class _ConvFwd(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = _ConvDgrad.apply(dy, w, ctx.wscale) if ctx.needs_input_grad[0] else None
-        dw = _ConvWgrad.apply(x, dy, w.shape[0], ctx.wscale) if (ctx.needs_input_grad[1] and _want(ctx.w_id)) else None
+        dw = None
+        if ctx.needs_input_grad[1] and _want(ctx.w_id) and not _sink_wgrad(x, dy, w.shape[0], ctx.wscale, ctx.w_id):
+            dw = _ConvWgrad.apply(x, dy, w.shape[0], ctx.wscale)
         return dx, dw, None
 
 
@@ -112,8 +168,9 @@ class _ConvDgrad(torch.autograd.Function):
     def backward(ctx, ddx):
         dy, w = ctx.saved_tensors
         d_dy = _ConvFwd.apply(ddx.contiguous(), w, ctx.wscale) if ctx.needs_input_grad[0] else None
-        d_w = (_ConvWgrad.apply(ddx.contiguous(), dy, w.shape[0], ctx.wscale)
-               if (ctx.needs_input_grad[1] and _want(ctx.w_id)) else None)
+        d_w = None
+        if ctx.needs_input_grad[1] and _want(ctx.w_id) and not _sink_wgrad(ddx, dy, w.shape[0], ctx.wscale, ctx.w_id):
+            d_w = _ConvWgrad.apply(ddx.contiguous(), dy, w.shape[0], ctx.wscale)
         return d_dy, d_w, None
 
 
@@ -262,6 +319,8 @@ class _Conv2d(torch.autograd.Function):
         need_b = ctx.has_bias and ctx.needs_input_grad[2] and _want(ctx.bias_id)
         if not want_w and not need_b:
             return dx, None, None, None, None, None
+        if want_w and _sink_wgrad(x, dpre, w.shape[0], ctx.wscale, ctx.w_id, ctx.bias_id, need_b):
+            return dx, None, None, None, None, None             # queued: dW / db land in the parameters' sinks at the flush
         if want_w and not torch.is_grad_enabled():
             # first-order fast path: dW and db from ONE pass of the wgrad kernel
             sw, sb = ctx.sinks

@@ -264,6 +264,7 @@ class GenerativeAdverserialNetwork(object):
         self._graphs = {}
         self._graph_alpha = {}                                  # last fade-in weight written into each graph's static tensor
         self._plan = None
+        self._gflat, self._gsinks = None, None                  # flat gradient buffer + per-parameter sinks (dtype 'bf16')
         self._capture_stream = None
         self.dtype = params.get('dtype', 'f32')
         if self.dtype not in ('f32', 'bf16', 'mixed'):
@@ -466,7 +467,7 @@ class GenerativeAdverserialNetwork(object):
             return None
         return tuple(float(t) for t in self._last_losses)
 
-    _WIRING = ('generator', 'discriminator', '_prepare', '_build_network', '_d_grads', '_g_grads')
+    _WIRING = ('generator', 'discriminator', '_prepare', '_build_network', '_d_grads', '_g_grads', '_param_grads')
 
     def _act_gates(self):
         """ActGate (the activation backward riding in the consumer's dgrad kernel) promises that every gated activation
@@ -496,13 +497,37 @@ class GenerativeAdverserialNetwork(object):
         finally:
             ops.invalidate_packs()
 
+    # -- parameter gradients through sinks (bf16 storage): grouped weight-gradient launches, no framework adds -------------
+    def _param_grads(self, loss, named):
+        """torch.autograd.grad(loss, variables) for a solver step.  dtype 'bf16': the weight gradients of the bf16 feature
+        convolutions are not returned through autograd (one launch + finish per layer and pass, summed by framework adds)
+        but queued into per-parameter sinks -- views of one flat gradient buffer laid out like the parameter buffer -- and
+        run as grouped launches when the pass is over (functional.grad_sinks, ops_bf16.WgradQueue)."""
+        variables = [v for _, v in named]
+        if self.dtype != 'bf16' or self.store.flat is None:
+            with F.grads_wanted(variables):
+                return torch.autograd.grad(loss, variables, allow_unused=True)
+        from .. import ops_bf16 as ob
+        if self._gflat is None:
+            self._gflat = torch.zeros_like(self.store.flat)
+            self._gsinks = {id(v): self._gflat[o:o + v.numel()].view(v.shape)
+                            for name, v in self.store.vars.items() for o in [self.store.offsets.get(name)] if o is not None}
+        with F.grads_wanted(variables), F.grad_sinks(self._gsinks) as sk, ob.deferred_wgrads():
+            grads = list(torch.autograd.grad(loss, variables, allow_unused=True))
+        for i, v in enumerate(variables):                       # after the flush: the sinks hold their sums
+            if id(v) in sk.touched:
+                sink = self._gsinks[id(v)]
+                if grads[i] is not None:                        # a contribution that did not go through the queue
+                    sink.add_(grads[i])
+                grads[i] = sink
+        return tuple(grads)
+
     # the two halves of a solver step: (losses + gradients) and (Adam); the all-reduce sits between them
     def _d_grads(self, X, Z, alpha, r):
         self._pack_filters()
         d_vars, _ = self.get_training_variables(self.current_level)
         _, d_loss, g_loss = self._build_network(X, Z, alpha, r=r, need_g_graph=False)
-        with F.grads_wanted([v for _, v in d_vars]):            # not the block d_vars leaves out
-            grads = torch.autograd.grad(d_loss, [v for _, v in d_vars], allow_unused=True)
+        grads = self._param_grads(d_loss, d_vars)               # not the block d_vars leaves out (SURVEY a25)
         return d_vars, grads, (d_loss.detach(), g_loss.detach())
 
     def _g_grads(self, X, Z, alpha):
@@ -511,8 +536,7 @@ class GenerativeAdverserialNetwork(object):
         d_filters, _, Gz, _ = self._prepare(X, Z, alpha, need_g_graph=True)
         _, Dz = self.discriminator(Gz, d_filters)
         _, g_loss = F.wgan_losses(Dz)
-        with F.grads_wanted([v for _, v in g_vars]):            # the pass runs THROUGH the discriminator: none of its weights
-            grads = torch.autograd.grad(g_loss, [v for _, v in g_vars], allow_unused=True)
+        grads = self._param_grads(g_loss, g_vars)               # the pass runs THROUGH the discriminator: none of its weights
         return g_vars, grads, (g_loss.detach(),)
 
     def _d_solver(self, X, Z, alpha, r=None):

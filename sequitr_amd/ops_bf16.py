@@ -208,14 +208,23 @@ class WgradQueue(object):
     def __init__(self, max_elems=None):
         self.max_elems = WGRAD_GROUP_MAX_ELEMS if max_elems is None else int(max_elems)
         self.items, self.keep = [], []
+        self.seen_dw, self.seen_db = set(), set()               # destinations already written by an item of this queue
 
     def takes(self, x, Cin, Cout, dw_out):
         return (self.max_elems > 0 and dw_out is not None and Cin % 16 == 0 and Cout % 16 == 0
                 and x.numel() < self.max_elems)
 
-    def push(self, x, dy, K, dw, db, convT_cout=0, dw_scale=1.0):
+    def push(self, x, dy, K, dw, db, convT_cout=0, dw_scale=1.0, mosaic=None):
+        """a second item for the same destination ACCUMULATES (a parameter that several passes of one step use, e.g. the GAN's
+        discriminator: the stacked D(Gz | X) pass and the penalty's pass through D(mix)); the first one writes"""
         N, H, W, Cin = x.shape
-        self.items.append((_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), N, H, W, Cin, dy.shape[3], K, convT_cout, float(dw_scale)))
+        pw, pb = _ptr(dw), _ptr(db)
+        acc = (1 if pw in self.seen_dw else 0) | (2 if (pb is not None and pb in self.seen_db) else 0)
+        self.seen_dw.add(pw)
+        if pb is not None:
+            self.seen_db.add(pb)
+        R, Cc = mosaic if mosaic is not None else (0, 0)          # small images taken as one mosaic (ops._mosaic_plan)
+        self.items.append((_ptr(x), _ptr(dy), pw, pb, N, H, W, Cin, dy.shape[3], K, convT_cout, float(dw_scale), acc, R, Cc))
         self.keep.append((x, dy, dw, db))                       # alive until the launch has been enqueued
 
     def flush(self):
@@ -225,14 +234,14 @@ class WgradQueue(object):
         arr = (_lib.WgradItem * n)()
         for i, it in enumerate(self.items):
             (arr[i].x, arr[i].dy, arr[i].dw, arr[i].db, arr[i].N, arr[i].H, arr[i].W, arr[i].Cin, arr[i].Cout, arr[i].K,
-             arr[i].convT_cout, arr[i].dw_scale) = it
+             arr[i].convT_cout, arr[i].dw_scale, arr[i].accumulate, arr[i].mosaic_R, arr[i].mosaic_Cc) = it
         lib = _lib.load()
         nbytes = lib.sq_conv2d_nhwc_wgrad_group_workspace_bf16(arr, n)
         if nbytes < 0:
             raise _lib.SequitrHipError("WgradQueue: an item the grouped kernel does not take")
         ws = _workspace(nbytes, self.keep[0][0].device)
         _lib.check(lib.sq_conv2d_nhwc_wgrad_group_bf16(arr, n, _ptr(ws), _stream()), "sq_conv2d_nhwc_wgrad_group_bf16")
-        self.items, self.keep = [], []
+        self.items, self.keep = [], []                          # seen_* stay: a later flush of this queue still accumulates
 
 
 class deferred_wgrads(object):

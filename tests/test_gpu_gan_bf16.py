@@ -261,3 +261,37 @@ def test_storage_boundaries_and_dtypes():
     assert np.allclose(logits.detach().cpu().numpy(), logits32.cpu().numpy(), rtol=0.05, atol=0.05)
     img = g.predict(latent=np.ones((2, 1, 1, 512), np.float32))
     assert img.dtype == torch.float32 and tuple(img.shape) == (2, 16, 16, 2)
+
+
+def test_grouped_weight_gradients_mosaic_ragged_and_accumulating():
+    """ops_bf16.WgradQueue on the GAN's shapes: small-image batches as mosaics, 8-channel (ragged) layers, the equalised-LR
+    factor, and several contributions to ONE destination (first writes, later ones accumulate, in separate launches) --
+    against the single launches of ops.conv_wgrad_raw summed up by hand."""
+    from sequitr_amd import ops_bf16 as ob
+    rng = np.random.default_rng(5)
+    cases = [(6, 4, 4, 32, 32, 3), (5, 8, 8, 64, 32, 3), (2, 32, 32, 8, 16, 3), (2, 32, 32, 16, 8, 3), (2, 32, 32, 32, 32, 3),
+             (2, 16, 16, 64, 64, 3)]
+    items, want = [], []
+    for (N, H, W, Cin, Cout, K) in cases:
+        ws = float(np.sqrt(np.float32(2.0 / (K * K * Cout))))
+        contrib = []
+        for rep_ in range(3 if Cin == 32 and H == 32 else 2):     # 2 - 3 passes contribute to every weight
+            xg, _ = rb(rng, (N, H, W, Cin))
+            dg, _ = rb(rng, (N, H, W, Cout))
+            contrib.append((xg, dg))
+        dw = torch.full((K, K, Cin, Cout), 7.0, device="cuda")    # stale contents: the first contribution must overwrite them
+        db = torch.full((Cout,), 7.0, device="cuda")
+        items.append((contrib, K, ws, dw, db, ops._mosaic_plan(N, H, W) if W < 16 else None))
+        singles = [ops.conv_wgrad_raw(a, b, K, want_bias=True, dw_scale=ws) for a, b in contrib]
+        want.append((sum(s[0].double() for s in singles), sum(s[1].double() for s in singles)))
+    with ob.deferred_wgrads() as q:
+        for pass_ in range(3):                                   # interleaved, as a backward pass meets them
+            for contrib, K, ws, dw, db, plan in items:
+                if pass_ < len(contrib):
+                    q.push(contrib[pass_][0], contrib[pass_][1], K, dw, db if pass_ != 1 else None, dw_scale=ws, mosaic=plan)
+    for (contrib, K, ws, dw, db, plan), (rw, rb_) in zip(items, want):
+        assert float((dw.double() - rw).abs().max()) <= 1e-5 * float(rw.abs().max()), (K, tuple(dw.shape))
+    # db: passes 0 and 2 carried a bias destination (pass 1 did not): the sum of those two / that one
+    for (contrib, K, ws, dw, db, plan) in items:
+        ref = sum(ops.conv_wgrad_raw(a, b, K, want_bias=True)[1].double() for i, (a, b) in enumerate(contrib) if i != 1)
+        assert float((db.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
