@@ -505,14 +505,32 @@ __global__ __launch_bounds__(MB_BT) void mbstd_stats_kernel(const float *__restr
     const float *vg = v ? v + (int64_t)g * n * P : nullptr;
     float acc = 0.f, aa = 0.f;
     for (int64_t p = (int64_t)blockIdx.x * MB_BT + threadIdx.x; p < P; p += (int64_t)MB_B * MB_BT) {
+        // eight samples' loads in flight at a time (same order of the sums): one load per trip was a chain of 2 n round trips
         float mu = 0.f;
-        for (int i = 0; i < n; ++i) mu += xg[(int64_t)i * P + p];
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            float xv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xv[k] = i0 + k < n ? xg[(int64_t)(i0 + k) * P + p] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mu += xv[k];
+        }
         mu /= (float)n;
         float var = 0.f;
-        for (int i = 0; i < n; ++i) {
-            const float d = xg[(int64_t)i * P + p] - mu;
-            var = __builtin_fmaf(d, d, var);
-            if (vg) aa = __builtin_fmaf(vg[(int64_t)i * P + p], d, aa);
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            float xv[8], vv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                xv[k] = i0 + k < n ? xg[(int64_t)(i0 + k) * P + p] : mu;
+                vv[k] = (vg && i0 + k < n) ? vg[(int64_t)(i0 + k) * P + p] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (i0 + k < n) {
+                    const float d = xv[k] - mu;
+                    var = __builtin_fmaf(d, d, var);
+                    if (vg) aa = __builtin_fmaf(vv[k], d, aa);
+                }
+            }
         }
         acc += var / (float)n;
     }
