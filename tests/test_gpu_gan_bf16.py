@@ -295,3 +295,34 @@ def test_grouped_weight_gradients_mosaic_ragged_and_accumulating():
     for (contrib, K, ws, dw, db, plan) in items:
         ref = sum(ops.conv_wgrad_raw(a, b, K, want_bias=True)[1].double() for i, (a, b) in enumerate(contrib) if i != 1)
         assert float((db.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
+
+
+def test_bf16_storage_trains_like_the_f32_graph():
+    """Twelve D + G solver steps at level 2 (16 x 16) from the same initial weights, data and mixing draws in f32, mixed and
+    bf16 storage: the loss trajectories stay together (the first steps to the rounding of one evaluation, later ones drift as
+    the weights do), nothing blows up, and the weights move by comparable amounts."""
+    from tests.test_gpu_gan import make_gan, dev
+    runs = {}
+    for dtype in ("f32", "mixed", "bf16"):
+        g = make_gan(dtype=dtype, seed=11)
+        g.set_level(2)
+        w0 = {k: v.copy() for k, v in g.store.state_dict().items()}
+        rng = np.random.default_rng(4)
+        traj = []
+        for it in range(12):
+            z = dev(rng.standard_normal((4, 1, 1, 512)).astype(np.float32))
+            x = dev((rng.standard_normal((4, 16, 16, 2)) * 0.5 + 0.3).astype(np.float32))
+            r = dev(rng.random(4).astype(np.float32))
+            g.d_solver(x, z, 1.0, r=r)
+            g.g_solver(x, z, 1.0)
+            traj.append(g.last_losses)
+        w1 = g.store.state_dict()
+        moved = np.sqrt(sum(float(((w1[k] - w0[k]) ** 2).sum()) for k in w0))
+        runs[dtype] = (np.array(traj), moved)
+    f32, mixed, bf16 = runs["f32"], runs["mixed"], runs["bf16"]
+    assert np.isfinite(bf16[0]).all() and np.isfinite(mixed[0]).all()
+    scale = 1.0 + np.abs(f32[0])
+    dm, db = np.abs(mixed[0] - f32[0]) / scale, np.abs(bf16[0] - f32[0]) / scale
+    assert db[0].max() <= 0.1, db[0]                            # first evaluation: one pass of rounding
+    assert db.max() <= max(3.0 * dm.max(), 0.25), (dm.max(), db.max())   # later: no further from f32 than 3 x the mixed form is
+    assert 0.7 <= bf16[1] / f32[1] <= 1.4 and 0.7 <= mixed[1] / f32[1] <= 1.4, (f32[1], mixed[1], bf16[1])
