@@ -390,6 +390,13 @@ class GenerativeAdverserialNetwork(object):
                 if name.endswith('/filter') and v.dim() == 4 and name in self.store.offsets:
                     kh, kw, _, cout = v.shape
                     named.append((name, v, self.store.offsets[name], float(np.sqrt(np.float32(2.0 / float(kh * kw * cout))))))
+                elif name.endswith('/kernel') and v.dim() == 2 and name in self.store.offsets:
+                    # dense layers that run as bf16-multiply 1x1 convs -- forward where the reduction is short (the generator's
+                    # 512 -> 8192 dense1; >= 1024 inputs take the split-reduction f32 kernel), dgrad where the OUTPUT side is
+                    # short (the discriminator's 8208 -> 512 dense): packed with everything else instead of once per use
+                    forms = ('N' if v.shape[0] < 1024 else '') + ('T' if v.shape[1] < 1024 else '')
+                    if forms:
+                        named.append((name, v, self.store.offsets[name], 1.0, forms))
             self._plan = ops.FilterPackPlan(self.store.flat, named)
         self._plan.run()
 

@@ -149,19 +149,24 @@ class FilterPackPlan(object):
     """Every bf16 filter pack a solver step of the mixed-precision GAN needs -- the forward and the dgrad form of each
     equalised-LR conv kernel, factor folded in -- as ONE launch over the flat parameter buffer
     (sq_conv_pack_weights_multi_scaled_bf16) instead of one pack launch per use (97 per iteration at level 6).
-    `named` = [(name, leaf view of `flat`, float offset, wscale)].  run() packs and marks the plan fresh; any weight
+    `named` = [(name, leaf view of `flat`, float offset, wscale[, forms])].  run() packs and marks the plan fresh; any weight
     update (invalidate_packs) marks it stale, after which _packed_filter falls back to packing on demand."""
 
     def __init__(self, flat, named):
         lib = _lib.load()
         rows, scales, dst, item = [], [], 0, 0
         self.views = {}
-        for name, leaf, off, wscale in named:
-            if leaf.dim() != 4 or leaf.shape[0] != leaf.shape[1]:
+        for entry in named:
+            name, leaf, off, wscale = entry[:4]
+            forms = entry[4] if len(entry) > 4 else 'NT'        # which packs: N = forward, T = dgrad (transform)
+            if leaf.dim() == 2:                                 # a dense kernel (Cin, Cout): the 1x1 conv F.dense runs it as
+                K, (Cin, Cout) = 1, leaf.shape
+            elif leaf.dim() == 4 and leaf.shape[0] == leaf.shape[1]:
+                K, _, Cin, Cout = leaf.shape
+            else:
                 continue
-            K, _, Cin, Cout = leaf.shape
             for transform, (ci, co) in ((0, (Cin, Cout)), (1, (Cout, Cin))):
-                if ci % 8 or co % 4:
+                if ci % 8 or co % 4 or ('T' if transform else 'N') not in forms:
                     continue
                 n = lib.sq_conv_packed_weights_elems_bf16(K, ci, co)
                 if n <= 0:
@@ -180,7 +185,7 @@ class FilterPackPlan(object):
         self.table = torch.tensor(rows if rows else [[0] * 8], dtype=torch.int32, device=dev).contiguous()
         self.scales = torch.tensor(scales if scales else [1.0], dtype=torch.float32, device=dev)
         self.out = torch.zeros(max(dst, 8), dtype=torch.bfloat16, device=dev)
-        self.leaves = [leaf for _, leaf, _, _ in named]         # keep the ids valid
+        self.leaves = [entry[1] for entry in named]             # keep the ids valid
         _PLANS.add(self)
 
     def run(self):
@@ -191,7 +196,8 @@ class FilterPackPlan(object):
         self.fresh = True
 
     def lookup(self, w, K, Cin, Cout, wscale, transform):
-        e = self.views.get((id(w), bool(transform)))
+        base = w._base if w._base is not None else w            # F.dense hands the (1,1,Cin,Cout) view of its kernel
+        e = self.views.get((id(base), bool(transform)))
         if e is None or not self.fresh:
             return None
         d0, n, ws, k, ci, co = e
