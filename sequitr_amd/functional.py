@@ -231,9 +231,10 @@ def act(x, kind):
 class ActGate(object):
     """Backward of a convolution's fused activation as an epilogue of the kernel that produces the gradient.
     conv2d() hangs one of these on its output y (when FUSE_ACT_GATES is on); an op that is y's ONLY differentiable
-    consumer and whose backward kernel can apply act'(y) for free -- pixel_norm (y is its own input) and the 2x2
-    average pool (y is read for 4 bytes per element) -- takes it in FIRST-ORDER backward passes (grad mode off; the
-    penalty's create_graph pass keeps the separate differentiable _ActBwd), applies the gate and sets `applied`;
+    consumer and whose backward kernel can apply act'(y) for free -- pixel_norm (y is its own input), the 2x2
+    average pool (y is read for 4 bytes per element) and the next conv's dgrad -- takes it, applies the gate and sets
+    `applied` (pixel_norm: first-order passes only; pool and dgrad also in the penalty's create_graph pass, as the
+    differentiable _BcastGated / _ConvDgradGated);
     _Conv2d.backward then skips its own act_bwd pass (12 % of the GAN iteration).  Same multiply, same bits.
     The single-consumer premise holds for the reference's generator / discriminator wiring (gan.py:149-316: a conv's
     activation output feeds pixel_norm, the next conv or the pool, never two of them); it is a switch, default off,
@@ -263,6 +264,30 @@ class fuse_act_gates(object):
 def _gate_of(t):
     g = getattr(t, '_sq_act_gate', None)
     return g if isinstance(g, ActGate) else None
+
+
+class _ConvDgradGated(torch.autograd.Function):
+    """act_bwd(ConvDgrad(dy, w), gate, act) as ONE differentiable op: the gated dgrad kernel (ops.conv_dgrad_actgate) in passes
+    that are differentiated again -- the WGAN-GP penalty's create_graph pass through D(mix) used to run the dgrad and a
+    separate, differentiable act_bwd launch per conv -> leaky -> conv pair.  The gate is piecewise constant: no gradient
+    flows to it, and d/d(dy) = ConvFwd(act_bwd(ddx, gate)), d/dw = Wgrad(act_bwd(ddx, gate), dy) -- the kernels the unfused
+    pair's backward runs.  `out` = [the result, computed by the caller to find out whether the fused form exists]."""
+
+    @staticmethod
+    def forward(ctx, dy, w, wscale, gate, act, out):
+        ctx.wscale, ctx.act, ctx.w_id = wscale, act, _pid(w)
+        ctx.save_for_backward(dy, w, gate)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, ddx):
+        dy, w, gate = ctx.saved_tensors
+        g = _ActBwd.apply(ddx.contiguous(), gate, ctx.act)
+        d_dy = _ConvFwd.apply(g, w, ctx.wscale) if ctx.needs_input_grad[0] else None
+        d_w = None
+        if ctx.needs_input_grad[1] and _want(ctx.w_id) and not _sink_wgrad(g, dy, w.shape[0], ctx.wscale, ctx.w_id):
+            d_w = _ConvWgrad.apply(g, dy, w.shape[0], ctx.wscale)
+        return d_dy, d_w, None, None, None, None
 
 
 class _ChannelSum(torch.autograd.Function):
@@ -309,10 +334,12 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             ig = ctx.in_gate
-            if ig is not None and not ig.applied and not torch.is_grad_enabled():
+            if ig is not None and not ig.applied:
                 dx = ops.conv_dgrad_actgate(dpre, w, ctx.wscale, x, ig.act)
                 if dx is not None:
                     ig.applied = True                           # the conv that produced x skips its act_bwd pass
+                    if torch.is_grad_enabled():                 # a pass that is differentiated again: the same kernel, on the tape
+                        dx = _ConvDgradGated.apply(dpre, w, ctx.wscale, x, ig.act, [dx])
             if dx is None:
                 dx = _ConvDgrad.apply(dpre, w, ctx.wscale)
         want_w = ctx.needs_input_grad[1] and _want(ctx.w_id)
@@ -452,11 +479,29 @@ class _Pool2x2(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        if ctx.gate is not None and not torch.is_grad_enabled() and ctx.saved_tensors[0].shape[-1] % 4 == 0:
+        if ctx.gate is not None and ctx.saved_tensors[0].shape[-1] % 4 == 0:
             (x,) = ctx.saved_tensors                            # x = act(conv): act'(x) rides in the up-sampling (ActGate)
             ctx.gate.applied = True
+            if torch.is_grad_enabled():                         # a pass that is differentiated again: the same kernel, on the tape
+                return _BcastGated.apply(dy, x, ctx.scale, ctx.gate.act), None, None
             return ops.broadcast2x2_act_bwd(dy.contiguous(), x, ctx.scale, ctx.gate.act), None, None
         return _Bcast2x2.apply(dy, ctx.scale), None, None
+
+
+class _BcastGated(torch.autograd.Function):
+    """act_bwd(scale * up-sampling of dy, gate) as one differentiable op (the gated form of _Pool2x2's backward in passes that
+    are differentiated again); d/d(dy) = Pool(act_bwd(dd, gate)), nothing flows to the gate"""
+
+    @staticmethod
+    def forward(ctx, dy, gate, scale, act):
+        ctx.scale, ctx.act = scale, act
+        ctx.save_for_backward(gate)
+        return ops.broadcast2x2_act_bwd(dy.contiguous(), gate, scale, act)
+
+    @staticmethod
+    def backward(ctx, dd):
+        (gate,) = ctx.saved_tensors
+        return _Pool2x2.apply(_ActBwd.apply(dd.contiguous(), gate, ctx.act), ctx.scale, None), None, None, None
 
 
 class _Bcast2x2(torch.autograd.Function):
