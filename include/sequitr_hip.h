@@ -316,6 +316,10 @@ int sq_mosaic_unpack_f32(const float *m, float *y, int N, int H, int W, int C, i
 int64_t sq_dense_workspace_f32(int M, int K, int N);
 int sq_dense_fwd_f32(const float *x, const float *w, const float *bias, float *y, float *workspace, int M, int K, int N,
                      float wscale, int act, void *stream);
+/* its weight gradient: dW (K,N) = scale * x^T dY, db (N) or NULL = column sums of dY; x (M,K), dY (M,N), M <= 128 rows.
+ * accumulate: bit 0 -- dW is added to the contents of dw, bit 1 -- db to those of db. */
+int sq_dense_wgrad_f32(const float *x, const float *dy, float *dw, float *db, int M, int K, int N, float scale, int accumulate,
+                       void *stream);
 
 /* M (Ca,Cb) = sum_p a[p,:]^T b[p,:] with Ca <= 7, Cb % 4 == 0: weight gradient of to_image / from_image. */
 int64_t sq_wgrad1x1_small_workspace_f32(int64_t npix, int Ca, int Cb);

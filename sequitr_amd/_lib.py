@@ -110,6 +110,7 @@ SIGNATURES = {
     "sq_mbstd_map_bwd2_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int64, c_int, c_void_p]),
     "sq_wgan_losses_fwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "sq_wgan_losses_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_void_p]),
+    "sq_dense_wgrad_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_float, c_int, c_void_p]),
     "sq_wgrad1x1_small_workspace_f32": (c_int64, [c_int64, c_int, c_int]),
     "sq_wgrad1x1_small_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
     "sq_conv2d_concat_nhwc_fwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),

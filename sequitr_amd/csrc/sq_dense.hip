@@ -103,7 +103,53 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float *__restri
     y[i] = sq_act(v, act);
 }
 
+// Weight gradient of such a layer: dW (K,N) = scale * x^T dY, db (N) = column sums of dY, x (M,K), dY (M,N), M <= 128 rows.
+// As the 1x1 weight gradient of a "64-pixel image" it was 8208 blocks x one quarter-filled tile + a finish pass (61 us for
+// 0.5 GFLOP); here a block owns WK rows of dW: its WK columns of x sit in LDS (read as broadcasts), a thread owns one
+// output column and walks the M rows of dY once (fmaf chain in row order).  acc: bit 0 dW += , bit 1 db += .
+constexpr int WK = 32;
+__global__ __launch_bounds__(256) void dense_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                          float *__restrict__ dw, float *__restrict__ db, int M, int K, int N,
+                                                          float scale, int acc) {
+    __shared__ float xs[128][WK];
+    const int k0 = blockIdx.x * WK, n = blockIdx.y * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < M * WK; i += 256) {
+        const int m = i / WK, kk = i % WK;
+        xs[m][kk] = k0 + kk < K ? x[(size_t)m * K + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+    if (n >= N) return;
+    float a[WK], bs = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < WK; ++kk) a[kk] = 0.f;
+#pragma unroll 4
+    for (int m = 0; m < M; ++m) {
+        const float d = dy[(size_t)m * N + n];
+        bs += d;
+#pragma unroll
+        for (int kk = 0; kk < WK; ++kk) a[kk] = fmaf(xs[m][kk], d, a[kk]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < WK; ++kk)
+        if (k0 + kk < K) {
+            const size_t o = (size_t)(k0 + kk) * N + n;
+            const float v = scale == 1.0f ? a[kk] : a[kk] * scale;
+            dw[o] = (acc & 1) ? dw[o] + v : v;
+        }
+    if (db && blockIdx.x == 0) db[n] = (acc & 2) ? db[n] + bs : bs;
+}
+
 }  // namespace
+
+// dW (K,N) = scale * x^T dY and db (N, may be NULL) = column sums of dY for a dense layer's M <= 128 rows (f32, exact fmaf
+// chains in row order); accumulate: bit 0 -- add to the contents of dw, bit 1 -- of db.
+extern "C" int sq_dense_wgrad_f32(const float *x, const float *dy, float *dw, float *db, int M, int K, int N, float scale,
+                                  int accumulate, void *stream) {
+    SQ_REQUIRE(x && dy && dw && M > 0 && M <= 128 && K > 0 && N > 0, "sq_dense_wgrad_f32: bad arguments (1 <= M <= 128)");
+    hipLaunchKernelGGL(dense_wgrad_kernel, dim3((K + WK - 1) / WK, (N + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, dy, dw,
+                       db, M, K, N, scale, accumulate);
+    return sq_check_launch("sq_dense_wgrad_f32");
+}
 
 extern "C" int64_t sq_dense_workspace_f32(int M, int K, int N) {
     if (M <= 0 || K <= 0 || N <= 0) return -1;

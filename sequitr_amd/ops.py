@@ -254,6 +254,21 @@ def dense(x, w, bias=None, act=None, wscale=1.0):
     return y
 
 
+def dense_wgrad(x, dy, want_bias=True, dw_scale=1.0, shape4=False):
+    """(dW (K,N) * dw_scale, db (N) or None) of y = x @ w + b for a few rows: x (M,K), dY (M,N), M <= 128 (sq_dense_wgrad_f32);
+    shape4: dW as the (1,1,K,N) filter of the 1x1 conv F.dense runs the layer as."""
+    _chk(x, "x", ndim=2), _chk(dy, "dy", ndim=2)
+    M, K = x.shape
+    N = dy.shape[1]
+    if dy.shape[0] != M:
+        raise ValueError("dense_wgrad: x %s and dy %s differ in rows" % (tuple(x.shape), tuple(dy.shape)))
+    dw = torch.empty((1, 1, K, N) if shape4 else (K, N), dtype=torch.float32, device=x.device)
+    db = torch.empty((N,), dtype=torch.float32, device=x.device) if want_bias else None
+    _lib.check(_lib.load().sq_dense_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), M, K, N, float(dw_scale), 0, _stream()),
+               "sq_dense_wgrad_f32")
+    return dw, db
+
+
 def conv2d(x, w, bias=None, act=None, wscale=1.0, out=None, _dgrad=False):
     """KxK SAME conv + bias + activation.  x (N,H,W,Cin), w (K,K,Cin,Cout) HWIO.
     Batches of small images (H, W <= 8) run as one mosaic image (3x3) or as a flat pixel strip (1x1):
@@ -582,6 +597,8 @@ def conv2d_wgrad(x, dy, K, want_bias=True, dw_out=None, db_out=None, dw_scale=1.
     Cout = dy.shape[3]
     if tuple(dy.shape[:3]) != (N, H, W):
         raise ValueError("x %s and dy %s differ in N,H,W" % (tuple(x.shape), tuple(dy.shape)))
+    if K == 1 and N * H * W <= 128 and Cin * Cout >= (1 << 16) and USE_DENSE and dw_out is None and db_out is None:
+        return dense_wgrad(x.view(N * H * W, Cin), dy.view(N * H * W, Cout), want_bias, dw_scale, shape4=True)
     if USE_MOSAIC and W < 16 and N * H > 1 and Cin % 4 == 0 and Cout % 4 == 0:
         P = N * H * W
         if K == 1 and P % 16 == 0:

@@ -537,3 +537,20 @@ def test_act_gate_fusion_gives_the_same_bits(dtype):
     for k in wa:
         assert np.array_equal(wa[k], wb[k]), k
     assert not F.FUSE_ACT_GATES
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 8208, 512), (32, 512, 8192), (5, 300, 260), (128, 1024, 64)])
+def test_dense_weight_gradient_kernel(M, K, N):
+    """sq_dense_wgrad_f32: dW = scale * x^T dY and db = column sums of dY for a dense layer's few rows (the discriminator's
+    8208 -> 512 layer, the generator's 512 -> 8192 latent layer), exact-f32 fmaf chains in row order; also through
+    conv2d_wgrad's dispatch for the (1,1,M,K) form F.dense runs."""
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    dw, db = ops.dense_wgrad(dev(x), dev(dy), want_bias=True, dw_scale=0.5)
+    rw = 0.5 * (x.astype(np.float64).T @ dy.astype(np.float64))
+    assert np.abs(dw.cpu().numpy() - rw).max() <= 2e-6 * np.abs(rw).max() * np.sqrt(M)
+    assert np.allclose(db.cpu().numpy(), dy.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+    if K * N >= (1 << 16):
+        dw4, db4 = ops.conv2d_wgrad(dev(x.reshape(1, 1, M, K)), dev(dy.reshape(1, 1, M, N)), 1, want_bias=True, dw_scale=0.5)
+        assert tuple(dw4.shape) == (1, 1, K, N) and torch.equal(dw4.view(K, N), dw) and torch.equal(db4, db)
