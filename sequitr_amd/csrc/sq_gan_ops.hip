@@ -235,17 +235,36 @@ __global__ __launch_bounds__(256) void wgrad1x1_small_kernel(const float *__rest
 #pragma unroll
         for (int c = 0; c < CA; ++c)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) red[threadIdx.x * (CA * 4) + c * 4 + j] = acc[c][j];
-        __syncthreads();
-        if (tp == 0 && q < q4) {
+            for (int j = 0; j < 4; ++j) red[(c * 4 + j) * 256 + threadIdx.x] = acc[c][j];
+        // fold the pixel lanes: a fixed tree where pl is a power of two (thread = tp * quads_per_pass + tq); one thread adding
+        // all pl lanes of its quad was up to 2048 serial LDS reads per block (most of this kernel's time at Cb = 8)
+        if ((pl & (pl - 1)) == 0) {
+            for (int st = pl >> 1; st > 0; st >>= 1) {
+                __syncthreads();
+                if (tp < st) {
 #pragma unroll
-            for (int c = 0; c < CA; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float s = 0.f;
-                    for (int k = 0; k < pl; ++k) s += red[(k * quads_per_pass + tq) * (CA * 4) + c * 4 + j];
-                    out[c * Cb + q * 4 + j] = s;
+                    for (int e = 0; e < CA * 4; ++e) red[e * 256 + threadIdx.x] += red[e * 256 + threadIdx.x + st * quads_per_pass];
                 }
+            }
+            __syncthreads();
+            if (tp == 0 && q < q4) {
+#pragma unroll
+                for (int c = 0; c < CA; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) out[c * Cb + q * 4 + j] = red[(c * 4 + j) * 256 + tq];
+            }
+        } else {                                                // quad counts that do not divide 256: the serial fold
+            __syncthreads();
+            if (tp == 0 && q < q4) {
+#pragma unroll
+                for (int c = 0; c < CA; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float s = 0.f;
+                        for (int k = 0; k < pl; ++k) s += red[(c * 4 + j) * 256 + k * quads_per_pass + tq];
+                        out[c * Cb + q * 4 + j] = s;
+                    }
+            }
         }
         __syncthreads();
     }
