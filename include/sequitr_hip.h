@@ -639,6 +639,10 @@ int sq_wgrad1x1_small_bf16(const float *a, const void *b, float *m, float *asum,
  * otherwise be a handful of blocks, slices added in order by a finish kernel), and the weight gradient with the equalised-LR
  * factor in the finish kernel, plain or mosaic.
  * sq_conv2d_nhwc_wgrad_bf16 and the scaled form take channel counts that are multiples of 8 (8 mod 16: the ragged form). */
+/* a discriminator block's second conv with the 2x2 average pool that follows it (gan.py:171-192) written from the same kernel:
+ * y (N,H,W,Cout) and ypool (N,H/2,W/2,Cout) == sq_sumpool2x2_bf16(y, 0.25).  K = 3, even H and W. */
+int sq_conv2d_nhwc_fwd_avgpool_bf16(const void *x, const void *wp, const float *bias, void *y, void *ypool, int N, int H, int W,
+                                    int Cin, int Cout, int act, void *stream);
 int sq_conv2d_nhwc_dgrad_actgate_bf16(const void *dy, const void *wp_t, const void *gate, int act, void *dx, int N, int H,
                                       int W, int Cin, int Cout, int K, void *stream);
 int sq_conv2d_nhwc_mosaic_bf16(const void *x, const void *wp, const float *bias, const void *gate, void *y, int Nimg, int h,

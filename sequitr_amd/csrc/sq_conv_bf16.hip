@@ -56,6 +56,8 @@ struct SqDropEpi {
     // 2x2/s2 max pool of the block output in the same epilogue (pool != NULL; H, W even): the pooled tensor
     // (N,H/2,W/2,Cout) the next encoder level reads is written beside y, what sq_maxpool2x2_fwd_bf16 computes from y
     __bf16 *pool = nullptr;
+    int pool_avg = 0;                                           // 1: the 2x2 AVERAGE pool instead -- bf16(((a + b) + (c + d)) * 0.25) of the stored
+                                                                // bf16 values, sq_sumpool2x2_bf16's order and rounding (the GAN's discriminator blocks)
     // sign mask of a ReLU output, one bit per element in NHWC order (bit c & 7 of byte (pixel * C + c) >> 3; C % 16 == 0):
     // written by the forward conv beside y (FORM_MK), read by the dgrad that gates on that output (FORM_MG) in place
     // of the tensor itself -- 1/16 of its bytes
@@ -592,6 +594,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                         pprev = o;
                     } else {
                         bf16x4 m;
+                        if (drop.pool_avg) {
+                            // (a + b) + (c + d): the horizontal pairs first (the partner lane holds x + 1), rows r - 1 and r; odd lanes
+                            // compute the mirrored sum and do not store
+                            const uint2 tv = __builtin_bit_cast(uint2, pprev), bv = __builtin_bit_cast(uint2, o);
+                            uint2 tp, bp;
+                            tp.x = (unsigned)__shfl_xor((int)tv.x, 1); tp.y = (unsigned)__shfl_xor((int)tv.y, 1);
+                            bp.x = (unsigned)__shfl_xor((int)bv.x, 1); bp.y = (unsigned)__shfl_xor((int)bv.y, 1);
+                            const bf16x4 tq = __builtin_bit_cast(bf16x4, tp), bq = __builtin_bit_cast(bf16x4, bp);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                m[j] = (__bf16)((((float)pprev[j] + (float)tq[j]) + ((float)o[j] + (float)bq[j])) * 0.25f);
+                        } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) m[j] = (float)pprev[j] > (float)o[j] ? pprev[j] : o[j];
                         const uint2 mv = __builtin_bit_cast(uint2, m);
@@ -601,6 +615,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                         const bf16x4 pp = __builtin_bit_cast(bf16x4, pv);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) m[j] = (float)pp[j] > (float)m[j] ? pp[j] : m[j];
+                        }
                         const int gy = ty * TH + 4 * wv + r;
                         const unsigned poff = (off != OOB && !(li & 1))
                             ? (unsigned)((((n * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * Cout + co) * 2) : OOB;
@@ -1095,6 +1110,19 @@ extern "C" int sq_conv2d_nhwc_fwd_dropout_pool_bf16(const void *x, const void *w
     }
     d.pool = reinterpret_cast<__bf16 *>(ypool);
     return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, K, act, stream, nullptr, d);
+}
+
+// weighted_conv2d followed by the discriminator's 2x2 average pool (gan.py:171-192) on bf16 tensors: y (N,H,W,Cout) = act(conv + bias)
+// AND ypool (N,H/2,W/2,Cout) = the average pool of the stored y (sq_sumpool2x2_bf16(y, 0.25), bit for bit) from one kernel.
+// K = 3, H and W even.
+extern "C" int sq_conv2d_nhwc_fwd_avgpool_bf16(const void *x, const void *wp, const float *bias, void *y, void *ypool, int N, int H,
+                                               int W, int Cin, int Cout, int act, void *stream) {
+    SQ_REQUIRE(ypool && H % 2 == 0 && W % 2 == 0, "sq_conv2d_nhwc_fwd_avgpool_bf16: even H and W, ypool");
+    SQ_REQUIRE_ALIGNED(ypool);
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    d.pool = reinterpret_cast<__bf16 *>(ypool);
+    d.pool_avg = 1;
+    return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, 3, act, stream, nullptr, d);
 }
 
 // conv + bias + ReLU with the sign mask of the output beside it (mask: N*H*W*Cout/8 bytes, bit c & 7 of byte

@@ -331,40 +331,79 @@ class _Conv2d(torch.autograd.Function):
         if ctx.gate is not None:
             ctx.gate.applied = False
         dpre = _ActBwd.apply(dy, y, ctx.act) if (y is not None and not gated) else dy.contiguous()
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            ig = ctx.in_gate
-            if ig is not None and not ig.applied:
-                dx = ops.conv_dgrad_actgate(dpre, w, ctx.wscale, x, ig.act)
-                if dx is not None:
-                    ig.applied = True                           # the conv that produced x skips its act_bwd pass
-                    if torch.is_grad_enabled():                 # a pass that is differentiated again: the same kernel, on the tape
-                        dx = _ConvDgradGated.apply(dpre, w, ctx.wscale, x, ig.act, [dx])
-            if dx is None:
-                dx = _ConvDgrad.apply(dpre, w, ctx.wscale)
-        want_w = ctx.needs_input_grad[1] and _want(ctx.w_id)
-        need_b = ctx.has_bias and ctx.needs_input_grad[2] and _want(ctx.bias_id)
-        if not want_w and not need_b:
-            return dx, None, None, None, None, None
-        if want_w and _sink_wgrad(x, dpre, w.shape[0], ctx.wscale, ctx.w_id, ctx.bias_id, need_b):
-            return dx, None, None, None, None, None             # queued: dW / db land in the parameters' sinks at the flush
-        if want_w and not torch.is_grad_enabled():
-            # first-order fast path: dW and db from ONE pass of the wgrad kernel
-            sw, sb = ctx.sinks
-            Cin, Cout = w.shape[2], w.shape[3]
-            if sw is None or (Cout % 4) or not (Cin % 8 == 0 or Cin == 1):   # sinks only on the MFMA wgrad kernels
-                sw = sb = None
-            dw, db = ops.conv_wgrad_raw(x, dpre, w.shape[0], want_bias=need_b, dw_out=sw,
-                                        db_out=sb if need_b else None, dw_scale=ctx.wscale)   # w' = w * wscale (gan.py:79)
-            if sw is not None:
-                dw = None
-                db = None if sb is not None else db
+        return _conv_backward(ctx, x, w, dpre) + (None, None, None)
+
+
+def _conv_backward(ctx, x, w, dpre):
+    """(dx, dW, db) of pre = conv2d(x, w * wscale) + bias from d(pre): shared by _Conv2d and _Conv2dPool"""
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        ig = ctx.in_gate
+        if ig is not None and not ig.applied:
+            dx = ops.conv_dgrad_actgate(dpre, w, ctx.wscale, x, ig.act)
+            if dx is not None:
+                ig.applied = True                           # the conv that produced x skips its act_bwd pass
+                if torch.is_grad_enabled():                 # a pass that is differentiated again: the same kernel, on the tape
+                    dx = _ConvDgradGated.apply(dpre, w, ctx.wscale, x, ig.act, [dx])
+        if dx is None:
+            dx = _ConvDgrad.apply(dpre, w, ctx.wscale)
+    want_w = ctx.needs_input_grad[1] and _want(ctx.w_id)
+    need_b = ctx.has_bias and ctx.needs_input_grad[2] and _want(ctx.bias_id)
+    if not want_w and not need_b:
+        return dx, None, None
+    if want_w and _sink_wgrad(x, dpre, w.shape[0], ctx.wscale, ctx.w_id, ctx.bias_id, need_b):
+        return dx, None, None                               # queued: dW / db land in the parameters' sinks at the flush
+    if want_w and not torch.is_grad_enabled():
+        # first-order fast path: dW and db from ONE pass of the wgrad kernel
+        sw, sb = ctx.sinks
+        Cin, Cout = w.shape[2], w.shape[3]
+        if sw is None or (Cout % 4) or not (Cin % 8 == 0 or Cin == 1):   # sinks only on the MFMA wgrad kernels
+            sw = sb = None
+        dw, db = ops.conv_wgrad_raw(x, dpre, w.shape[0], want_bias=need_b, dw_out=sw,
+                                    db_out=sb if need_b else None, dw_scale=ctx.wscale)   # w' = w * wscale (gan.py:79)
+        if sw is not None:
+            dw = None
+            db = None if sb is not None else db
+    else:
+        if want_w:
+            dw = _ConvWgrad.apply(x, dpre, w.shape[0], ctx.wscale)
+        if need_b:
+            db = _ChannelSum.apply(dpre)
+    return dx, dw, db
+
+
+class _Conv2dPool(torch.autograd.Function):
+    """avgpool2x2(act(conv2d(x, w * wscale) + bias)): the pooled tensor is written from the conv's epilogue (ops.conv2d_avgpool),
+    y stays for the backward -- the up-sampling of d(pool) through the activation's backward (the gated broadcast kernel; in
+    passes that are differentiated again its tape form _BcastGated), then the conv's own backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, act, wscale):
+        ctx.in_gate = _gate_of(x) if FUSE_ACT_GATES else None
+        y, p = ops.conv2d_avgpool(x, w, bias, act=act, wscale=wscale)
+        ctx.act, ctx.wscale, ctx.has_bias = act, wscale, bias is not None
+        ctx.w_id, ctx.bias_id = _pid(w), _pid(bias)
+        ctx.sinks = (None, None)
+        ctx.save_for_backward(x, w, y)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, w, y = ctx.saved_tensors
+        if not ops.ACT[ctx.act]:
+            dpre = _Bcast2x2.apply(dp, 0.25)
+        elif torch.is_grad_enabled():
+            dpre = _BcastGated.apply(dp, y, 0.25, ctx.act)
         else:
-            if want_w:
-                dw = _ConvWgrad.apply(x, dpre, w.shape[0], ctx.wscale)
-            if need_b:
-                db = _ChannelSum.apply(dpre)
-        return dx, dw, db, None, None, None
+            dpre = ops.broadcast2x2_act_bwd(dp.contiguous(), y, 0.25, ctx.act)
+        return _conv_backward(ctx, x, w, dpre) + (None, None)
+
+
+def conv2d_avgpool(x, w, bias=None, act=None, wscale=1.0):
+    """avgpool2x2(conv2d(...)) as one tape entry where the fused kernel exists (bf16 features, 3x3, even sides >= 16), else the two ops"""
+    if ops._conv2d_avgpool_takes(x, w):
+        return _Conv2dPool.apply(x, w, bias, act, float(wscale))
+    return avgpool2x2(conv2d(x, w, bias, act, wscale))
 
 
 def conv2d(x, w, bias=None, act=None, wscale=1.0):

@@ -54,9 +54,11 @@ def _act_name(activation):
 
 
 def weighted_conv2d(inputs=None, filters=None, kernel_size=[3, 3], padding="same",
-                    activation=k_leaky_relu_alpha, name='conv', reuse=None, norm=True):
+                    activation=k_leaky_relu_alpha, name='conv', reuse=None, norm=True, pool=False):
     """Equalised-learning-rate convolution (gan.py:61-99): kernel ~ N(0,1) scaled at run time by
-    sqrt(2 / (kh*kw*filters)), + bias (1,1,1,filters), activation, optional pixel norm."""
+    sqrt(2 / (kh*kw*filters)), + bias (1,1,1,filters), activation, optional pixel norm.
+    pool (not in the reference's signature): the 2x2 average pool of the discriminator's blocks (gan.py:189-192) applied to
+    the result -- written from the conv kernel's epilogue where that form exists, else F.avgpool2x2 of the result."""
     if padding.lower() != 'same':
         raise ValueError('only SAME padding is implemented')
     kh, kw = int(kernel_size[0]), int(kernel_size[1])
@@ -65,10 +67,12 @@ def weighted_conv2d(inputs=None, filters=None, kernel_size=[3, 3], padding="same
         kernels = scope.get_variable('filter', (kh, kw, cin, filters), scope.random_normal)
         bias = scope.get_variable('bias', (1, 1, 1, filters), scope.zeros)
     wscale = float(np.sqrt(np.float32(2.0 / float(kh * kw * filters))))
+    if pool and not norm:
+        return F.conv2d_avgpool(inputs, kernels, bias.view(-1), act=_act_name(activation), wscale=wscale)
     out = F.conv2d(inputs, kernels, bias.view(-1), act=_act_name(activation), wscale=wscale)
     if norm:
         out = pixel_norm(out)
-    return out
+    return F.avgpool2x2(out) if pool else out
 
 
 def to_image(X, filters=2, n=None):
@@ -124,9 +128,9 @@ def discriminator_network(x, filters, groups=1):
         with variable_scope("layer_{0:d}".format(num_layers - l - 1)):
             conv1 = weighted_conv2d(inputs=conv_layers[-1], filters=f, kernel_size=[3, 3],
                                     activation=k_leaky_relu_alpha, name='conv1', norm=False)
-            conv2 = weighted_conv2d(inputs=conv1, filters=f, kernel_size=[3, 3],
-                                    activation=k_leaky_relu_alpha, name='conv2', norm=False)
-            conv_layers.append(F.avgpool2x2(conv2))
+            # conv2 and the average pool that follows it: one kernel where the fused form exists (weighted_conv2d(pool=True))
+            conv_layers.append(weighted_conv2d(inputs=conv1, filters=f, kernel_size=[3, 3],
+                                               activation=k_leaky_relu_alpha, name='conv2', norm=False, pool=True))
     x = conv_layers[-1]
     with variable_scope('output'):
         mbstd = minibatch_stdev(x, groups)

@@ -855,6 +855,15 @@ def scale(x, s, one_minus=False):
     return y
 
 
+def _conv2d_avgpool_takes(x, w):
+    return x.dtype == _BF16 and _gb().conv2d_avgpool_takes(x, w)
+
+
+def conv2d_avgpool(x, w, bias=None, act=None, wscale=1.0):
+    """(y, 2x2 average pool of y), y = act(conv3x3(x, w * wscale) + bias), from one kernel (bf16 feature tensors only)"""
+    return _gb().conv2d_avgpool(x, w, bias, act, wscale)
+
+
 def cast(x, dtype):
     """float32 <-> bfloat16 copy (the GAN's two storage boundaries)"""
     return _gb().cast(x, dtype)

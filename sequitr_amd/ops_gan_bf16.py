@@ -313,3 +313,28 @@ def conv_wgrad(x, dy, K, want_bias=False, dw_out=None, db_out=None, dw_scale=1.0
     _lib.check(lib.sq_conv2d_nhwc_wgrad_scaled_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), N, H, W, Cin, Cout, K,
                                                    float(dw_scale), _stream()), "sq_conv2d_nhwc_wgrad_scaled_bf16")
     return dw, db
+
+
+def conv2d_avgpool_takes(x, w):
+    """can conv2d_avgpool fuse this block?  bf16 features, 3x3, even image sides of at least 16 (the small-image levels keep
+    their mosaic conv + a pool launch)"""
+    return (x.dtype == BF16 and x.dim() == 4 and w.dim() == 4 and w.shape[0] == 3 and w.shape[1] == 3 and x.shape[1] % 2 == 0
+            and x.shape[2] % 2 == 0 and x.shape[2] >= 16 and x.shape[3] % 8 == 0 and w.shape[3] % 8 == 0 and w.shape[2] == x.shape[3])
+
+
+def conv2d_avgpool(x, w, bias=None, act=None, wscale=1.0):
+    """(y, avgpool2x2(y)) with y = act(conv3x3(x, w * wscale) + bias): the second conv of a discriminator block and the pool that
+    follows it (gan.py:171-192) from one kernel; the pooled tensor equals sumpool2x2(y, 0.25) bit for bit."""
+    if not conv2d_avgpool_takes(x, w):
+        raise _lib.SequitrHipError("conv2d_avgpool: needs bf16 features, a 3x3 filter and even sides >= 16")
+    _feat(x, "x"), _chk(w, "w", dtype=F32)
+    if bias is not None:
+        _chk(bias, "bias", dtype=F32)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    wp = ops._packed_filter(w, 3, Cin, Cout, wscale, False)
+    y = torch.empty((N, H, W, Cout), dtype=BF16, device=x.device)
+    p = torch.empty((N, H // 2, W // 2, Cout), dtype=BF16, device=x.device)
+    _lib.check(_lib.load().sq_conv2d_nhwc_fwd_avgpool_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(p), N, H, W, Cin, Cout,
+                                                          ACT[act], _stream()), "sq_conv2d_nhwc_fwd_avgpool_bf16")
+    return y, p

@@ -326,3 +326,36 @@ def test_bf16_storage_trains_like_the_f32_graph():
     assert db[0].max() <= 0.1, db[0]                            # first evaluation: one pass of rounding
     assert db.max() <= max(3.0 * dm.max(), 0.25), (dm.max(), db.max())   # later: no further from f32 than 3 x the mixed form is
     assert 0.7 <= bf16[1] / f32[1] <= 1.4 and 0.7 <= mixed[1] / f32[1] <= 1.4, (f32[1], mixed[1], bf16[1])
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 16, 16), (1, 32, 48, 8, 16), (2, 64, 32, 32, 32), (1, 16, 16, 64, 64)])
+def test_conv_with_average_pool_epilogue(N, H, W, Cin, Cout):
+    """ops.conv2d_avgpool: the discriminator block's second conv and its 2x2 average pool from one kernel -- y and the pooled
+    tensor equal the two launches bit for bit; the tape entry's gradients (first order and the penalty's second order)
+    equal those of conv2d followed by avgpool2x2"""
+    rng = np.random.default_rng(N + H + W + Cin + Cout)
+    xg, _ = rb(rng, (N, H, W, Cin))
+    w = torch.as_tensor(rng.standard_normal((3, 3, Cin, Cout)), dtype=torch.float32).cuda()
+    b = torch.as_tensor(rng.standard_normal(Cout) * 0.1, dtype=torch.float32).cuda()
+    ws = float(np.sqrt(np.float32(2.0 / (9 * Cout))))
+    y, p = ops.conv2d_avgpool(xg, w, b, act="leaky", wscale=ws)
+    y0 = ops.conv2d(xg, w, b, act="leaky", wscale=ws)
+    assert torch.equal(y, y0) and torch.equal(p, ops.avgpool2x2(y0))
+    # gradients: fused tape entry vs the two ops, first order and through a create_graph pass
+    res = []
+    for fused in (True, False):
+        xa = xg.clone().requires_grad_(True)
+        wa, ba = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        out = F.conv2d_avgpool(xa, wa, ba, act="leaky", wscale=ws) if fused else F.avgpool2x2(F.conv2d(xa, wa, ba, act="leaky", wscale=ws))
+        gp, _ = rb(np.random.default_rng(1), tuple(out.shape))
+        (gx,) = torch.autograd.grad(out, xa, gp, create_graph=True)
+        pen = (gx.float() ** 2).sum()
+        g1 = torch.autograd.grad(out, [xa, wa, ba], gp, retain_graph=True)
+        g2 = torch.autograd.grad(pen, [wa], allow_unused=True)
+        res.append((out.detach(), gx.detach(), g1, g2))
+    (o1, x1, a1, s1), (o2, x2, a2, s2) = res
+    assert torch.equal(o1, o2) and torch.equal(x1, x2)
+    for u, v in zip(a1, a2):
+        assert torch.equal(u, v)
+    for u, v in zip(s1, s2):
+        assert (u is None) == (v is None) and (u is None or torch.equal(u, v))
