@@ -911,7 +911,7 @@ def main_weightmap2(args):
            "config": {"workload": "ImageWeightMap2(w0=10, sigma=5) on 16 x 512x512 binary label tiles resident in HBM: device "
                                   "boundary points, native exact Delaunay on host threads, device point location + Gaussian "
                                   "+ weights (triangulation = %s)" % tri,
-                      "simplices": int(simp.shape[0]), "boundary_points": int(xy.shape[0]),
+                      "simplices": int((simp[:, 0] >= 0).sum()), "boundary_points": int(xy.shape[0]),
                       "stage_ms": {"boundary_points_and_compaction": round(t_pts * 1e3, 3), "points_d2h": round(t_d2h * 1e3, 3),
                                    "host_triangulation": round(t_tri * 1e3, 3), "simplices_h2d": round(t_h2d * 1e3, 3),
                                    "device_raster_gauss_weights": round(kms, 4)},

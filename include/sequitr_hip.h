@@ -593,8 +593,10 @@ int sq_wm2_boundary_points_u8(const float *img, uint8_t *points, int N, int H, i
  * scipy.spatial.Delaunay (pipeline.py:531-537) -- integer predicates in 128-bit arithmetic, incremental insertion in scan
  * order, tiles on a small pool of host threads (SQ_HOST_THREADS, default 16).  xy = the (row, column) int32 pairs of
  * `nsets` tiles back to back, tile s = points offsets[s] .. offsets[s+1] (0 <= coordinate < 32768, distinct); writes
- * the (tile, x0, y0, x1, y1, x2, y2) rows and longest edges sq_weightmap2_delaunay_f32 takes; cap = 2 * offsets[nsets]
- * rows always suffice.  Returns the number of rows, or a negative SQ_E* code. */
+ * the (tile, x0, y0, x1, y1, x2, y2) rows and longest edges sq_weightmap2_delaunay_f32 takes.  A triangulation of n points
+ * has < 2 n triangles: tile s owns rows 2 offsets[s] .. 2 offsets[s+1] - 1, written by the worker that triangulated it (no
+ * second pass); the few rows a tile does not need are padding with tile = -1, which sq_weightmap2_delaunay_f32 skips.
+ * Returns the number of rows = 2 * offsets[nsets] (cap must hold them), or a negative SQ_E* code. */
 int64_t sq_delaunay2d_batch_i32(const int32_t *xy, const int64_t *offsets, int nsets, int32_t *simplices, double *longest,
                                 int64_t cap);
 int sq_weightmap2_delaunay_f32(const float *img, const int32_t *simplices, const double *longest, int nsimp, double *out64,

@@ -257,18 +257,25 @@ extern "C" int sq_wm2_boundary_points_u8(const float *img, uint8_t *points, int 
 
 // HOST function (no GPU work).  xy: the boundary points of `nsets` tiles back to back, (row, column) int32 pairs, tile s
 // = points offsets[s] .. offsets[s + 1]; simplices: room for `cap` rows of 7 int32 {tile, x0, y0, x1, y1, x2, y2};
-// longest: `cap` doubles.  Returns the number of rows written (a Delaunay triangulation of n points has < 2 n
-// triangles, so cap = 2 * offsets[nsets] always suffices), or a negative SQ_E* code.
+// longest: `cap` doubles.  A Delaunay triangulation of n points has < 2 n triangles, so tile s owns rows 2 offsets[s] ..
+// 2 offsets[s + 1] - 1: every worker writes its tile's rows as soon as the tile is triangulated (no second pass, no
+// barrier between the tiles), and pads the few rows its tile does not need with tile = -1 (the raster kernel skips those).
+// Returns the number of rows = 2 * offsets[nsets] (cap must hold them), or a negative SQ_E* code.
 extern "C" int64_t sq_delaunay2d_batch_i32(const int32_t *xy, const int64_t *offsets, int nsets, int32_t *simplices,
                                            double *longest, int64_t cap) {
     if (!xy || !offsets || !simplices || !longest || nsets <= 0) {
         sq_set_error("sq_delaunay2d_batch_i32: bad arguments");
         return SQ_EINVAL;
     }
-    std::vector<std::vector<int>> tris((size_t)nsets);
-    std::vector<int64_t> row0((size_t)nsets + 1, 0);
-    std::atomic<int> next(0), failed(-1), next_out(0);
-    auto triangulate = [&]() {
+    const int64_t rows = 2 * offsets[nsets];
+    if (rows > cap) {
+        sq_set_error("sq_delaunay2d_batch_i32: %lld rows (2 per point) exceed the capacity %lld", (long long)rows, (long long)cap);
+        return SQ_EINVAL;
+    }
+    std::atomic<int> next(0), failed(-1);
+    const bool prof = getenv("SQ_DL_PROF") != nullptr;
+    auto work = [&]() {
+        std::vector<int> tv;
         for (;;) {
             const int s = next.fetch_add(1);
             if (s >= nsets) return;
@@ -276,67 +283,55 @@ extern "C" int64_t sq_delaunay2d_batch_i32(const int32_t *xy, const int64_t *off
             bool ok = e >= b && e - b < ((int64_t)1 << 24);
             for (int64_t i = 2 * b; ok && i < 2 * e; ++i) ok = xy[i] >= 0 && xy[i] < (1 << 15);
             const auto d0 = std::chrono::steady_clock::now();
-            if (ok) ok = delaunay(xy + 2 * b, (int)(e - b), tris[(size_t)s]);
+            tv.clear();
+            if (ok) ok = delaunay(xy + 2 * b, (int)(e - b), tv);
+            const auto d1 = std::chrono::steady_clock::now();
+            int64_t r = 2 * b;
+            const int64_t rend = 2 * e;
+            if (ok && (int64_t)tv.size() / 3 > rend - r) ok = false;
             if (!ok) failed.store(s);
-            if (getenv("SQ_DL_PROF"))
-                fprintf(stderr, "  tile %d: %lld points %.3f ms\n", s, (long long)(e - b),
-                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d0).count());
-        }
-    };
-    // second phase, also per tile: the rows the raster kernel takes, written at the tile's offset
-    auto emit = [&]() {
-        for (;;) {
-            const int s = next_out.fetch_add(1);
-            if (s >= nsets) return;
-            const int32_t *pts = xy + 2 * offsets[s];
-            const std::vector<int> &tv = tris[(size_t)s];
-            int64_t r = row0[(size_t)s];
-            for (size_t k = 0; k + 2 < tv.size(); k += 3, ++r) {
-                int32_t *row = simplices + 7 * r;
-                row[0] = s;
-                long long best = 0;
-                for (int j = 0; j < 3; ++j) {
-                    const int a = tv[k + j], b = tv[k + (j + 1) % 3];
-                    row[1 + 2 * j] = pts[2 * a];
-                    row[2 + 2 * j] = pts[2 * a + 1];
-                    const long long dx = (long long)pts[2 * a] - pts[2 * b], dy = (long long)pts[2 * a + 1] - pts[2 * b + 1];
-                    best = std::max(best, dx * dx + dy * dy);
+            const int32_t *pts = xy + 2 * b;
+            if (ok)
+                for (size_t k = 0; k + 2 < tv.size(); k += 3, ++r) {
+                    int32_t *row = simplices + 7 * r;
+                    row[0] = s;
+                    long long best = 0;
+                    for (int j = 0; j < 3; ++j) {
+                        const int a = tv[k + j], c = tv[k + (j + 1) % 3];
+                        row[1 + 2 * j] = pts[2 * a];
+                        row[2 + 2 * j] = pts[2 * a + 1];
+                        const long long dx = (long long)pts[2 * a] - pts[2 * c], dy = (long long)pts[2 * a + 1] - pts[2 * c + 1];
+                        best = std::max(best, dx * dx + dy * dy);
+                    }
+                    longest[r] = std::sqrt((double)best);      // = np.sqrt(dx^2 + dy^2).max(): sqrt is monotone, the integers exact
                 }
-                longest[r] = std::sqrt((double)best);          // = np.sqrt(dx^2 + dy^2).max(): sqrt is monotone, the integers exact
+            for (; r < rend; ++r) {                             // rows this tile does not need
+                int32_t *row = simplices + 7 * r;
+                row[0] = -1;
+                for (int j = 1; j < 7; ++j) row[j] = 0;
+                longest[r] = 0.0;
             }
+            if (prof)
+                fprintf(stderr, "  tile %d: %lld points, triangulate %.3f ms, rows %.3f ms\n", s, (long long)(e - b),
+                        std::chrono::duration<double, std::milli>(d1 - d0).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d1).count());
         }
     };
     const int nt = host_threads(nsets);
-    const bool prof = getenv("SQ_DL_PROF") != nullptr;
     const auto c0 = std::chrono::steady_clock::now();
     {
         std::vector<std::thread> pool;
-        for (int i = 1; i < nt; ++i) pool.emplace_back(triangulate);
-        triangulate();
+        for (int i = 1; i < nt; ++i) pool.emplace_back(work);
+        work();
         for (auto &th : pool) th.join();
     }
-    const auto c1 = std::chrono::steady_clock::now();
     if (failed.load() >= 0) {
         sq_set_error("sq_delaunay2d_batch_i32: tile %d could not be triangulated (coordinates out of range or an "
                      "internal inconsistency)", failed.load());
         return SQ_EINVAL;
     }
-    for (int s = 0; s < nsets; ++s) row0[(size_t)s + 1] = row0[(size_t)s] + (int64_t)tris[(size_t)s].size() / 3;
-    const int64_t r = row0[(size_t)nsets];
-    if (r > cap) {
-        sq_set_error("sq_delaunay2d_batch_i32: %lld simplices exceed the capacity %lld", (long long)r, (long long)cap);
-        return SQ_EINVAL;
-    }
-    {
-        std::vector<std::thread> pool;
-        for (int i = 1; i < nt; ++i) pool.emplace_back(emit);
-        emit();
-        for (auto &th : pool) th.join();
-    }
-    if (prof) {
-        const auto c2 = std::chrono::steady_clock::now();
-        fprintf(stderr, "sq_delaunay2d_batch_i32: %d tiles, %d threads: triangulate %.3f ms, emit %.3f ms\n", nsets, nt,
-                std::chrono::duration<double, std::milli>(c1 - c0).count(), std::chrono::duration<double, std::milli>(c2 - c1).count());
-    }
-    return r;
+    if (prof)
+        fprintf(stderr, "sq_delaunay2d_batch_i32: %d tiles, %d threads: %.3f ms\n", nsets, nt,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count());
+    return rows;
 }

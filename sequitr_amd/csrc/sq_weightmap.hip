@@ -376,6 +376,7 @@ __global__ __launch_bounds__(256) void wm2_raster_kernel(const int *__restrict__
     if (s >= nsimp) return;
     const int *v = simp + (size_t)s * 7;                        // tile, x0, y0, x1, y1, x2, y2 (x = row, y = column as np.where)
     const int n = v[0];
+    if (n < 0) return;                                          // a padding row of sq_delaunay2d_batch_i32
     const long long x0 = v[1], y0 = v[2], x1 = v[3], y1 = v[4], x2 = v[5], y2 = v[6];
     const int xmin = (int)min(x0, min(x1, x2)), xmax = (int)max(x0, max(x1, x2));
     const int ymin = (int)min(y0, min(y1, y2)), ymax = (int)max(y0, max(y1, y2));

@@ -1348,11 +1348,12 @@ def wm2_boundary_points(img):
 _DELAUNAY_OUT = {}
 
 
-def delaunay2d_batch(xy, offsets):
+def delaunay2d_batch(xy, offsets, compact=False):
     """HOST: exact Delaunay triangulation of each tile's integer points (sq_delaunay2d_batch_i32, native, threaded).
     xy (P,2) int32 CPU tensor (row, column), offsets (T+1) int64 CPU tensor.  Returns (simplices (S,7) int32, longest (S)
     float64) as views of a pinned staging buffer ready for the upload -- overwritten by the next call: upload (or
-    clone) them first."""
+    clone) them first.  S = 2 P: tile s owns rows 2 offsets[s] .. 2 offsets[s+1] - 1 and the few it does not need are
+    padding with tile = -1 (weightmap_delaunay skips them); compact=True returns copies without the padding rows."""
     if xy.device.type != "cpu" or offsets.device.type != "cpu" or xy.dtype != torch.int32 or offsets.dtype != torch.int64:
         raise TypeError("delaunay2d_batch takes CPU tensors: xy int32 (P,2), offsets int64 (T+1)")
     xy, offsets = xy.contiguous(), offsets.contiguous()
@@ -1368,6 +1369,9 @@ def delaunay2d_batch(xy, offsets):
     n = _lib.load().sq_delaunay2d_batch_i32(xy.data_ptr(), offsets.data_ptr(), nsets, simp.data_ptr(), lng.data_ptr(), cap)
     if n < 0:
         _lib.check(int(n), "sq_delaunay2d_batch_i32")
+    if compact:
+        keep = simp[:n, 0] >= 0
+        return simp[:n][keep].clone(), lng[:n][keep].clone()
     return simp[:n], lng[:n]
 
 

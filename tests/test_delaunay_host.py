@@ -16,7 +16,7 @@ def triangulate(sets):
     xy = torch.from_numpy(np.ascontiguousarray(np.concatenate(sets).astype(np.int32)))
     off = torch.zeros(len(sets) + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(torch.tensor([len(s) for s in sets]), 0)
-    simp, lng = ops.delaunay2d_batch(xy, off)
+    simp, lng = ops.delaunay2d_batch(xy, off, compact=True)        # without the per-tile padding rows
     return simp.numpy(), lng.numpy()
 
 

@@ -153,7 +153,7 @@ def test_weightmap2_native_triangulation_no_scipy_in_the_path():
     # kernels pinned: device map == CPU rasterisation of the same (native) triangulation
     for lab in labs:
         P = np.column_stack(np.where(weightmap_ref.boundary_points(lab))).astype(np.int32)
-        simp, _ = ops.delaunay2d_batch(torch.from_numpy(P), torch.tensor([0, len(P)], dtype=torch.int64))
+        simp, _ = ops.delaunay2d_batch(torch.from_numpy(P), torch.tensor([0, len(P)], dtype=torch.int64), compact=True)
         emu, _ = weightmap_ref.image_weight_map2_raster(lab, 10., 5., vertices=simp.numpy()[:, 1:].reshape(-1, 3, 2))
         got = device_weightmaps2(lab[None], 10., 5., device="cuda:0", dtype=torch.float64).cpu().numpy()[0]
         assert np.abs(got - emu).max() <= 1e-12
@@ -193,7 +193,7 @@ def test_create_weightmaps_gpu_methods_write_the_reference_layout(tmp_path):
         else:
             from sequitr_amd import ops
             P = np.column_stack(np.where(weightmap_ref.boundary_points(lab))).astype(np.int32)
-            simp, _ = ops.delaunay2d_batch(torch.from_numpy(P), torch.tensor([0, len(P)], dtype=torch.int64))
+            simp, _ = ops.delaunay2d_batch(torch.from_numpy(P), torch.tensor([0, len(P)], dtype=torch.int64), compact=True)
             want = weightmap_ref.image_weight_map2_raster(lab.astype(np.float32), 10., 5.,
                                                           vertices=simp.numpy()[:, 1:].reshape(-1, 3, 2))[0][..., 0].astype(np.float32)
         assert np.abs(got - want).max() <= 1e-6, method
