@@ -889,7 +889,7 @@ def main_weightmap2(args):
         return (time.perf_counter() - t) / reps, r
     t_pts, idx = clock(lambda: torch.nonzero(sq_ops.wm2_boundary_points(img)))
     counts = torch.bincount(idx[:, 0], minlength=nb).cpu()
-    t_d2h, xy = clock(lambda: idx[:, 1:].to(torch.int32).cpu())
+    t_d2h, xy = clock(lambda: idx[:, 1:].to(torch.int32).contiguous().cpu())   # nonzero's (P,3) result is column-major
     offsets = torch.zeros(nb + 1, dtype=torch.int64)
     offsets[1:] = torch.cumsum(counts, 0)
     t_tri, (simp, lng) = clock(lambda: sq_ops.delaunay2d_batch(xy, offsets))

@@ -141,14 +141,18 @@ def device_weightmaps2(labels, w0=10., sigma=5., device=None, dtype=None, triang
             lab = lab[..., 0]
         img = (lab > 0).to(torch.float32).contiguous()
         N = img.shape[0]
-        idx = torch.nonzero(ops.wm2_boundary_points(img)).to(torch.int32).cpu()   # (P,3) [tile, row, column], scan order
-        counts = np.bincount(idx[:, 0].numpy(), minlength=N)
+        # (P,3) [tile, row, column] in scan order.  torch.nonzero hands back a COLUMN-major (P,3) tensor: the (row, column) pairs
+        # are made contiguous on the device (a 0.8 MB copy there; 0.32 ms per call when it was left to the host) and the per-tile
+        # counts are taken there too
+        nz = torch.nonzero(ops.wm2_boundary_points(img))
+        counts = torch.bincount(nz[:, 0], minlength=N).cpu().numpy()
+        xy = nz[:, 1:].to(torch.int32).contiguous().cpu()
         offsets = torch.zeros(N + 1, dtype=torch.int64)
         offsets[1:] = torch.from_numpy(np.cumsum(counts))
         if int(counts.min()) < 3:
             raise ValueError('ImageWeightMap2 needs at least three boundary points per tile (tile %d has %d): the '
                              'reference\'s Delaunay call fails there too' % (int(counts.argmin()), int(counts.min())))
-        simp, lng = ops.delaunay2d_batch(idx[:, 1:].contiguous(), offsets)
+        simp, lng = ops.delaunay2d_batch(xy, offsets)
         simp_d, lng_d = simp.to(dev, non_blocking=True), lng.to(dev, non_blocking=True)
         w = ops.weightmap_delaunay(img, simp_d, lng_d, w0, sigma, dtype=dtype or torch.float32)
         torch.cuda.current_stream(dev).synchronize()            # the pinned staging buffer is reused by the next call
