@@ -1231,8 +1231,10 @@ def gan_line(args, world, rank, dist, dev):
                "data": "synthetic",
                "config": {"workload": "progressive WGAN-GP level 6 (256x256x2), filters "
                                       "[512,256,128,64,32,16,8], batch 32 per GPU, alpha 1; " +
-                                      ("f32 tensors, bf16-multiply / f32-accumulate convolutions"
-                                       if args.dtype == "bf16" else "fp32") +
+                                      {"bf16": "bf16 feature maps and feature-map gradients in HBM, bf16-multiply / f32-accumulate "
+                                               "convolutions, f32 parameters / images / losses",
+                                       "mixed": "f32 tensors, bf16-multiply / f32-accumulate convolutions",
+                                       "f32": "fp32"}[args.dtype] +
                                       ("; hipGraph replay" if args.graph else "; eager launches"),
                           "d_loss": g.last_losses[0], "g_loss": g.last_losses[1]},
                "roofline": rl}
