@@ -359,3 +359,34 @@ def test_conv_with_average_pool_epilogue(N, H, W, Cin, Cout):
         assert torch.equal(u, v)
     for u, v in zip(s1, s2):
         assert (u is None) == (v is None) and (u is None or torch.equal(u, v))
+
+
+@pytest.mark.parametrize("batch_d", [True, False])
+def test_parameter_gradients_through_sinks_equal_the_autograd_sums(batch_d, monkeypatch):
+    """GenerativeAdverserialNetwork._param_grads (dtype 'bf16'): weight gradients queued into per-parameter sinks and run as
+    grouped launches (first contribution writes, later ones accumulate) against the same step with the queue switched off --
+    every contribution returned through autograd and summed by the framework.  batch_d=False: D(Gz), D(X) and D(mix) are
+    three separate passes, so a discriminator weight receives up to four contributions.  Same products; the sums are grouped
+    differently (blocks per layer, order of the contributions): equal to f32 rounding."""
+    from sequitr_amd import ops_bf16 as ob
+    from tests.test_gpu_gan import make_gan, dev
+    rng = np.random.default_rng(8)
+    z = dev(rng.standard_normal((4, 1, 1, 512)).astype(np.float32))
+    x = dev(rng.standard_normal((4, 16, 16, 2)).astype(np.float32))
+    r = dev(rng.random(4).astype(np.float32))
+
+    def grads(group):
+        monkeypatch.setattr(ob, "WGRAD_GROUP_MAX_ELEMS", (1 << 31) if group else 0)
+        g = make_gan(dtype="bf16", batch_d=batch_d)
+        g.set_level(2)
+        with g.precision(), F.fuse_act_gates(True):
+            d_vars, gd, _ = g._d_grads(x, z, 0.7, r)
+            g_vars, gg, _ = g._g_grads(x, z, 0.7)
+        return [n for n, _ in d_vars + g_vars], [None if t is None else t.detach().clone() for t in list(gd) + list(gg)]
+    names, a = grads(True)
+    _, b = grads(False)
+    assert sum(t is not None for t in a) == sum(t is not None for t in b) >= 20
+    for n, u, v in zip(names, a, b):
+        assert (u is None) == (v is None), n
+        if u is not None:
+            assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 1e-7, n
