@@ -216,13 +216,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const int li = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.y * BN;
     const int vb = (int)sq_xcd_remap(blockIdx.x, gridDim.x);
-    const int t_begin = vb * tiles_per_block;
-    const int t_end = min(t_begin + tiles_per_block, ntiles);
-    if (t_begin >= t_end) return;
+    // tiles_per_block < 0: block b walks tiles b, b + G, b + 2G, ... (the G tiles in flight are a contiguous run of the image)
+    const bool il = tiles_per_block < 0;
+    const int tstride = il ? (int)gridDim.x : 1;
+    const int t_begin = il ? vb : vb * tiles_per_block;
+    const int t_count = il ? (ntiles - vb + tstride - 1) / tstride : min(tiles_per_block, ntiles - t_begin);
+    if (t_begin >= ntiles || t_count <= 0) return;
     const int nchunk_all = Cin / KC;
     const int nchunk = SK ? drop.sk_chunks : nchunk_all;        // chunks this block reduces over ...
     const int chunk0 = SK ? (int)blockIdx.z * drop.sk_chunks : 0;   // ... starting here
-    const int nitems = (t_end - t_begin) * nchunk;
+    const int nitems = t_count * nchunk;
     const bool restage_w = nchunk > 1;
 
     const size_t io_pixels = MOS ? (size_t)drop.mos_n * drop.mos_h * drop.mos_w : (size_t)N * H * W;   // pixels behind x / y
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     // as well.  Measured per form at level 0 (r02t16 / r02t17): pool form 78 -> 69 us, junction form 124 -> 118 us, plain and
     // mask-out forms 62 -> 66 us (their short epilogues gain nothing and the request now queues behind the stores).
     constexpr bool EARLY = SQ_CONV_EARLY_ISSUE == 1 || (SQ_CONV_EARLY_ISSUE == 2 && (PL || JN));
-    auto step = [&](int &t, int &c) { if (++c == nchunk) { c = 0; ++t; } };
+    auto step = [&](int &t, int &c) { if (++c == nchunk) { c = 0; t += tstride; } };
     if (EARLY && nitems > 1) {
         int t1 = t_begin, c1 = 0;
         step(t1, c1);
@@ -796,8 +799,9 @@ int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int
     if (tpb < 1) tpb = 1;
     const int gx = (ntiles + tpb - 1) / tpb;
     const int gz = FORM == FORM_SK ? (Cin / KC) / drop.sk_chunks : 1;
+    static const int il = [] { const char *e = getenv("SQ_CONV_BF16_INTERLEAVE"); return e ? atoi(e) : 1; }();   // 0: contiguous tile runs (A/B switch)
     hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), C::LDS_BYTES, st, x, wp, bias, y, N, H, W, Cin, Cout, act,
-                       tiles_x, tiles_y, ntiles, tpb, gate, drop);
+                       tiles_x, tiles_y, ntiles, (il && !MOS) ? -tpb : tpb, gate, drop);
     return sq_check_launch("sq_conv2d_nhwc_fwd_bf16");
 }
 

@@ -93,7 +93,7 @@ struct SqMos {
 template <int KS, int NI, int NO, int PF, typename TIO, bool MOS, bool RAG>
 __device__ __forceinline__ void conv_wgrad_bf16_body(
     const TIO *__restrict__ x, const TIO *__restrict__ dy, float *__restrict__ partials, int N, int H,
-    int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block, const SqMos &mos, int bx, int by, int gy) {
+    int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block, const SqMos &mos, int bx, int by, int gy, int gxl) {
     using C = WB<KS, NI, NO>;
     constexpr int PAD = KS / 2;
     constexpr int ES = (int)sizeof(TIO), XV = ES == 4 ? 2 : 1;  // 16-byte loads per 8-channel LDS item
@@ -103,7 +103,12 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(
     const int li = lane & 15, kg = lane >> 4, q = li >> 2, p = li & 3;
     const int nco = (Cout + C::CO - 1) / C::CO;
     const int ci0 = (by / nco) * C::CI, co0 = (by % nco) * C::CO;
-    const int t_begin = bx * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
+    // tiles_per_block < 0: block bx of the layer's gxl tile-range blocks takes tiles bx, bx + gxl, ... -- the tiles in flight
+    // at any moment are a contiguous run of the image (DRAM pages, shared halos), as in conv_mfma_bf16_kernel
+    const bool il = tiles_per_block < 0;
+    const int ts = il ? gxl : 1;
+    const int t_begin = il ? bx : bx * tiles_per_block;
+    const int cnt = il ? (ntiles - bx + ts - 1) / ts : min(tiles_per_block, ntiles - t_begin);
 
     const size_t io_pixels = MOS ? (size_t)mos.n * mos.h * mos.w : (size_t)N * H * W;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -227,19 +232,19 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(
     const unsigned char *xa = xs + ((4 * wv) * C::HALO_W + lane_hx) * PSB + p * 8;
 
     // an out-of-range tile index loads nothing (every lane's offset is out of bounds) and is never committed
-    auto issue_if = [&](int tile, uint4 (&xr_)[C::XSLOTS][XV], uint4 (&yr_)[C::YSLOTS][XV]) {
-        if (tile < t_end) issue(tile, xr_, yr_);
+    auto issue_if = [&](int k, uint4 (&xr_)[C::XSLOTS][XV], uint4 (&yr_)[C::YSLOTS][XV]) {
+        if (k < cnt) issue(t_begin + k * ts, xr_, yr_);
     };
 #pragma unroll
-    for (int u = 0; u < PF; ++u) issue_if(t_begin + u, xr[u], yr[u]);
-    if (t_begin < t_end) commit(xr[0], yr[0]);
+    for (int u = 0; u < PF; ++u) issue_if(u, xr[u], yr[u]);
+    if (cnt > 0) commit(xr[0], yr[0]);
     __syncthreads();
-    for (int base = t_begin; base < t_end; base += PF) {
+    for (int base = 0; base < cnt; base += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int tile = base + u;
-            if (tile >= t_end) break;
-            issue_if(tile + PF, xr[u], yr[u]);                 // set u was committed before this tile's compute
+            const int k = base + u;
+            if (k >= cnt) break;
+            issue_if(k + PF, xr[u], yr[u]);                    // set u was committed before this tile's compute
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const unsigned char *yk = yb + (2 * ks) * TW * PSB;
@@ -277,7 +282,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(
                 }
             }
             __syncthreads();
-            if (tile + 1 < t_end) {
+            if (k + 1 < cnt) {
                 // (a second LDS buffer with one barrier per tile was measured: slower on the 16-channel and 1x1 shapes,
                 // within 3 % on the deep 3x3 ones -- the barriers are not what this loop waits for)
                 commit(xr[(u + 1) % PF], yr[(u + 1) % PF]);
@@ -323,7 +328,8 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
     const TIO *__restrict__ x, const TIO *__restrict__ dy, float *__restrict__ partials, int N, int H,
     int W, int Cin, int Cout, int tiles_x, int tiles_y, int ntiles, int tiles_per_block, SqMos mos) {
     conv_wgrad_bf16_body<KS, NI, NO, PF, TIO, MOS, RAG>(x, dy, partials, N, H, W, Cin, Cout, tiles_x, tiles_y, ntiles,
-                                                        tiles_per_block, mos, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+                                                        tiles_per_block, mos, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y,
+                                                        (int)gridDim.x);
 }
 
 // Several layers' weight gradients in ONE launch: the deep layers of a training step are 13 launches of ~37 us each for
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(256, (wgrad_occ<KS, NI, NO>())) void conv_wgrad_bf1
     conv_wgrad_bf16_body<KS, NI, NO, PF, TIO, MOS, RAG>(
         reinterpret_cast<const TIO *>(g.x[e]), reinterpret_cast<const TIO *>(g.dy[e]), g.partials[e], g.N[e], g.H[e], g.W[e],
         g.Cin[e], g.Cout[e], g.tiles_x[e], g.tiles_y[e], g.tiles_x[e] * g.tiles_y[e] * g.N[e], g.tpb[e], g.mos[e], local % gx,
-        local / gx, gy);
+        local / gx, gy, gx);
 }
 
 // factor the finish kernel applies to dW (not db): set by the *_scaled_* entry points around their dispatch, 1 otherwise
@@ -461,6 +467,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_finish_group_kernel(const
                                             g.ct[e], (int)blockIdx.x - g.first[e], red, g.acc[e]);
 }
 
+inline bool wgrad_interleave() {                                // SQ_WGRAD_INTERLEAVE=0: contiguous tile runs per block (A/B switch)
+    static const bool v = [] { const char *e = getenv("SQ_WGRAD_INTERLEAVE"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 template <int KS, int NI, int NO>
 void plan(int N, int H, int W, int Cin, int Cout, int *gx, int *tpb, int64_t *ws_floats) {
     using C = WB<KS, NI, NO>;
@@ -509,7 +520,7 @@ int launch_mos(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int npairs = (Cin / C::CI) * (Cout / C::CO);
     hipLaunchKernelGGL(kern, dim3(gx, npairs), dim3(256), C::LDS_BYTES, st, x, dy, ws, N, H, W, Cin, Cout, tiles_x, tiles_y,
-                       tiles_x * tiles_y * N, tpb, t_mos);
+                       tiles_x * tiles_y * N, wgrad_interleave() ? -tpb : tpb, t_mos);
     int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_mixed_mosaic_f32");
     if (rc) return rc;
     return finish<KS, NI, NO>(ws, dw, db, gx, Cin, Cout, st);
@@ -542,7 +553,7 @@ int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, 
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int npairs = (Cin / C::CI) * (Cout / C::CO);
     hipLaunchKernelGGL(kern, dim3(gx, npairs), dim3(256), C::LDS_BYTES, st, x, dy, ws, N, H, W, Cin, Cout, tiles_x,
-                       tiles_y, tiles_x * tiles_y * N, tpb, SqMos{});
+                       tiles_y, tiles_x * tiles_y * N, wgrad_interleave() ? -tpb : tpb, SqMos{});
     int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_bf16");
     if (rc) return rc;
     return finish<KS, NI, NO>(ws, dw, db, gx, Cin, Cout, st);
@@ -571,7 +582,7 @@ int launch_rag(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int npairs = ((Cin + 15) / 16) * ((Cout + 15) / 16);
     hipLaunchKernelGGL(kern, dim3(gx, npairs), dim3(256), C::LDS_BYTES, st, x, dy, ws, N, H, W, Cin, Cout, tiles_x, tiles_y,
-                       tiles_x * tiles_y * N, tpb, SqMos{});
+                       tiles_x * tiles_y * N, wgrad_interleave() ? -tpb : tpb, SqMos{});
     int rc = sq_check_launch("sq_conv2d_nhwc_wgrad_bf16(ragged)");
     if (rc) return rc;
     return finish<KS, 1, 1>(ws, dw, db, gx, Cin, Cout, st);
@@ -773,7 +784,7 @@ int launch_group(const sq_wgrad_item *const *items, int n, float *ws, hipStream_
             g.mos[e].mh = (65536u + (unsigned)it.H) / (unsigned)(it.H + 1);
             g.mos[e].mw = (65536u + (unsigned)it.W) / (unsigned)(it.W + 1);
         }
-        g.tpb[e] = tpb; g.gx[e] = gx;
+        g.tpb[e] = wgrad_interleave() ? -tpb : tpb; g.gx[e] = gx;
         blocks += gx * npairs;
         int G = sq_group_size(gx);
         if (G > 16) G = 16;
