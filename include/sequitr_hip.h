@@ -536,6 +536,13 @@ int sq_conv1x1_head_wce_fwd_bf16(const void *x, const float *w, const float *bia
 int sq_conv1x1_head_wce_bwd_bf16(const void *x, const float *w, const float *bias, const uint8_t *onehot,
                                  const float *weights, const float *dloss, void *dx, float *dw, float *db, float *workspace,
                                  int64_t npix, int Cin, int Cout, float gate_scale, void *stream);
+/* the backward pass that also leaves the LOSS (sq_conv1x1_head_wce_fwd_bf16's value, bit for bit) in `loss`: a training
+ * step that runs the backward right behind the forward skips the forward kernel and its read of the level-0 activation
+ * (the loss of unet.py:395-401's tensor contract is only a reported number there).  partials as in the forward. */
+int sq_conv1x1_head_wce_bwd_loss_bf16(const void *x, const float *w, const float *bias, const uint8_t *onehot,
+                                      const float *weights, const float *dloss, void *dx, float *dw, float *db,
+                                      float *workspace, double *partials, float *loss, int64_t npix, int Cin, int Cout,
+                                      float gate_scale, void *stream);
 
 /* weight gradient of the first (Cin -> Cout, Cin 1..7) 3x3 convolution from the f32 image and a bf16 dY:
  * dW (3,3,Cin,Cout) f32, db (Cout) f32 or NULL */

@@ -152,6 +152,7 @@ SIGNATURES = {
     "sq_conv1x1_head_bwd_gate_bf16": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_float, c_void_p]),
     "sq_conv1x1_head_wce_fwd_bf16": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]),
     "sq_conv1x1_head_wce_bwd_bf16": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, c_float, c_void_p]),
+    "sq_conv1x1_head_wce_bwd_loss_bf16": (c_int, [c_void_p] * 12 + [c_int64, c_int, c_int, c_float, c_void_p]),
     "sq_act_dropout_bwd_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_float, c_int, c_void_p]),
     "sq_conv2d_nhwc_dgrad_relu_bf16": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "sq_pixelnorm_fwd_bf16": (c_int, [c_void_p] * 2 + [c_int64, c_int, c_float, c_void_p]),

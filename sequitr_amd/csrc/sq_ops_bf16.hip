@@ -418,6 +418,7 @@ struct SqHeadCE {
     const float *wgt;
     const float *dloss;         // device scalar: the gradient arriving at the loss (backward only)
     float inv_npix;
+    double *lparts;             // backward only, may be NULL: the block's loss partial, as head_wce_fwd_bf16_kernel writes it
 };
 
 template <int COUT>
@@ -477,6 +478,7 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const __bf16 *__rest
                                                              SqHeadCE ce = SqHeadCE{}) {
     constexpr int NVAL = CIN * COUT + COUT;
     __shared__ float red[4][NVAL];
+    double tsum = 0.0;                                          // CE with lparts: this thread's pixels in head_wce_fwd's order
     float gw[CIN][COUT], gb[COUT];
 #pragma unroll
     for (int o = 0; o < COUT; ++o) gb[o] = 0.f;
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const __bf16 *__rest
                     yc[o] = (float)ce.yoh[p * COUT + o];
                 }
                 const float wp = ce.wgt[p];
-                sq_wce_pixel<COUT>(acc, yc, COUT, wp, wp * ce.inv_npix, g);
+                tsum += (double)sq_wce_pixel<COUT>(acc, yc, COUT, wp, wp * ce.inv_npix, g);
                 const float up = ce.dloss[0];
 #pragma unroll
                 for (int o = 0; o < COUT; ++o) g[o] = g[o] * up;
@@ -557,6 +559,18 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const __bf16 *__rest
     if ((int)threadIdx.x < NVAL)
         partials[(size_t)blockIdx.x * NVAL + threadIdx.x] =
             ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if constexpr (CE) {
+        if (ce.lparts) {                                        // the loss the forward pass did not compute: same tree, same bits
+            __shared__ double lred[256];
+            lred[threadIdx.x] = tsum;
+            __syncthreads();
+            for (int s = 128; s > 0; s >>= 1) {
+                if ((int)threadIdx.x < s) lred[threadIdx.x] += lred[threadIdx.x + s];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) ce.lparts[blockIdx.x] = lred[0];
+        }
+    }
 }
 __global__ __launch_bounds__(256) void head_finish2_kernel(const float *__restrict__ partials, float *__restrict__ dw,
                                                            float *__restrict__ db, int nblk, int nw, int nb, int G) {
@@ -817,7 +831,7 @@ extern "C" int sq_conv1x1_head_wce_fwd_bf16(const void *x, const float *w, const
     const int64_t nb64 = sq_wsoftmax_ce_partials(npix);
     const unsigned nb = (unsigned)nb64;
     hipStream_t st = SQ_ST(stream);
-    const SqHeadCE ce{bias, onehot, weights, nullptr, 0.f};
+    const SqHeadCE ce{bias, onehot, weights, nullptr, 0.f, nullptr};
     switch (Cout) {
     case 1: hipLaunchKernelGGL(head_wce_fwd_bf16_kernel<1>, dim3(nb), dim3(256), 0, st, BF(x), w, ce, partials, npix, Cin); break;
     case 2: hipLaunchKernelGGL(head_wce_fwd_bf16_kernel<2>, dim3(nb), dim3(256), 0, st, BF(x), w, ce, partials, npix, Cin); break;
@@ -838,6 +852,23 @@ extern "C" int sq_conv1x1_head_wce_bwd_bf16(const void *x, const float *w, const
                                             float *workspace, int64_t npix, int Cin, int Cout, float gate_scale,
                                             void *stream) {
     SQ_REQUIRE(onehot && weights && dloss, "sq_conv1x1_head_wce_bwd_bf16: null pointer");
-    const SqHeadCE ce{bias, onehot, weights, dloss, 1.0f / (float)npix};
+    const SqHeadCE ce{bias, onehot, weights, dloss, 1.0f / (float)npix, nullptr};
     return head_bwd_impl<true>(x, w, nullptr, dx, dw, db, workspace, npix, Cin, Cout, gate_scale, stream, ce);
+}
+
+// the same backward pass that ALSO leaves the loss (sq_conv1x1_head_wce_fwd_bf16's value, bit for bit: same grid, same
+// per-thread pixel order, same fp64 tree): a training step that always runs the backward right after the forward skips the
+// forward kernel -- one read of the level-0 activation less.  partials: sq_wsoftmax_ce_partials(npix) doubles.
+extern "C" int sq_conv1x1_head_wce_bwd_loss_bf16(const void *x, const float *w, const float *bias, const uint8_t *onehot,
+                                                 const float *weights, const float *dloss, void *dx, float *dw, float *db,
+                                                 float *workspace, double *partials, float *loss, int64_t npix, int Cin,
+                                                 int Cout, float gate_scale, void *stream) {
+    SQ_REQUIRE(onehot && weights && dloss && partials && loss, "sq_conv1x1_head_wce_bwd_loss_bf16: null pointer");
+    SQ_REQUIRE(sq_wsoftmax_ce_partials(npix) == head_blocks(npix), "sq_conv1x1_head_wce_bwd_loss_bf16: grids differ");
+    const SqHeadCE ce{bias, onehot, weights, dloss, 1.0f / (float)npix, partials};
+    int rc = head_bwd_impl<true>(x, w, nullptr, dx, dw, db, workspace, npix, Cin, Cout, gate_scale, stream, ce);
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_wce_finish_kernel, dim3(1), dim3(256), 0, SQ_ST(stream), partials, head_blocks(npix),
+                       1.0 / (double)npix, loss);
+    return sq_check_launch("sq_conv1x1_head_wce_bwd_loss_bf16(finish)");
 }

@@ -2,6 +2,8 @@
 weights / biases / gradients-of-weights.  First order only (the U-Net training graph); torch.autograd
 is the tape, every forward and gradient is a HIP kernel of ops_bf16.py."""
 import numpy as np
+import contextlib
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -417,16 +419,39 @@ def conv1x1_head(x, w, bias=None, x_single_use=False):
     return _Head.apply(x, w, bias, _gate_of(x) if x_single_use else None)
 
 
+_DEFER_LOSS = [False]
+
+
+@contextlib.contextmanager
+def deferred_loss(on=True):
+    """Inside: conv1x1_head_loss() returns an UNINITIALISED loss tensor that its backward fills in (the forward kernel's
+    value, bit for bit) -- for callers that run .backward() before they read the loss (UNetTrainer.forward_backward): the
+    forward kernel, one read of the level-0 activation, is not launched.  Without gradients (validation) nothing changes."""
+    prev = _DEFER_LOSS[0]
+    _DEFER_LOSS[0] = bool(on)
+    try:
+        yield
+    finally:
+        _DEFER_LOSS[0] = prev
+
+
 class _HeadLoss(torch.autograd.Function):
     """to_image + weighted softmax cross-entropy as one tape entry: the logits are recomputed from x in backward
     instead of being written, read by the loss, and their gradient written and read again (three kernels and two f32
     tensors less per step); same loss and same gradients, bit for bit, as _Head followed by F.weighted_softmax_cross_entropy."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, onehot, weights, gate):
+    def forward(ctx, x, w, bias, onehot, weights, gate, defer):
         ctx.gate = gate
         ctx.save_for_backward(x, w, bias, onehot, weights)
         ctx.sinks = (grad_sink(w), grad_sink(bias))
+        ctx.loss_out = None
+        if defer:
+            # deferred_loss(): the caller runs the backward before it looks at the loss -- the backward kernel recomputes
+            # the logits anyway and leaves the forward kernel's value in this tensor (until then it is uninitialised)
+            loss = torch.empty((), dtype=torch.float32, device=x.device)
+            ctx.loss_out = loss.detach()                        # an alias without the autograd node: no reference cycle
+            return loss
         return ob.head_wce_fwd(x, w, bias, onehot, weights)
 
     @staticmethod
@@ -436,13 +461,16 @@ class _HeadLoss(torch.autograd.Function):
         sw, sb = ctx.sinks
         gs = ctx.gate.take() if (ctx.gate is not None and ctx.needs_input_grad[0]) else 0.0
         dx, dw, db = ob.head_wce_bwd(x, w, bias, onehot, weights, dloss.contiguous(), want_dx=ctx.needs_input_grad[0],
-                                     dw_out=sw, db_out=sb if bias is not None else None, gate_scale=gs)
+                                     dw_out=sw, db_out=sb if bias is not None else None, gate_scale=gs,
+                                     loss_out=ctx.loss_out)
         return (dx, (None if sw is not None else dw), (db if bias is not None and sb is None else None), None, None,
-                None)
+                None, None)
 
 
 def conv1x1_head_loss(x, w, bias, onehot, weights, x_single_use=False):
-    return _HeadLoss.apply(x, w, bias, onehot, weights, _gate_of(x) if x_single_use else None)
+    # (grad mode is read HERE: inside Function.forward it is always off)
+    defer = _DEFER_LOSS[0] and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
+    return _HeadLoss.apply(x, w, bias, onehot, weights, _gate_of(x) if x_single_use else None, defer)
 
 
 class _BatchNormTrain(torch.autograd.Function):

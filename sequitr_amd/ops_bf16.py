@@ -578,8 +578,9 @@ def head_wce_fwd(x, w, bias, onehot, weights):
     return loss
 
 
-def head_wce_bwd(x, w, bias, onehot, weights, dloss, want_dx=True, dw_out=None, db_out=None, gate_scale=0.0):
-    """backward of head_wce_fwd from the 0-d f32 gradient arriving at the loss: (dx, dW, db)."""
+def head_wce_bwd(x, w, bias, onehot, weights, dloss, want_dx=True, dw_out=None, db_out=None, gate_scale=0.0, loss_out=None):
+    """backward of head_wce_fwd from the 0-d f32 gradient arriving at the loss: (dx, dW, db).  loss_out (0-d f32): the same
+    pass also writes the loss there -- the forward's value, bit for bit (a deferred loss, functional_bf16.deferred_loss)."""
     npix, Cin, Cout = _head_wce_check(x, w, onehot, weights)
     _chk(dloss, "dloss", dtype=torch.float32)
     lib = _lib.load()
@@ -587,6 +588,14 @@ def head_wce_bwd(x, w, bias, onehot, weights, dloss, want_dx=True, dw_out=None, 
     dx = torch.empty_like(x) if want_dx else None
     dw = _grad_out(dw_out, (1, 1, Cin, Cout), x.device)
     db = _grad_out(db_out, (Cout,), x.device)
+    if loss_out is not None:
+        _chk(loss_out, "loss_out", dtype=torch.float32)
+        parts = torch.empty(lib.sq_wsoftmax_ce_partials(npix), dtype=torch.float64, device=x.device)
+        _lib.check(lib.sq_conv1x1_head_wce_bwd_loss_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(onehot), _ptr(weights), _ptr(dloss),
+                                                        _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), _ptr(parts), _ptr(loss_out),
+                                                        npix, Cin, Cout, float(gate_scale), _stream()),
+                   "sq_conv1x1_head_wce_bwd_loss_bf16")
+        return dx, dw, db
     _lib.check(lib.sq_conv1x1_head_wce_bwd_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(onehot), _ptr(weights), _ptr(dloss),
                                                _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), npix, Cin, Cout, float(gate_scale),
                                                _stream()), "sq_conv1x1_head_wce_bwd_bf16")

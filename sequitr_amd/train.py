@@ -113,7 +113,9 @@ class UNetTrainer(object):
             if self.pack_plan is not None:
                 self.pack_plan.run()                            # every bf16 filter pack of the step, one launch
             if self.fuse_head_loss and hasattr(self.net, 'build_loss'):
-                loss = self.net.build_loss(x, onehot, weights)  # bf16 graph: head + loss as one tape entry
+                from . import functional_bf16 as FB
+                with FB.deferred_loss():                        # the backward below leaves the loss: no forward head kernel
+                    loss = self.net.build_loss(x, onehot, weights)  # bf16 graph: head + loss as one tape entry
             else:
                 loss = F.weighted_softmax_cross_entropy(self.net.build(x), onehot, weights)
             if self.pack_plan is not None:                      # the bf16 graph

@@ -437,6 +437,40 @@ def test_head_plus_loss_tape_entry_equals_head_then_loss(cfg):
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+@pytest.mark.parametrize("shape,C", [((2, 64, 64, 16), 2), ((3, 40, 24, 32), 3), ((4, 512, 512, 16), 2)])
+def test_deferred_loss_is_the_forward_kernels_loss(shape, C):
+    """functional_bf16.deferred_loss(): the loss the backward kernel leaves (sq_conv1x1_head_wce_bwd_loss_bf16) equals the
+    forward kernel's bit for bit -- also past 2048 blocks, where threads walk several pixels -- and so do the gradients,
+    with a non-unit gradient arriving at the loss; without gradients the forward kernel still runs."""
+    from sequitr_amd import functional_bf16 as FB
+    N, H, W, Cin = shape
+    rng = np.random.default_rng(9)
+    x = dev(tiles(61, N, H, W, Cin), torch.bfloat16)
+    w = dev(rand_weights(62, (1, 1, Cin, C), 0.3))
+    bias = dev(rng.standard_normal(C).astype(np.float32))
+    lab = rng.integers(0, C, (N, H, W))
+    onehot = dev((lab[..., None] == np.arange(C)).astype(np.uint8))
+    wmap = dev((1 + 4 * rng.random((N, H, W, 1))).astype(np.float32))
+    res = []
+    calls = []
+    real = ob.head_wce_fwd
+    for defer in (False, True):
+        xs, ws, bs = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        ob.head_wce_fwd = lambda *a, **k: (calls.append(defer), real(*a, **k))[1]
+        try:
+            with FB.deferred_loss(defer):
+                loss = FB.conv1x1_head_loss(xs, ws, bs, onehot, wmap)
+        finally:
+            ob.head_wce_fwd = real
+        (loss * 0.61).backward()
+        res.append((loss.detach().clone(), xs.grad, ws.grad, bs.grad))
+    assert calls == [False]                                     # the deferred form did not launch the forward kernel
+    for u, v in zip(res[0], res[1]):
+        assert torch.equal(u, v)
+    with torch.no_grad(), FB.deferred_loss():
+        assert torch.equal(FB.conv1x1_head_loss(x, w, bias, onehot, wmap), res[0][0])
+
+
 @pytest.mark.parametrize("shape", [(2, 12, 20, 64, 32), (1, 16, 16, 32, 16), (1, 8, 8, 256, 128)])
 def test_convT_wgrad_writes_the_transpose_conv_layouts(shape):
     """sq_convT2x2s2_wgrad_bf16 = the 1x1 wgrad of the space-to-depth form, with dW permuted to (2,2,Cout,Cin) and db
