@@ -486,6 +486,12 @@ int sq_conv2d_nhwc_fwd_dropout_bf16(const void *x, const void *wp, const float *
 int sq_conv2d_nhwc_fwd_dropout_pool_bf16(const void *x, const void *wp, const float *bias, void *y, void *ypool, int N, int H,
                                          int W, int Cin, int Cout, int K, int act, float rate, uint32_t seed,
                                          const int32_t *step_dev, void *stream);
+/* conv_block of down0 + max_pool_layer (unet.py:238-243, 265-277), training form, ONE launch for a single-channel f32 image
+ * and 16 filters: y1 = relu(conv3x3(x, w1) + b1) and its sign mask mask1 (sq_conv3x3_first_fwd_mask_bf16's outputs, bit for
+ * bit) are made per tile and never read back; y, ypool as sq_conv2d_nhwc_fwd_dropout_pool_bf16(y1, wp2, b2, relu). */
+int sq_conv3x3_first_block_dropout_pool_bf16(const float *x, const float *w1, const float *b1, void *y1, void *mask1,
+                                             const void *wp2, const float *b2, void *y, void *ypool, int N, int H, int W,
+                                             float rate, uint32_t seed, const int32_t *step_dev, void *stream);
 int sq_relu_scale_bwd_bf16(const void *dy, const void *y, void *dx, int64_t n, float scale, void *stream);
 /* dX of a convolution whose input was the ReLU output `gate` (same shape as dx): sq_conv2d_nhwc_fwd_bf16 of dy
  * with the transposed packed filter, passed only where gate > 0 (the upstream ReLU backward fused in) */

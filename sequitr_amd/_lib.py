@@ -143,6 +143,7 @@ SIGNATURES = {
     "sq_conv2d_nhwc_mixed_mosaic_f32": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "sq_conv2d_nhwc_dgrad_actgate_mixed_f32": (c_int, [c_void_p] * 3 + [c_int, c_void_p] + [c_int] * 6 + [c_void_p]),
     "sq_conv2d_nhwc_fwd_dropout_pool_bf16": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_float, ctypes.c_uint32, c_void_p, c_void_p]),
+    "sq_conv3x3_first_block_dropout_pool_bf16": (c_int, [c_void_p] * 9 + [c_int] * 3 + [c_float, ctypes.c_uint32, c_void_p, c_void_p]),
     "sq_relu_scale_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_float, c_void_p]),
     "sq_bridge_bwd_s2d_bf16": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "sq_maxpool2x2_bwd_add_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),

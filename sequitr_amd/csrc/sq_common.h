@@ -110,7 +110,16 @@ __device__ __forceinline__ float sq_wce_pixel(const float (&zc)[MAXC], const flo
 // partials g, g+G, ... in order, then an xor butterfly folds the group.
 __device__ __forceinline__ float sq_group_reduce(const float *__restrict__ p, size_t stride, int nblk, int g, int G) {
     float s = 0.f;
-    for (int b = g; b < nblk; b += G) s += p[(size_t)b * stride];
+    int b = g;
+    // eight loads in flight, added in the same order as one at a time (a lane's 32 partials were 32 serial round trips)
+    for (; b + 7 * G < nblk; b += 8 * G) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(b + u * G) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nblk; b += G) s += p[(size_t)b * stride];
     for (int m = G >> 1; m > 0; m >>= 1) s += __shfl_xor(s, m);
     return s;
 }

@@ -74,6 +74,12 @@ struct SqDropEpi {
     // sq_mosaic_pack_f32's layout) that is never materialised: loads, the gate and the stores address the compact
     // (mos_n, mos_h, mos_w, C) tensors directly, separator pixels read as zero and are not stored
     int mos_h = 0, mos_w = 0, mos_cc = 0, mos_n = 0;
+    // FORM_FP: the block input y1 = relu(conv3x3(f_x, f_w) + f_b) of the single-channel f32 image f_x (N,H,W,1) is evaluated in
+    // the block for the tile's 18 x 18 halo (conv_first_bf16_kernel's chain and rounding), written to LDS as the conv's input and,
+    // for the tile's own pixels, to f_y1 (N,H,W,16) with its sign mask f_mask -- the first conv of down0 never runs as a launch
+    const float *f_x = nullptr, *f_w = nullptr, *f_b = nullptr;
+    __bf16 *f_y1 = nullptr;
+    unsigned char *f_mask = nullptr;
     unsigned mos_mh = 0, mos_mw = 0;                            // ceil(2^16 / (h+1)), ceil(2^16 / (w+1)): q = (v * m) >> 16, exact for
 };                                                              // v < 2^13 at pitches <= 9 (set by the entry point)
 
@@ -196,7 +202,9 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
 //         roundings of the dgrad -> sq_act_bwd_bf16 pair it replaces
 //   7 SK: split-K partial sums (SqDropEpi::sk_ws): the small-image levels of the GAN are 4 - 8 mosaic tiles x Cout / 16 blocks,
 //         each walking all 16 channel chunks alone (one block per CU at best, 22 - 28 us of exposed round trips)
-enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4, FORM_GF = 5, FORM_GB = 6, FORM_SK = 7 };
+//   8 FP: FORM_PL whose input is made in the block from the single-channel image (SqDropEpi::f_*): conv_block of down0 with
+//         its max pool as ONE launch (16 channels)
+enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4, FORM_GF = 5, FORM_GB = 6, FORM_SK = 7, FORM_FP = 8 };
 template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN, bool MOS = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const TIO *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
@@ -204,13 +212,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     int ntiles, int tiles_per_block, const __bf16 *__restrict__ gate, SqDropEpi drop) {
     using C = CfgB<BN, KS, KC>;
     constexpr int NR = BN / 16, PAD = KS / 2;
-    constexpr bool JN = FORM == FORM_JN, PL = FORM == FORM_PL, MK = FORM == FORM_MK, MG = FORM == FORM_MG;
+    constexpr bool FP = FORM == FORM_FP;
+    static_assert(!FP || (BN == 16 && KS == 3 && KC == 16 && sizeof(TIO) == 2 && !MOS), "FORM_FP is the 16-channel level-0 block");
+    constexpr bool JN = FORM == FORM_JN, PL = FORM == FORM_PL || FP, MK = FORM == FORM_MK, MG = FORM == FORM_MG;
     constexpr bool GF = FORM == FORM_GF, GB = FORM == FORM_GB, SK = FORM == FORM_SK;
     constexpr bool F32IO = sizeof(TIO) == 4;                    // f32 activations in HBM, bf16 in LDS
     constexpr int ES = (int)sizeof(TIO), XV = F32IO ? 2 : 1;    // 16-byte loads per 8-channel LDS item
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *xs = smem;
     unsigned char *ws = smem + C::XS_BYTES;
+    float *xin = reinterpret_cast<float *>(smem + C::LDS_BYTES);   // FP: the tile's 20 x 20 image patch
+    constexpr int IN_W = TW + 4, IN_FLOATS = IN_W * IN_W;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
@@ -243,6 +255,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         drop.mask, 0, ((MK || MG) && drop.mask) ? (int)((size_t)N * H * W * Cout / 8) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
         drop.pool, 0, (PL && drop.pool) ? (int)((size_t)N * (H >> 1) * (W >> 1) * Cout * 2) : 0, 0x00020000);
+
+    const __amdgpu_buffer_rsrc_t firsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(drop.f_x), 0, FP ? (int)((size_t)N * H * W * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fyrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        drop.f_y1, 0, (FP && drop.f_y1) ? (int)((size_t)N * H * W * 16 * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fmrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        drop.f_mask, 0, (FP && drop.f_mask) ? (int)((size_t)N * H * W * 2) : 0, 0x00020000);
+    float inr[2];                                               // FP: 400 patch pixels over 256 threads
 
     // MOS: compact pixel index of mosaic pixel (gy, gx), or -1 for a separator / padding cell / outside
     auto mos_pixel = [&](int gy, int gx) {
@@ -277,8 +297,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW - PAD, y0 = ty * TH - PAD;
         const int base = (((n * H + y0) * W + x0) * Cin + chunk * KC) * ES;
+        if constexpr (FP) {                                     // the 20 x 20 image patch around the tile (halo of the halo)
 #pragma unroll
-        for (int sl = 0; sl < C::XSLOTS; ++sl) {
+            for (int sl = 0; sl < 2; ++sl) {
+                const int idx = tid + sl * 256;
+                const int py = idx / IN_W, px = idx % IN_W;
+                const bool inb = idx < IN_FLOATS && (unsigned)(y0 - 1 + py) < (unsigned)H && (unsigned)(x0 - 1 + px) < (unsigned)W;
+                inr[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    firsrc, inb ? (unsigned)(((n * H + y0 - 1 + py) * W + x0 - 1 + px) * 4) : OOB, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < (FP ? 0 : C::XSLOTS); ++sl) {
             bool inb;
             unsigned off;
             if constexpr (MOS) {
@@ -307,8 +337,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         }
     };
     auto commit = [&](bool want_w) {
+        if constexpr (FP) {
 #pragma unroll
-        for (int sl = 0; sl < C::XSLOTS; ++sl) {
+            for (int sl = 0; sl < 2; ++sl)
+                if (tid + sl * 256 < IN_FLOATS) xin[tid + sl * 256] = inr[sl];
+        }
+#pragma unroll
+        for (int sl = 0; sl < (FP ? 0 : C::XSLOTS); ++sl) {
             const int idx = tid + sl * 256;
             if (idx < C::XITEMS) {
                 uint4 item;
@@ -347,6 +382,60 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         if (tap > KS * KS - 1) tap = KS * KS - 1;                  // zero-weight padding step: any valid address
         toff[s] = ((tap / KS) * C::HALO_W + tap % KS) * C::PSB;
     }
+
+    // FP: conv1 (3x3, 1 -> 16, bias, ReLU, bf16) of the 18 x 18 halo on the matrix cores, as the f32 FIRST form does it
+    // (sq_conv_f32_v2.hip): the 9 taps are the reduction -- 3 steps of v_mfma_f32_16x16x4_f32, taps 9..11 with zero weights, so a
+    // value is exactly conv_first_bf16_kernel's chain "acc = 0; fmaf over the taps in raster order", then + bias, ReLU, one
+    // rounding.  21 column blocks of 16 halo pixels over the 4 waves.  Halo pixels outside the image are conv2's ZERO padding.
+    float a1[3] = {0.f, 0.f, 0.f};
+    int toff1[3] = {0, 0, 0};
+    float4 b1v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (FP) {
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int tap = 4 * s3 + kg;
+            a1[s3] = tap < 9 ? drop.f_w[tap * 16 + li] : 0.f;
+            const int tc = tap < 9 ? tap : 8;
+            toff1[s3] = (tc / 3) * IN_W + tc % 3;
+        }
+        if (drop.f_b) b1v = *reinterpret_cast<const float4 *>(drop.f_b + 4 * kg);
+    }
+    auto first_conv = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        constexpr int NBLK = (C::HP + 15) / 16;                 // 21 column blocks: 6 / 5 / 5 / 5 per wave, unrolled so that the
+#pragma unroll                                                  // independent chains of a wave overlap (a rolled loop ran them serially)
+        for (int u = 0; u < (NBLK + 3) / 4; ++u) {
+            const int blk = wv + 4 * u;
+            if (blk >= NBLK) break;
+            const int pix = blk * 16 + li;
+            const int pc = pix < C::HP ? pix : C::HP - 1;
+            const int py = pc / C::HALO_W, px = pc % C::HALO_W;
+            const float *src = xin + py * IN_W + px;
+            f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s3], src[toff1[s3]], c1, 0, 0, 0);
+            const int gy = ty * TH - 1 + py, gx = tx * TW - 1 + px;
+            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const float v[4] = {c1[0] + b1v.x, c1[1] + b1v.y, c1[2] + b1v.z, c1[3] + b1v.w};
+            bf16x4 o;
+            unsigned nib = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (__bf16)((inside && v[j] > 0.f) ? v[j] : 0.f);
+                nib |= ((float)o[j] > 0.f ? 1u : 0u) << j;
+            }
+            if (pix < C::HP) *reinterpret_cast<bf16x4 *>(xs + pix * C::PSB + 8 * kg) = o;
+            // the tile's own pixels also go to HBM (conv2's weight gradient reads y1) with their sign mask (conv2's dgrad gate)
+            const bool own = pix < C::HP && inside && py >= 1 && py <= TH && px >= 1 && px <= TW;
+            const unsigned p = (unsigned)((n * H + gy) * W + gx);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
+                __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, o), fyrsrc, own ? p * 32u + 8u * kg : OOB, 0, 0);
+            unsigned v16 = nib << (4 * kg);                     // the four kg lanes of a pixel: 16 channels, 16 bits
+            v16 |= (unsigned)__shfl_xor((int)v16, 16);
+            v16 |= (unsigned)__shfl_xor((int)v16, 32);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v16, fmrsrc, (own && kg == 0) ? p * 2u : OOB, 0, 0);
+        }
+    };
 
     f32x4 acc[4][NR];
 #pragma unroll
@@ -531,6 +620,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                 }
                 continue;
             }
+            // (16-byte stores through v_permlane16_swap_b32 row pairs -- guide T21 -- were built and measured: +1.8 % on the training step,
+            // +0.9 % on the GAN iteration; these epilogues are not bound by the number of store instructions.  Removed.)
             unsigned mbits[4];
             (void)mbits;
             if constexpr (MG) {
@@ -635,6 +726,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), stated outside commit()'s branches (see the main loop)
     commit(true);
     __syncthreads();
+    if constexpr (FP) {
+        first_conv(t_begin);
+        __syncthreads();
+    }
     int tile = t_begin, chunk = 0;
     // EARLY: the loads of the next item are requested as soon as the staging registers are free again -- right after the
     // commit, BEFORE the epilogue of the tile that just finished -- so a block has a tile in flight during its epilogue
@@ -684,6 +779,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
             int t2 = ntile, c2 = nchk;
             step(t2, c2);
             issue(t2, c2, restage_w);
+        }
+        if constexpr (FP) {
+            if (has_next) {
+                __syncthreads();                                // the image patch is complete
+                first_conv(ntile);
+            }
         }
         if (chunk == nchunk - 1) epilogue(tile);
         if (has_next) __syncthreads();
@@ -766,6 +867,9 @@ int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int
         if (drop.gate_slope) return launch<BN, KS, KC, TIO, FORM_GB>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
     }
     if constexpr (FORM == FORM_PLAIN && KS == 3 && sizeof(TIO) == 2) {
+        if constexpr (BN == 16 && KC == 16) {
+            if (drop.f_x) return launch<BN, KS, KC, TIO, FORM_FP>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+        }
         if (drop.j_g) return launch<BN, KS, KC, TIO, FORM_JN>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
         if (drop.pool) return launch<BN, KS, KC, TIO, FORM_PL>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
         if (drop.mask)
@@ -776,14 +880,15 @@ int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int
     static bool attr_set = false;
     static int occ = 2;                                         // resident blocks per CU (registers / LDS)
     auto kern = conv_mfma_bf16_kernel<BN, KS, KC, TIO, FORM, MOS>;
+    constexpr int LDS = C::LDS_BYTES + (FORM == FORM_FP ? (TW + 4) * (TW + 4) * 4 : 0);
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                C::LDS_BYTES) != hipSuccess) {
-            sq_set_error("conv_mfma_bf16: cannot reserve %d bytes of LDS", C::LDS_BYTES);
+                                LDS) != hipSuccess) {
+            sq_set_error("conv_mfma_bf16: cannot reserve %d bytes of LDS", LDS);
             return SQ_ELAUNCH;
         }
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, C::LDS_BYTES) ==
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, LDS) ==
                 hipSuccess && nb >= 1)
             occ = nb > 8 ? 8 : nb;
         attr_set = true;
@@ -800,7 +905,7 @@ int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int
     const int gx = (ntiles + tpb - 1) / tpb;
     const int gz = FORM == FORM_SK ? (Cin / KC) / drop.sk_chunks : 1;
     static const int il = [] { const char *e = getenv("SQ_CONV_BF16_INTERLEAVE"); return e ? atoi(e) : 1; }();   // 0: contiguous tile runs (A/B switch)
-    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), C::LDS_BYTES, st, x, wp, bias, y, N, H, W, Cin, Cout, act,
+    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), LDS, st, x, wp, bias, y, N, H, W, Cin, Cout, act,
                        tiles_x, tiles_y, ntiles, (il && !MOS) ? -tpb : tpb, gate, drop);
     return sq_check_launch("sq_conv2d_nhwc_fwd_bf16");
 }
@@ -1114,6 +1219,35 @@ extern "C" int sq_conv2d_nhwc_fwd_dropout_pool_bf16(const void *x, const void *w
     }
     d.pool = reinterpret_cast<__bf16 *>(ypool);
     return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, K, act, stream, nullptr, d);
+}
+
+// conv_block of down0 + max_pool_layer (sequitr/networks/unet.py:238-243, 265-277) for a single-channel f32 image and 16
+// filters, the training form, in ONE launch: y1 = relu(conv3x3(x, w1) + b1) (sq_conv3x3_first_fwd_mask_bf16's tensor and sign
+// mask, bit for bit: the weight gradient of conv2 and the gate of its dgrad need them) is evaluated per tile for the 18 x 18
+// halo and never read back from HBM; y = dropout(relu(conv3x3(y1, wp2) + b2)) and ypool as sq_conv2d_nhwc_fwd_dropout_pool_bf16.
+extern "C" int sq_conv3x3_first_block_dropout_pool_bf16(const float *x, const float *w1, const float *b1, void *y1, void *mask1,
+                                                        const void *wp2, const float *b2, void *y, void *ypool, int N, int H,
+                                                        int W, float rate, uint32_t seed, const int32_t *step_dev,
+                                                        void *stream) {
+    SQ_REQUIRE(x && w1 && y1 && mask1 && wp2 && y && ypool, "sq_conv3x3_first_block_dropout_pool_bf16: null tensor pointer");
+    SQ_REQUIRE(rate >= 0.f && rate < 1.f, "sq_conv3x3_first_block_dropout_pool_bf16: rate must be in [0, 1)");
+    SQ_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "sq_conv3x3_first_block_dropout_pool_bf16: even H and W");
+    SQ_REQUIRE_ALIGNED(w1); SQ_REQUIRE_ALIGNED(y1); SQ_REQUIRE_ALIGNED(ypool);
+    if (b1) SQ_REQUIRE_ALIGNED(b1);
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    if (rate > 0.f) {
+        d.thr = (unsigned)(rate * 65536.0f);
+        d.inv = 1.0f / (1.0f - rate);
+        d.seed = seed;
+        d.step = step_dev;
+        SQ_REQUIRE(d.thr != 0u, "sq_conv3x3_first_block_dropout_pool_bf16: rate too small for the 16-bit threshold");
+    }
+    d.pool = reinterpret_cast<__bf16 *>(ypool);
+    d.f_x = x; d.f_w = w1; d.f_b = b1;
+    d.f_y1 = reinterpret_cast<__bf16 *>(y1);
+    d.f_mask = reinterpret_cast<unsigned char *>(mask1);
+    // the kernel's `x` is y1: never read (the halo is made in the block), it only passes the pointer checks
+    return conv_fwd_bf16_impl(y1, wp2, b2, y, N, H, W, 16, 16, 3, SQ_ACT_RELU, stream, nullptr, d);
 }
 
 // weighted_conv2d followed by the discriminator's 2x2 average pool (gan.py:171-192) on bf16 tensors: y (N,H,W,Cout) = act(conv + bias)

@@ -133,6 +133,16 @@ class _ConvBlock(torch.autograd.Function):
         ctx.gate, ctx.junction = gate, junction
         f = w1.shape[3]
         m1 = None
+        pooling = poolbox is not None and mask is None and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+        if FUSE_FIRST and FUSE_MASK and first and pooling and ob.conv_first_block_takes(x, w1, w2):
+            # down0 with its pool in ONE launch: y1 is made per tile inside conv2's kernel (and stored for the weight gradient)
+            y1, m1, out, pooled = ob.conv_first_block_dropout_pool(x, w1, b1, ob.pack_weights(w2), b2, rate, seed=seed,
+                                                                   step_dev=step_dev)
+            poolbox.append(pooled)
+            ctx.rate, ctx.first = rate, first
+            ctx.sinks = (grad_sink(w1), grad_sink(b1), grad_sink(w2), grad_sink(b2))
+            ctx.save_for_backward(x, w1, w2, y1, out, None, m1)
+            return out
         if FUSE_MASK and f % 16 == 0:
             # conv1's ReLU sign mask (1 bit per element) leaves its epilogue: conv2's dgrad gates on it in the backward
             # instead of reading y1 again (y1 itself stays: it is conv2's wgrad operand)
@@ -203,6 +213,9 @@ class _ConvBlock(torch.autograd.Function):
 
 FUSE_POOL = __import__("os").environ.get("SQ_FUSE_POOL", "1") != "0"
 FUSE_MASK = __import__("os").environ.get("SQ_FUSE_MASK", "1") != "0"
+# down0 as ONE launch (sq_conv3x3_first_block_dropout_pool_bf16): bit-identical, measured 127 us against 48 + 65 us for the two
+# kernels (the per-tile conv1 phase sits on the block's critical path, which is one HBM round trip per tile) -- off by default
+FUSE_FIRST = __import__("os").environ.get("SQ_FUSE_FIRST", "0") != "0"
 
 
 def conv_block(x, w1, b1, w2, b2, rate=0.0, seed=0, mask=None, step_dev=None, pool_follows=False):

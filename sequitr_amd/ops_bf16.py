@@ -129,6 +129,27 @@ def conv2d_dropout_pool(x, wp, bias, K, Cout, act, rate, seed=0, step_dev=None):
     return y, yp
 
 
+def conv_first_block_takes(x, w1, w2):
+    """the one-launch first block: a single-channel f32 image, 16 filters, even H and W."""
+    return (x.dtype == torch.float32 and x.dim() == 4 and x.shape[3] == 1 and tuple(w1.shape) == (3, 3, 1, 16) and
+            tuple(w2.shape) == (3, 3, 16, 16) and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0)
+
+
+def conv_first_block_dropout_pool(x, w1, b1, wp2, b2, rate, seed=0, step_dev=None):
+    """(y1, mask1, y, maxpool2x2(y)): conv3x3_first_mask(x, w1, b1) followed by conv2d_dropout_pool(y1, wp2, b2, 3, 16, 'relu',
+    rate) as ONE kernel -- y1 is made per tile in the block and only written (for conv2's weight gradient), never re-read."""
+    _chk(x, "x", dtype=torch.float32, ndim=4), _chk(w1, "w1", dtype=torch.float32, ndim=4), _chk(wp2, "wp2")
+    N, H, W, _ = x.shape
+    y1 = torch.empty((N, H, W, 16), dtype=BF16, device=x.device)
+    m1 = sign_mask_like(y1)
+    y = torch.empty((N, H, W, 16), dtype=BF16, device=x.device)
+    yp = torch.empty((N, H // 2, W // 2, 16), dtype=BF16, device=x.device)
+    _lib.check(_lib.load().sq_conv3x3_first_block_dropout_pool_bf16(
+        _ptr(x), _ptr(w1), _ptr(b1), _ptr(y1), _ptr(m1), _ptr(wp2), _ptr(b2), _ptr(y), _ptr(yp), N, H, W, float(rate),
+        int(seed) & 0xFFFFFFFF, _ptr(step_dev), _stream()), "sq_conv3x3_first_block_dropout_pool_bf16")
+    return y1, m1, y, yp
+
+
 def relu_scale_bwd(dy, y, scale):
     """dx = y > 0 ? dy * scale : 0 -- backward of dropout(relu(.)) from its output alone."""
     _chk(dy, "dy"), _chk(y, "y")

@@ -437,6 +437,51 @@ def test_head_plus_loss_tape_entry_equals_head_then_loss(cfg):
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+@pytest.mark.parametrize("rate", [0.0, 0.4])
+@pytest.mark.parametrize("shape", [(2, 64, 64), (3, 40, 24), (1, 18, 50), (2, 512, 512)])
+def test_first_block_in_one_launch_equals_the_two_kernels(shape, rate):
+    """sq_conv3x3_first_block_dropout_pool_bf16 (down0's conv1 made per tile inside conv2's kernel) against
+    sq_conv3x3_first_fwd_mask_bf16 -> sq_conv2d_nhwc_fwd_dropout_pool_bf16: y1, its sign mask, the block output and the pooled
+    tensor, bit for bit -- ragged tiles and image borders included."""
+    N, H, W = shape
+    rng = np.random.default_rng(13)
+    x = dev(rng.standard_normal((N, H, W, 1)).astype(np.float32))
+    w1, b1 = dev(rand_weights(71, (3, 3, 1, 16), 0.5)), dev(rng.standard_normal(16).astype(np.float32) * 0.1)
+    w2, b2 = dev(rand_weights(72, (3, 3, 16, 16), 0.1)), dev(rng.standard_normal(16).astype(np.float32) * 0.1)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    y1r, m1r = ob.conv3x3_first_mask(x, w1, b1)
+    outr, poolr = ob.conv2d_dropout_pool(y1r, ob.pack_weights(w2), b2, 3, 16, 'relu', rate, seed=5, step_dev=step)
+    assert ob.conv_first_block_takes(x, w1, w2)
+    y1, m1, out, pool = ob.conv_first_block_dropout_pool(x, w1, b1, ob.pack_weights(w2), b2, rate, seed=5, step_dev=step)
+    assert torch.equal(y1, y1r) and torch.equal(m1, m1r)
+    assert torch.equal(out, outr) and torch.equal(pool, poolr)
+
+
+def test_first_block_fusion_gives_the_same_training_step(monkeypatch):
+    """functional_bf16.FUSE_FIRST on / off: same loss, same gradients, bit for bit."""
+    from sequitr_amd.train import UNetTrainer
+    from sequitr_amd import functional_bf16 as FB
+    base = {"shape": (64, 64), "dropout": 0.4, "device": "cuda:0", "seed": 5, "filters": (16, 32, 64), "dtype": "bf16"}
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2, 64, 64, 1)).astype(np.float32)
+    lab = rng.random((2, 64, 64)) < 0.4
+    onehot = np.stack([~lab, lab], -1).astype(np.uint8)
+    wmap = (1 + rng.random((2, 64, 64, 1))).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to("cuda:0")
+    out, calls = [], []
+    real = ob.conv_first_block_dropout_pool
+    monkeypatch.setattr(ob, "conv_first_block_dropout_pool", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    for fuse in (True, False):
+        monkeypatch.setattr(FB, "FUSE_FIRST", fuse)
+        t = UNetTrainer(dict(base))
+        loss = t.forward_backward(d(x), d(onehot), d(wmap))
+        out.append((loss.item(), t.grads()))
+    assert calls == [1]                                         # the fused form ran, once, in the first trainer only
+    assert out[0][0] == out[1][0]
+    for k in out[1][1]:
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k
+
+
 @pytest.mark.parametrize("shape,C", [((2, 64, 64, 16), 2), ((3, 40, 24, 32), 3), ((4, 512, 512, 16), 2)])
 def test_deferred_loss_is_the_forward_kernels_loss(shape, C):
     """functional_bf16.deferred_loss(): the loss the backward kernel leaves (sq_conv1x1_head_wce_bwd_loss_bf16) equals the
