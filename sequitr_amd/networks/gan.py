@@ -268,6 +268,7 @@ class GenerativeAdverserialNetwork(object):
         self._graphs = {}
         self._graph_alpha = {}                                  # last fade-in weight written into each graph's static tensor
         self._plan = None
+        self._pack_epoch = -1
         self._gflat, self._gsinks = None, None                  # flat gradient buffer + per-parameter sinks (dtype 'bf16')
         self._capture_stream = None
         self.dtype = params.get('dtype', 'f32')
@@ -381,28 +382,54 @@ class GenerativeAdverserialNetwork(object):
         self.__level = 0
         self.store.flatten()                                    # one contiguous parameter buffer (views keep their names)
         self._plan = None
+        self._pack_epoch = -1
         self.initialized = True
 
     def _pack_filters(self):
-        """dtype 'bf16': every bf16 filter pack of the solver step (forward + dgrad form of each equalised-LR conv
-        kernel) in one launch; the packs stay valid until the step's Adam update (ops.FilterPackPlan)."""
+        """dtype 'bf16' / 'mixed': the bf16 filter packs of a solver step (forward + dgrad form of each equalised-LR conv
+        kernel), one launch per NETWORK whose weights have moved since they were packed (ops.FilterPackPlan).  A solver step
+        updates one network: d_solver leaves the generator's packs valid and g_solver the discriminator's, so in the
+        alternating loop every weight is packed once per iteration, not once per step (2 x 73 us -> 2 x ~37 us at level 6).
+        Anybody else writing parameters (checkpoint load, assign, another optimiser) shows in ops.invalidation_epoch() and
+        stales both."""
         if self.dtype == 'f32' or self.store.flat is None:
             return
         if self._plan is None:
-            named = []
+            named = {'d': [], 'g': []}
             for name, v in self.store.vars.items():
-                if name.endswith('/filter') and v.dim() == 4 and name in self.store.offsets:
-                    kh, kw, _, cout = v.shape
-                    named.append((name, v, self.store.offsets[name], float(np.sqrt(np.float32(2.0 / float(kh * kw * cout))))))
-                elif name.endswith('/kernel') and v.dim() == 2 and name in self.store.offsets:
-                    # dense layers that run as bf16-multiply 1x1 convs -- forward where the reduction is short (the generator's
-                    # 512 -> 8192 dense1; >= 1024 inputs take the split-reduction f32 kernel), dgrad where the OUTPUT side is
-                    # short (the discriminator's 8208 -> 512 dense): packed with everything else instead of once per use
-                    forms = ('N' if v.shape[0] < 1024 else '') + ('T' if v.shape[1] < 1024 else '')
-                    if forms:
-                        named.append((name, v, self.store.offsets[name], 1.0, forms))
-            self._plan = ops.FilterPackPlan(self.store.flat, named)
-        self._plan.run()
+                which = 'd' if name.startswith('GAN/discriminator/') else 'g'
+                self._pack_named(named[which], name, v)
+            self._plan = {k: ops.FilterPackPlan(self.store.flat, named[k]) for k in ('d', 'g')}
+            self._pack_ok = {'d': False, 'g': False}
+        if ops.invalidation_epoch() != self._pack_epoch:
+            self._pack_ok = {'d': False, 'g': False}
+        for k in ('d', 'g'):
+            if self._pack_ok[k]:
+                self._plan[k].fresh = True                      # its weights have not moved since it was packed
+            else:
+                self._plan[k].run()
+                self._pack_ok[k] = True
+        self._pack_epoch = ops.invalidation_epoch()
+
+    def _weights_moved(self, kind):
+        """the end of a solver step: `kind`'s weights were updated -- every cached pack goes, the OTHER network's plan
+        comes back on the next _pack_filters()"""
+        ops.invalidate_packs()
+        if self._plan is not None:
+            self._pack_ok[kind] = False
+            self._pack_epoch = ops.invalidation_epoch()
+
+    def _pack_named(self, named, name, v):
+        if name.endswith('/filter') and v.dim() == 4 and name in self.store.offsets:
+            kh, kw, _, cout = v.shape
+            named.append((name, v, self.store.offsets[name], float(np.sqrt(np.float32(2.0 / float(kh * kw * cout))))))
+        elif name.endswith('/kernel') and v.dim() == 2 and name in self.store.offsets:
+            # dense layers that run as bf16-multiply 1x1 convs -- forward where the reduction is short (the generator's
+            # 512 -> 8192 dense1; >= 1024 inputs take the split-reduction f32 kernel), dgrad where the OUTPUT side is
+            # short (the discriminator's 8208 -> 512 dense): packed with everything else instead of once per use
+            forms = ('N' if v.shape[0] < 1024 else '') + ('T' if v.shape[1] < 1024 else '')
+            if forms:
+                named.append((name, v, self.store.offsets[name], 1.0, forms))
 
     def _build_optimizers(self, level=0):
         return _Adam(self.learning_rate, 0.0, 0.99), _Adam(self.learning_rate, 0.0, 0.99)
@@ -496,7 +523,7 @@ class GenerativeAdverserialNetwork(object):
                     return self._solver_graphed('d', X, Z, alpha)
                 return self._d_solver(X, Z, alpha, r)
         finally:
-            ops.invalidate_packs()      # the step ends with a weight update, also under an outer precision() block
+            self._weights_moved('d')    # the step ends with a weight update, also under an outer precision() block
 
     def g_solver(self, X, Z, alpha):
         """g_opt.minimize(g_loss, var_list=g_vars, global_step) for the current level (gan.py:650-651)."""
@@ -506,7 +533,7 @@ class GenerativeAdverserialNetwork(object):
                     return self._solver_graphed('g', X, Z, alpha)
                 return self._g_solver(X, Z, alpha)
         finally:
-            ops.invalidate_packs()
+            self._weights_moved('g')
 
     # -- parameter gradients through sinks (bf16 storage): grouped weight-gradient launches, no framework adds -------------
     def _param_grads(self, loss, named):
@@ -535,14 +562,12 @@ class GenerativeAdverserialNetwork(object):
 
     # the two halves of a solver step: (losses + gradients) and (Adam); the all-reduce sits between them
     def _d_grads(self, X, Z, alpha, r):
-        self._pack_filters()
         d_vars, _ = self.get_training_variables(self.current_level)
         _, d_loss, g_loss = self._build_network(X, Z, alpha, r=r, need_g_graph=False)
         grads = self._param_grads(d_loss, d_vars)               # not the block d_vars leaves out
         return d_vars, grads, (d_loss.detach(), g_loss.detach())
 
     def _g_grads(self, X, Z, alpha):
-        self._pack_filters()
         _, g_vars = self.get_training_variables(self.current_level)
         d_filters, _, Gz, _ = self._prepare(X, Z, alpha, need_g_graph=True)
         _, Dz = self.discriminator(Gz, d_filters)
@@ -551,6 +576,7 @@ class GenerativeAdverserialNetwork(object):
         return g_vars, grads, (g_loss.detach(),)
 
     def _d_solver(self, X, Z, alpha, r=None):
+        self._pack_filters()
         d_vars, grads, losses = self._d_grads(X, Z, alpha, r)
         scale = self._allreduce(grads)
         self.d_opt.apply(d_vars, grads, grad_scale=scale)
@@ -558,6 +584,7 @@ class GenerativeAdverserialNetwork(object):
         return losses[0]
 
     def _g_solver(self, X, Z, alpha):
+        self._pack_filters()
         g_vars, grads, losses = self._g_grads(X, Z, alpha)
         scale = self._allreduce(grads)
         self.g_opt.apply(g_vars, grads, grad_scale=scale)
@@ -588,6 +615,7 @@ class GenerativeAdverserialNetwork(object):
             sr = torch.empty((X.shape[0],), dtype=torch.float32, device=self.device) if kind == 'd' else None
             if self._capture_stream is None:
                 self._capture_stream = torch.cuda.Stream(device=self.device)
+            self._pack_filters()                                # the packs are launched in FRONT of the graph, by staleness (below)
             torch.cuda.synchronize(self.device)
             g_grad, g_adam = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_grad, stream=self._capture_stream):
@@ -606,6 +634,7 @@ class GenerativeAdverserialNetwork(object):
             self._graph_alpha[key] = float(alpha)
         if sr is not None:
             sr.copy_(self._mixing_r(X.shape[0]))
+        self._pack_filters()                                    # whichever network's weights moved since its packs were made
         g_grad.replay()
         self._allreduce(grads)
         g_adam.replay()

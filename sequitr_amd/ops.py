@@ -137,12 +137,23 @@ _PACKS = {}
 _PLANS = __import__('weakref').WeakSet()     # live FilterPackPlans: their packs go stale with every weight update too
 
 
+_INVALIDATIONS = [0]
+
+
 def invalidate_packs():
     """drop every cached bf16 filter pack (call after anything that writes parameters in place)"""
     _PACKS.clear()
     _TRANSFORMS.clear()
+    _INVALIDATIONS[0] += 1
     for p in list(_PLANS):
         p.fresh = False
+
+
+def invalidation_epoch():
+    """number of invalidate_packs() calls so far: an owner of several FilterPackPlans that knows WHICH weights its own steps
+    move (the GAN: a solver step updates one network) compares it with the value it saw last to learn whether anybody else
+    wrote parameters in between"""
+    return _INVALIDATIONS[0]
 
 
 class FilterPackPlan(object):

@@ -361,6 +361,52 @@ def test_conv_with_average_pool_epilogue(N, H, W, Cin, Cout):
         assert (u is None) == (v is None) and (u is None or torch.equal(u, v))
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_filter_packs_follow_the_network_whose_weights_moved(graph):
+    """GenerativeAdverserialNetwork._pack_filters: d_solver leaves the generator's packs valid, g_solver the discriminator's
+    (one pack launch per network and iteration in the alternating loop) -- against a twin that repacks everything before every
+    step: same weights, bit for bit, after D, G, D, D, G, an outside write to a generator weight, G, D; and the launch
+    counts: 2 packs on the first step, then exactly one per step while the steps alternate."""
+    from tests.test_gpu_gan import make_gan, dev
+    rng = np.random.default_rng(21)
+    zs = [dev(rng.standard_normal((4, 1, 1, 512)).astype(np.float32)) for _ in range(8)]
+    xs = [dev(rng.standard_normal((4, 16, 16, 2)).astype(np.float32)) for _ in range(8)]
+    rs = [dev(rng.random(4).astype(np.float32)) for _ in range(8)]
+    out = []
+    for lazy in (True, False):
+        g = make_gan(dtype="bf16", graph=graph)
+        g.set_level(2)
+        g._torch_rng.manual_seed(3)
+        runs = []
+        real = ops.FilterPackPlan.run
+
+        def counted(plan, _runs=runs):
+            _runs.append(1)
+            return real(plan)
+        ops.FilterPackPlan.run = counted
+        try:
+            per_step = []
+            for i, kind in enumerate("dgddg" + "gd"):
+                if i == 5:                                      # somebody else writes a generator weight
+                    name = "GAN/generator/layer_0/conv1/filter"
+                    g.store.load_state_dict({name: (g.store.vars[name].detach() * 1.01).cpu().numpy()})
+                if not lazy:
+                    g._pack_epoch = -1                          # the twin: everything is stale before every step
+                n0 = len(runs)
+                (g.d_solver(xs[i], zs[i], 1.0) if kind == 'd' else g.g_solver(xs[i], zs[i], 1.0))
+                per_step.append(len(runs) - n0)
+        finally:
+            ops.FilterPackPlan.run = real
+        torch.cuda.synchronize()
+        out.append(({k: v.detach().clone() for k, v in g.store.vars.items()}, per_step))
+    if not graph:
+        #        D  G  D  D  G | write | G  D     (D after D: its own weights moved; G after the outside write: both)
+        assert out[0][1] == [2, 1, 1, 1, 1, 2, 1], out[0][1]
+        assert out[1][1] == [2] * 7                             # (a capture step packs again after its recorded Adam)
+    for k in out[1][0]:
+        assert torch.equal(out[0][0][k], out[1][0][k]), k
+
+
 @pytest.mark.parametrize("batch_d", [True, False])
 def test_parameter_gradients_through_sinks_equal_the_autograd_sums(batch_d, monkeypatch):
     """GenerativeAdverserialNetwork._param_grads (dtype 'bf16'): weight gradients queued into per-parameter sinks and run as
