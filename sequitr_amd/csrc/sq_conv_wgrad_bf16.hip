@@ -68,8 +68,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char *p0, const unsigne
 // Cin / (16 NI) times over the whole launch, so wider blocks cut the (L2 / HBM) traffic that bounds this
 // kernel; the accumulators (NTAP x NI x NO MFMA blocks) are what limits NI, NO.
 // blocks per CU the register budget is sized for: the 36-accumulator-block shapes take the whole file
+#ifndef SQ_WGRAD_OCC3_UPTO
+#define SQ_WGRAD_OCC3_UPTO 18       // accumulator blocks up to which a shape is built for THREE blocks per CU (168 VGPRs, a shorter prefetch ring)
+#endif
+#ifndef SQ_WGRAD_OCC4_16x16
+#define SQ_WGRAD_OCC4_16x16 0       // ... and the 3x3 16 x 16-channel shape for FOUR (128 VGPRs; the 1x1 32 x 64 shape spills there)
+#endif
 template <int KS, int NI, int NO>
-constexpr int wgrad_occ() { return KS * KS * NI * NO > SQ_WGRAD_OCC1_ABOVE ? 1 : 2; }
+constexpr int wgrad_occ() {
+    constexpr int blocks = KS * KS * NI * NO;
+    return blocks > SQ_WGRAD_OCC1_ABOVE ? 1 : ((SQ_WGRAD_OCC4_16x16 && KS == 3 && NI * NO == 1) ? 4 : (blocks <= SQ_WGRAD_OCC3_UPTO ? 3 : 2));
+}
 
 __device__ __forceinline__ uint4 f32x8_to_bf16x8(const uint4 &a, const uint4 &b) {
     const float4 lo = __builtin_bit_cast(float4, a), hi = __builtin_bit_cast(float4, b);
@@ -533,7 +542,7 @@ int launch(const TIO *x, const TIO *dy, float *dw, float *db, float *ws, int N, 
     static bool attr_set = false;
     // prefetch depth: as deep as the accumulators leave registers for (f32 tensors: twice the registers per set)
     constexpr int acc_regs = C::NTAP * NI * NO * 4, set_regs = (C::XSLOTS + C::YSLOTS) * 4 * (int)(sizeof(TIO) / 2);
-    constexpr int budget = (wgrad_occ<KS, NI, NO>() == 1 ? 300 : SQ_WGRAD_BUDGET2) - acc_regs - 40;
+    constexpr int budget = (wgrad_occ<KS, NI, NO>() == 1 ? 300 : (wgrad_occ<KS, NI, NO>() == 4 ? 100 : (wgrad_occ<KS, NI, NO>() == 3 ? 140 : SQ_WGRAD_BUDGET2))) - acc_regs - 40;
     constexpr int PF = budget / set_regs >= 4 ? 4 : (budget / set_regs >= 3 ? 3 : (budget / set_regs >= 2 ? 2 : 1));
     if constexpr (KS == 3) {
         if (t_mos.h) return launch_mos<KS, NI, NO, PF, TIO>(x, dy, dw, db, ws, N, H, W, Cin, Cout, st);
@@ -720,7 +729,7 @@ template <int KS, int NI, int NO>
 constexpr int pf_bf16() {
     using C = WB<KS, NI, NO>;
     constexpr int acc_regs = C::NTAP * NI * NO * 4, set_regs = (C::XSLOTS + C::YSLOTS) * 4;
-    constexpr int budget = (wgrad_occ<KS, NI, NO>() == 1 ? 300 : SQ_WGRAD_BUDGET2) - acc_regs - 40;
+    constexpr int budget = (wgrad_occ<KS, NI, NO>() == 1 ? 300 : (wgrad_occ<KS, NI, NO>() == 4 ? 100 : (wgrad_occ<KS, NI, NO>() == 3 ? 140 : SQ_WGRAD_BUDGET2))) - acc_regs - 40;
     return budget / set_regs >= 4 ? 4 : (budget / set_regs >= 3 ? 3 : (budget / set_regs >= 2 ? 2 : 1));
 }
 
