@@ -9,6 +9,7 @@
 // 8 channels (one 16-byte piece) per lane everywhere: every feature tensor of the GAN has C % 8 == 0.
 // Where a fused form replaces two stored passes (gate variants) it keeps BOTH roundings, so fused == unfused, bit for bit.
 #include "sq_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -62,7 +63,10 @@ __device__ __forceinline__ float group_sum(float v) {
 //                           output of an activation, out1 leaves through its backward as a second stored rounding]
 //   MODE 2 (2nd backward):  v = dL/d(dx):  out1 = dg = r v - r^3 t x,  t = mean_c(v x)
 //                           out2 = dx2 = (-r^3 u + 3 r^5 s t) x - r^3 t g - r^3 s v,       u = mean_c(v g)
-template <int MODE, int GL>
+// NCH > 0: C == 8 * GL * NCH -- a lane's NCH chunks of every operand are loaded ONCE, all requests in flight together, and both passes
+// (the channel sums, then the outputs) run on the registers; NCH == 0: any C, the operands are read again for the second pass.
+// Same per-lane order of additions either way: same bits.
+template <int MODE, int GL, int NCH = 0>
 __global__ __launch_bounds__(256) void pixelnorm_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ g,
                                                               const __bf16 *__restrict__ v, __bf16 *__restrict__ out1,
                                                               __bf16 *__restrict__ out2, int64_t npix, int C, float eps,
@@ -76,6 +80,62 @@ __global__ __launch_bounds__(256) void pixelnorm_bf16_kernel(const __bf16 *__res
         const int64_t p = pb + sub;
         const bool live = p < npix;
         float sxx = 0.f, sgx = 0.f, svx = 0.f, svg = 0.f;
+        if constexpr (NCH > 0) {
+            F8 xr[NCH], gr[MODE >= 1 ? NCH : 1], vr[MODE == 2 ? NCH : 1];
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int c = 8 * lg + 8 * GL * k;
+                    xr[k] = ld8(x + p * C + c);
+                    if (MODE >= 1) gr[k] = ld8(g + p * C + c);
+                    if (MODE == 2) vr[k] = ld8(v + p * C + c);
+                }
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    sxx += dot8(xr[k], xr[k]);
+                    if (MODE >= 1) sgx += dot8(gr[k], xr[k]);
+                    if (MODE == 2) { svx += dot8(vr[k], xr[k]); svg += dot8(vr[k], gr[k]); }
+                }
+            }
+            sxx = group_sum<GL>(sxx);
+            if (MODE >= 1) sgx = group_sum<GL>(sgx);
+            if (MODE == 2) { svx = group_sum<GL>(svx); svg = group_sum<GL>(svg); }
+            const float r = 1.0f / __builtin_sqrtf(sxx * invC + eps);
+            const float r3 = r * r * r, s = sgx * invC, t = svx * invC, u = svg * invC;
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int c = 8 * lg + 8 * GL * k;
+                    const F8 xv = xr[k];
+                    F8 o;
+                    if (MODE == 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o.v[j] = xv.v[j] * r;
+                        st8(out1 + p * C + c, o);
+                    } else if (MODE == 1) {
+                        const F8 gv = gr[k];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            o.v[j] = r * gv.v[j] - r3 * s * xv.v[j];
+                            if (gate_slope != 1.0f) o.v[j] = gate_bf16((float)(__bf16)o.v[j], xv.v[j], gate_slope);
+                        }
+                        st8(out1 + p * C + c, o);
+                    } else {
+                        const F8 gv = gr[k], vv = vr[k];
+                        const float a = -r3 * u + 3.0f * r3 * r * r * s * t, b = -r3 * t, d = -r3 * s;
+                        F8 o2;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            o.v[j] = r * vv.v[j] - r3 * t * xv.v[j];
+                            o2.v[j] = a * xv.v[j] + b * gv.v[j] + d * vv.v[j];
+                        }
+                        st8(out1 + p * C + c, o);
+                        st8(out2 + p * C + c, o2);
+                    }
+                }
+            }
+            continue;
+        }
         if (live)
             for (int c = 8 * lg; c < C; c += 8 * GL) {
                 const F8 xv = ld8(x + p * C + c);
@@ -133,12 +193,20 @@ int launch_pixelnorm(const void *x, const void *g, const void *v, void *o1, void
     const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *gb = reinterpret_cast<const __bf16 *>(g),
                  *vb = reinterpret_cast<const __bf16 *>(v);
     __bf16 *a = reinterpret_cast<__bf16 *>(o1), *b = reinterpret_cast<__bf16 *>(o2);
-#define SQ_PN(GL_) hipLaunchKernelGGL((pixelnorm_bf16_kernel<MODE, GL_>), dim3(grid_for(npix * GL_)), dim3(256), 0, st, xb, gb, vb, a, b, npix, C, eps, slope)
-    if (C <= 8) SQ_PN(1);
-    else if (C <= 16) SQ_PN(2);
-    else if (C <= 32) SQ_PN(4);
-    else if (C <= 64) SQ_PN(8);
-    else SQ_PN(16);
+#define SQ_PN(GL_, NCH_) hipLaunchKernelGGL((pixelnorm_bf16_kernel<MODE, GL_, NCH_>), dim3(grid_for(npix * GL_)), dim3(256), 0, st, xb, gb, vb, a, b, npix, C, eps, slope)
+    static const bool regs = [] { const char *e = getenv("SQ_PIXELNORM_REGS"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (regs && C == 8) SQ_PN(1, 1);
+    else if (regs && C == 16) SQ_PN(2, 1);
+    else if (regs && C == 32) SQ_PN(4, 1);
+    else if (regs && C == 64) SQ_PN(8, 1);
+    else if (regs && C == 128) SQ_PN(16, 1);
+    else if (regs && C == 256) SQ_PN(16, 2);
+    else if (regs && C == 512) SQ_PN(16, 4);
+    else if (C <= 8) SQ_PN(1, 0);
+    else if (C <= 16) SQ_PN(2, 0);
+    else if (C <= 32) SQ_PN(4, 0);
+    else if (C <= 64) SQ_PN(8, 0);
+    else SQ_PN(16, 0);
 #undef SQ_PN
     return 0;
 }
