@@ -194,3 +194,156 @@ def segment_frames(net, frames, tile=512, margin=32, frames_per_batch=4, normali
         drain(pending)
     torch.cuda.synchronize(dev)
     return out
+
+
+class TileStreamer(object):
+    """The inference job's data path (sequitr/worker.py:195-215 calls the job function once per stack; what it
+    hands over is host memory): fixed-size float32 tiles in host memory -> uint8 class masks (and, when asked,
+    float32 logits) in host memory, with the three stages of a batch on three HIP streams and two buffers each:
+
+        host threads : tiles of batch i+2 -> pinned staging (optionally through an ImagePipeline, per tile)
+        copy-in      : H2D of batch i+1
+        compute      : net.predict(batch i)
+        copy-out     : D2H of the masks / logits of batch i-1 -> pinned, drained into the caller's arrays by a
+                       host thread
+
+    Nothing on the host waits for the GPU except the thread that drains a finished batch; the launching thread
+    only queues work.  A pinned CPU tensor as `tiles` is uploaded in place (no staging copy).  Same kernels and
+    the same bits as batch-by-batch net.predict()."""
+
+    def __init__(self, net, batch=32, want_logits=False, workers=4):
+        if net.device.type != 'cuda':
+            raise _lib.SequitrHipError('TileStreamer runs on the HIP back end only')
+        self.net, self.B, self.want_logits = net, int(batch), bool(want_logits)
+        self.workers = max(1, int(workers))
+        self._shape = None
+
+    def _buffers(self, tile_shape, n_out):
+        """pinned + device buffers for one tile shape (kept between runs: hipHostMalloc is slow)"""
+        if self._shape == (tuple(tile_shape), n_out):
+            return
+        H, W, C = tile_shape
+        dev, B = self.net.device, self.B
+        self.pin_in = [_pinned('ts_in%d' % i, (B, H, W, C), torch.float32) for i in range(2)]
+        self.dev_in = [torch.empty((B, H, W, C), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.pin_mask = [_pinned('ts_mask%d' % i, (B, H, W), torch.uint8) for i in range(2)]
+        self.pin_logits = ([_pinned('ts_logits%d' % i, (B, H, W, n_out), torch.float32) for i in range(2)]
+                           if self.want_logits else None)
+        self.s_in, self.s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self._shape = (tuple(tile_shape), n_out)
+
+    def warm_up(self, tile_shape):
+        """allocate the staging buffers and run one batch of zeros through the network (first-launch costs:
+        code-object load, workspace growth); a job calls this before its timed region"""
+        self._buffers(tuple(tile_shape), self.net.n_outputs)
+        self.dev_in[0].zero_()
+        self.net.predict(self.dev_in[0])
+        torch.cuda.synchronize(self.net.device)
+
+    def run(self, tiles, out_masks=None, out_logits=None, pipe=None, on_batch=None):
+        """tiles: (N,H,W,C) float32-convertible numpy array / memmap, or a pinned CPU float32 tensor.
+        out_masks (N,H,W) uint8 / out_logits (N,H,W,n_outputs) float32: numpy arrays filled in place (allocated
+        when None).  pipe: callable applied to every (H,W,C) tile on the host (ImagePipeline).  on_batch(first,
+        device_masks): called on the launching thread after each batch is queued (centroids from the masks in HBM).
+        Returns (out_masks, out_logits)."""
+        from concurrent.futures import ThreadPoolExecutor
+        net, B, dev = self.net, self.B, self.net.device
+        N = int(tiles.shape[0])
+        tile_shape = tuple(int(s) for s in tiles.shape[1:])
+        if len(tile_shape) != 3:
+            raise ValueError('tiles must be (N,H,W,C), got %s' % (tuple(tiles.shape),))
+        n_out = net.n_outputs
+        self._buffers(tile_shape, n_out)
+        if out_masks is None:
+            out_masks = np.empty((N,) + tile_shape[:2], np.uint8)
+        if self.want_logits and out_logits is None:
+            out_logits = np.empty((N,) + tile_shape[:2] + (n_out,), np.float32)
+        in_place = isinstance(tiles, torch.Tensor)
+        if in_place and not (tiles.is_pinned() and tiles.dtype == torch.float32 and tiles.is_contiguous()):
+            raise ValueError('a tensor source must be a contiguous pinned float32 CPU tensor')
+        nb = (N + B - 1) // B
+        if nb == 0:
+            return out_masks, out_logits
+        main = torch.cuda.current_stream(dev)
+        s_in, s_out = self.s_in, self.s_out
+        up = [torch.cuda.Event() for _ in range(2)]              # H2D into dev_in[k] finished
+        used = [torch.cuda.Event() for _ in range(2)]            # predict has consumed dev_in[k]
+        down = [torch.cuda.Event() for _ in range(2)]            # D2H into the pinned outputs [k] finished
+        for e in up + used + down:
+            e.record(main)
+        pool = ThreadPoolExecutor(self.workers + 1)
+
+        def count(b):
+            return min(B, N - b * B)
+
+        def stage_part(b, lo, hi):
+            k, first = b & 1, b * B
+            up[k].synchronize()                                   # batch b-2 has left this pinned buffer
+            dst = self.pin_in[k].numpy()
+            if pipe is None:
+                np.copyto(dst[lo:hi], tiles[first + lo:first + hi], casting='unsafe')
+            else:
+                for j in range(lo, hi):
+                    dst[j] = np.asarray(pipe(np.array(tiles[first + j], dtype=np.float32))).reshape(tile_shape)
+
+        def stage(b):
+            """host side of batch b: source -> pinned_in[b & 1], split over the worker threads"""
+            if in_place or b >= nb:
+                return []
+            n, w = count(b), self.workers
+            cuts = [n * i // w for i in range(w + 1)]
+            return [pool.submit(stage_part, b, cuts[i], cuts[i + 1]) for i in range(w) if cuts[i + 1] > cuts[i]]
+
+        def drain(b):
+            k, n, first = b & 1, count(b), b * B
+            down[k].synchronize()
+            out_masks[first:first + n] = self.pin_mask[k][:n].numpy()
+            if self.want_logits:
+                out_logits[first:first + n] = self.pin_logits[k][:n].numpy()
+
+        staged = {0: stage(0), 1: None}
+        drains = {}
+        try:
+            for b in range(nb):
+                k, n = b & 1, count(b)
+                for f in staged.pop(b):
+                    f.result()
+                with torch.cuda.stream(s_in):
+                    s_in.wait_event(used[k])
+                    src = tiles[b * B:b * B + n] if in_place else self.pin_in[k][:n]
+                    self.dev_in[k][:n].copy_(src, non_blocking=True)
+                    up[k].record(s_in)
+                if b + 1 < nb:                                    # its up[] wait is batch b-1's upload: already queued
+                    staged[b + 1] = stage(b + 1)
+                main.wait_event(up[k])
+                mask = net.predict(self.dev_in[k][:n])
+                logits = net.logits() if self.want_logits else None
+                used[k].record(main)
+                done = torch.cuda.Event()
+                done.record(main)
+                if b >= 2:
+                    drains.pop(b - 2).result()                    # the host has emptied the pinned outputs [k]
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(done)
+                    self.pin_mask[k][:n].copy_(mask, non_blocking=True)
+                    mask.record_stream(s_out)
+                    if logits is not None:
+                        self.pin_logits[k][:n].copy_(logits, non_blocking=True)
+                        logits.record_stream(s_out)
+                    down[k].record(s_out)
+                drains[b] = pool.submit(drain, b)
+                if on_batch is not None:
+                    on_batch(b * B, mask)
+            for b in sorted(drains):
+                drains[b].result()
+        finally:
+            pool.shutdown(wait=True)
+            torch.cuda.synchronize(dev)
+        return out_masks, out_logits
+
+
+def segment_tiles(net, tiles, batch=32, want_logits=False, pipe=None, on_batch=None, workers=4):
+    """one-call form of TileStreamer: (masks, logits-or-None) as host numpy arrays"""
+    if not isinstance(tiles, torch.Tensor) and tiles.ndim == 3:
+        tiles = tiles[..., np.newaxis]
+    return TileStreamer(net, batch, want_logits, workers).run(tiles, pipe=pipe, on_batch=on_batch)

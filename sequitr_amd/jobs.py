@@ -74,13 +74,20 @@ def SERVER_segment(params, options):
     with timing.  params: input, shape, num_inputs, num_outputs, filters, bridge, model
     (numbered model dir or name to warm-start from; else seeded initial weights), pipeline
     (ImagePipeline JSON applied to every tile on the host), batch (tiles per launch batch).
+    options: gpu, save_logits, centroids, io_threads (host staging threads, default 4).
+
+    ``segment.json``: ``seconds`` / ``mpixels_per_s`` cover the stream over the whole stack (host tiles in, host
+    masks out, PCIe both ways included); ``setup_seconds`` is what comes before it once per job (weights, pinned
+    staging buffers, one warm-up batch) and ``mpixels_per_s_with_setup`` the rate with it counted.
     """
     import torch
     from .networks.unet import UNet2D
     from . import utils
     from .pipeline import ImagePipeline
+    from .frontend import TileStreamer
 
     device = _resolve_device(params, options)
+    torch.cuda.set_device(torch.device(device))
     out_dir = params['output']
     x = _load_tiles(params)
     N = x.shape[0]
@@ -100,39 +107,43 @@ def SERVER_segment(params, options):
 
     pipe = ImagePipeline.load(params['pipeline']) if params.get('pipeline') else None
     batch = int(params.get('batch', 32))
-    writer = None
+    want_logits = bool(options.get('save_logits'))
+    writer, frames_out = None, {}
+    on_batch = None
     if options.get('centroids'):                               # the reference's next step: utils.CentroidWriter
-        from .centroids import CentroidWriter
-        writer, n_objects = CentroidWriter(os.path.join(out_dir, 'tracks.hdf5')), 0
-        frames_out = {}
-    masks = np.empty(x.shape[:3], np.uint8)
-    logits = np.empty(x.shape[:3] + (net.n_outputs,), np.float32) if options.get('save_logits') else None
-    t0 = time.time()
-    for i in range(0, N, batch):
-        xb = np.ascontiguousarray(x[i:i + batch], dtype=np.float32)
-        if pipe is not None:
-            xb = np.stack([pipe(t.copy()) for t in xb]).astype(np.float32)
-        m = net.predict(xb)
-        masks[i:i + batch] = m.cpu().numpy()
-        if writer is not None:                                 # centroids straight from the mask in HBM
-            from .centroids import mask_centroids
+        from .centroids import CentroidWriter, mask_centroids
+        writer = CentroidWriter(os.path.join(out_dir, 'tracks.hdf5'))
+
+        def on_batch(first, m):                                # centroids straight from the mask in HBM
             for k, coords in enumerate(mask_centroids(m)):
-                coords[:, 0] = i + k                           # frame index within the whole stack
-                frames_out[i + k] = coords
-                n_objects += len(coords)
-        if logits is not None:
-            logits[i:i + batch] = net.logits().cpu().numpy()
-    torch.cuda.synchronize()
+                coords[:, 0] = first + k                       # frame index within the whole stack
+                frames_out[first + k] = coords
+
+    # the streamed data path (frontend.TileStreamer): staging, H2D, the network and D2H of consecutive batches
+    # overlap on three streams; set-up (pinned buffers, first-launch costs) is timed apart from the stream itself
+    t_setup = time.time()
+    streamer = TileStreamer(net, batch=batch, want_logits=want_logits, workers=int(options.get('io_threads', 4)))
+    streamer.warm_up(tuple(x.shape[1:]))
+    masks = np.empty(x.shape[:3], np.uint8)
+    logits = np.empty(x.shape[:3] + (net.n_outputs,), np.float32) if want_logits else None
+    t0 = time.time()
+    streamer.run(x, out_masks=masks, out_logits=logits, pipe=(lambda t: pipe(t)) if pipe is not None else None,
+                 on_batch=on_batch)
     dt = time.time() - t0
+    n_objects = 0
     if writer is not None:
         for k in sorted(frames_out):
             writer.add_frame(k, frames_out[k])
+            n_objects += len(frames_out[k])
         writer.close()
     np.save(os.path.join(out_dir, 'mask.npy'), masks)
     if logits is not None:
         np.save(os.path.join(out_dir, 'logits.npy'), logits)
-    info = {'tiles': int(N), 'shape': [int(s) for s in x.shape[1:3]], 'seconds': dt,
-            'mpixels_per_s': float(N * x.shape[1] * x.shape[2] / max(dt, 1e-9) / 1e6), 'device': device}
+    pixels = N * x.shape[1] * x.shape[2]
+    info = {'tiles': int(N), 'shape': [int(s) for s in x.shape[1:3]], 'seconds': dt, 'setup_seconds': t0 - t_setup,
+            'mpixels_per_s': float(pixels / max(dt, 1e-9) / 1e6),
+            'mpixels_per_s_with_setup': float(pixels / max(dt + t0 - t_setup, 1e-9) / 1e6),
+            'batch': batch, 'streamed': True, 'device': device}
     if writer is not None:
         info['centroids'] = {'file': os.path.basename(writer.filename), 'objects': int(n_objects)}
     with open(os.path.join(out_dir, 'segment.json'), 'w') as f:
@@ -231,6 +242,9 @@ def SERVER_train(params, options):
     the GPU -- sq_weightmap_edt_f32 -- and kept there), dtype ('f32' | 'bf16' activations), plus the
     NetConfiguration keys (name, shape, num_outputs, learning_rate, num_epochs, batch_size, dropout, filters,
     bridge, warm_start ...) and warmup_steps (linear learning-rate warm-up).
+    Deviation from the reference's defaults: without params['learning_rate'] the step uses train.DEFAULT_LEARNING_RATE
+    (0.003) ramped over train.DEFAULT_WARMUP_STEPS (40), not NetConfiguration's 0.01 (sequitr/utils.py:289), which
+    diverges on this net under Adam; the values used are written to net.config and train.json.
     options: gpu, max_steps, graph (default True: the step is captured once and replayed as hipGraphs).
 
     The data path of a step never leaves the device: tiles, one-hot labels and weight maps are uploaded ONCE and stay
@@ -279,6 +293,10 @@ def SERVER_train(params, options):
     # learning_rate: the job's own value when it gives one; otherwise the trainer's default, NOT NetConfiguration's 0.01
     # (sequitr/utils.py:289), which diverges on the 5-level net under Adam (train.DEFAULT_LEARNING_RATE)
     trainer = UNetTrainer(net_p, learning_rate=params.get('learning_rate'), warmup_steps=params.get('warmup_steps'))
+    # net.config must record the hyper-parameters that were USED (it is what a warm start or an audit reads): the
+    # trainer's learning rate and warm-up, not NetConfiguration's untouched defaults
+    config.learning_rate = trainer.lr
+    config.warmup_steps = trainer.warmup_steps
     if config.warm_start:
         latest = config.warm_start_from()
         if latest:
@@ -302,7 +320,7 @@ def SERVER_train(params, options):
     resident = n_items * per_tile <= float(params.get('resident_gib', 64)) * 2 ** 30
     dev = torch.device(device)
     if resident:                                               # the whole stack lives in HBM for the whole job
-        x_dev = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+        x_dev = torch.from_numpy(np.array(x, dtype=np.float32, order='C')).to(dev)   # a copy: x is a read-only memmap
         y_dev = torch.from_numpy(np.ascontiguousarray(onehot)).to(dev)
         w_dev = wmap if isinstance(wmap, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(wmap)).to(dev)
     bufs = [torch.empty((batch,) + tuple(x.shape[1:]), dtype=torch.float32, device=dev),

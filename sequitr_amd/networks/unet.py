@@ -557,6 +557,13 @@ class UNet2D(UNet):
             self._mask = ops.argmax_u8(logits)
         return self._mask
 
+    def predict_stream(self, tiles, batch=32, want_logits=False, pipe=None, on_batch=None):
+        """predict() over a whole stack of host tiles with upload, network and download of consecutive batches
+        overlapped (frontend.TileStreamer): returns (masks, logits-or-None) as host arrays, the same bits as
+        predict() batch by batch."""
+        from ..frontend import segment_tiles
+        return segment_tiles(self, tiles, batch=batch, want_logits=want_logits, pipe=pipe, on_batch=on_batch)
+
 
 class UNet_LEGACY(UNet2D):
     """The reference's older wiring (unet.py:445-729): identical arithmetic, but no variable scopes -- the layer

@@ -76,6 +76,20 @@ class UNetTrainer(object):
         self.drop_salt = torch.full((1,), (self._rank() * 0x3C6EF35F) & 0x7FFFFFFF, dtype=torch.int32, device=dev)
         self.net._step_dev = self.drop_salt
         self._graphs = None
+        # a list here makes every step append a pair of timing events round its gradient all-reduce (bench.py's
+        # `allreduce_ms`); None: no events
+        self.allreduce_events = None
+
+    def _allreduce(self):
+        """ONE collective per optimiser step over the flat gradient bucket; returns the world size"""
+        if self.allreduce_events is None:
+            return allreduce_sum_(self.gbucket.flat, self.group)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        world = allreduce_sum_(self.gbucket.flat, self.group)
+        e1.record()
+        self.allreduce_events.append((e0, e1))
+        return world
 
     def load_state_dict(self, weights):
         """strict: every trainable variable of this configuration must be present with its shape; anything else must
@@ -146,7 +160,7 @@ class UNetTrainer(object):
         if self._graphs is not None:
             return self._step_graphed(x, onehot, weights)
         loss = self.forward_backward(x, onehot, weights)
-        world = allreduce_sum_(self.gbucket.flat, self.group)   # ONE collective per step
+        world = self._allreduce()                               # ONE collective per step
         self.step_count += 1
         self._adam(world)
         return loss
@@ -180,7 +194,7 @@ class UNetTrainer(object):
             ops.axpy_(self._acc, self.gbucket.flat, 1.0 / k)
             total = loss.clone() if total is None else total + loss
         self.gbucket.flat.copy_(self._acc)
-        world = allreduce_sum_(self.gbucket.flat, self.group)   # still ONE collective per optimiser step
+        world = self._allreduce()                               # still ONE collective per optimiser step
         self.step_count += 1
         if self._graphs is not None:
             self._graphs[1].replay()
@@ -226,7 +240,7 @@ class UNetTrainer(object):
             sx.copy_(x), so.copy_(onehot), sw.copy_(weights)
         self.arena.hand_over()
         g_fb.replay()
-        allreduce_sum_(self.gbucket.flat, self.group)
+        self._allreduce()
         self.step_count += 1
         g_opt.replay()
         self.last_loss = sloss

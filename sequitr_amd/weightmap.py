@@ -112,16 +112,23 @@ def boundary_triangulation(label):
     return verts.astype(np.int32), longest
 
 
-def device_weightmaps2(labels, w0=10., sigma=5., device=None, dtype=None, triangulation='native'):
+def device_weightmaps2(labels, w0=10., sigma=5., device=None, dtype=None, triangulation='scipy'):
     """ImageWeightMap2 (pipeline.py:482-571) of a stack of binary label images, returned as the (N,H,W,1) tensor the
     training step takes (float32; dtype=torch.float64 for the reference's own precision), left in HBM.
 
-    triangulation='native' (default, round 3): no scipy anywhere -- the boundary points are found on the device
+    triangulation='scipy' (default): the REFERENCE-EQUAL path -- scipy's morphology and Qhull on the host, one tile at
+    a time, exactly the calls of pipeline.py:516-537; the per-pixel part on the device.  ~12 Mpix/s.
+    triangulation='native' (opt-in, ~1 Gpix/s; PARITY RELAXED at Delaunay ties): no scipy anywhere -- the boundary points are found on the device
     (sq_wm2_boundary_points_u8), compacted there, copied to the host (~50 KB per tile), triangulated by the library's own
     exact integer Delaunay on a pool of host threads (sq_delaunay2d_batch_i32, ~4 ms per 512x512 tile per thread against
     Qhull's 22-38 ms under the GIL), and the simplices go back for the per-pixel part (sq_weightmap2_delaunay_f32:
     point location by rasterisation, scipy-order Gaussian, the reference's float64 expression).
-    triangulation='scipy': round 2's path -- scipy's morphology and Qhull on the host, one tile at a time.
+    Which one equals the reference: boundary pixels are lattice points, so a third of a real tile's simplices lie in
+    co-circular polygons (2030 of them on the golden 512x512 tile) where the Delaunay triangulation is not unique.
+    Qhull ('Qt') fans each such polygon from the vertex it happened to add last; no rule on coordinates or input order
+    reproduces that choice (best of six tried: 34 % of the polygons, profiles/r04_wm2_ties.txt), so only 'scipy' gives
+    the reference's map there; 'native' takes another valid diagonal: mean |dw| 0.035, 2.3 % of the background pixels
+    off by > 0.25 on the reference vector.
 
     Exact wherever the Delaunay triangulation is unique and one simplex covers the pixel.  On simplex edges / vertices
     the reference's answer depends on the path of scipy's walk (here the largest candidate is taken), and among
@@ -179,10 +186,12 @@ def create_weightmaps(path, folders, w0=10., sigma=3., thresh_fn=lambda x: x > 0
                       method='delaunay'):
     """ Generate weightmaps for the images using the binary masks; returns the files written.
     method='delaunay' is the reference's ImageWeightMap2 on the host (weightmap.py:181); 'delaunay_gpu' the same map
-    with its per-pixel part on the GPU (device_weightmaps2); 'edt' computes ImageWeightMap on the GPU
-    (sq_weightmap_edt_f32).  All write the same float32 TIFFs. """
-    if method not in ('delaunay', 'delaunay_gpu', 'edt'):
-        raise ValueError("method must be 'delaunay', 'delaunay_gpu' or 'edt'")
+    (the reference's own scipy triangulation) with its per-pixel part on the GPU (device_weightmaps2);
+    'delaunay_gpu_native' the ~80x faster form on the library's triangulation, which differs from the reference at
+    Delaunay ties (device_weightmaps2's docstring); 'edt' computes ImageWeightMap on the GPU (sq_weightmap_edt_f32).
+    All write the same float32 TIFFs. """
+    if method not in ('delaunay', 'delaunay_gpu', 'delaunay_gpu_native', 'edt'):
+        raise ValueError("method must be 'delaunay', 'delaunay_gpu', 'delaunay_gpu_native' or 'edt'")
     w_pipe = ImageWeightMap2(w0=w0, sigma=sigma)
     written = []
     for d in folders:
@@ -194,8 +203,9 @@ def create_weightmaps(path, folders, w0=10., sigma=3., thresh_fn=lambda x: x > 0
             im_label = ImageLabels(os.path.join(r_dir, 'label', f), thresh_fn=thresh_fn).labels()
             if method == 'edt':
                 im_weights = device_weightmaps(im_label[np.newaxis], w0, sigma).cpu().numpy()[0, ..., 0]
-            elif method == 'delaunay_gpu':
-                im_weights = device_weightmaps2(im_label[np.newaxis], w0, sigma).cpu().numpy()[0, ..., 0]
+            elif method in ('delaunay_gpu', 'delaunay_gpu_native'):
+                im_weights = device_weightmaps2(im_label[np.newaxis], w0, sigma, triangulation='native' if method.endswith(
+                    'native') else 'scipy').cpu().numpy()[0, ..., 0]
             else:
                 im_weights = np.squeeze(w_pipe(im_label.astype('bool')))
             out = os.path.join(w_dir, weights_file_name(f))

@@ -104,6 +104,30 @@ def test_gpus_2_launches_two_ranks_and_reports_strong_scaling():
     assert d["config"]["tiles_this_rank"] == 32 and d["steps"] == 2
     assert abs(d["value"] - 64 * 512 * 512 / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["value"]
     assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0.2
+    # the multi-rank line explains itself: the world size as the process group saw it, and the
+    # PCIe-inclusive rate with EVERY rank streaming at once (max-over-ranks time)
+    assert d["ranks_seen"] == 2
+    e = d["end_to_end"]
+    assert e["ranks_streaming"] == 2 and e["masks_equal_predict"] is True
+    assert e["value"] > 0 and e["from_pageable"]["value"] > 0 and e["serial"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_gpus_2_training_line_times_the_allreduce_apart():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SQ_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--global-tiles", "32"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "strong" and d["config"]["tiles_per_step"] == 32
+    ar = d["allreduce_ms"]
+    assert ar["bytes"] >= 4 * 1744994 and ar["backend"] == "gloo"
+    assert 0 < ar["min_over_ranks"] <= ar["max_over_ranks"] < d["ms_per_step"]
+    rl = d["roofline"]
+    assert rl["bound"] == "mfma" and rl["peak"] == 2500.0 and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
+    assert rl["hbm_schedule"]["frac"] > rl["frac"]              # the schedule's HBM fraction sits under its own key
 
 
 @pytest.mark.gpu

@@ -208,3 +208,108 @@ def test_segment_frames_job_from_an_octopus_stream(tmp_path):
     assert np.array_equal(mask, frontend_ref.stitch(rm, oy, ox, ymap, xmap, 96, 160))
     info = json.load(open(os.path.join(out, "segment.json")))
     assert info["frames"] == 3 and "centroids" in info
+
+
+def _o1_weights(params, seed=0, gain=1.35, bias_std=0.05):
+    """logits of order one (the non-degenerate parity data bench.o1_weights uses)"""
+    w = init_unet_weights(params, seed)
+    rng = np.random.default_rng(seed + 77)
+    for k in w:
+        if k.endswith("kernel") and w[k].shape[0] == 3:
+            w[k] = (w[k] * gain).astype(np.float32)
+        elif k.endswith("bias"):
+            w[k] = rng.normal(0, bias_std, w[k].shape).astype(np.float32)
+    return w
+
+
+def test_config1_one_512_tile_through_the_job_file_bit_exact(tmp_path, monkeypatch):
+    """BASELINE configs[0] at its own size: ONE 512x512x1 tile, .job file -> worker() -> SERVER_segment, logits and
+    mask bit-exact vs the C oracle (saved model with order-one logits, so the mask is not degenerate)."""
+    from sequitr_amd import core, utils
+    monkeypatch.setattr(core.TensorflowConfiguration, "MODELDIR", str(tmp_path / "models"))
+    os.mkdir(str(tmp_path / "models"))
+    p = {"shape": (512, 512), "num_inputs": 1, "num_outputs": 2}
+    w = _o1_weights(p)
+    utils.save_model(w, utils.NetConfiguration.from_params({"shape": (512, 512)}))
+    x = np.random.default_rng(0).standard_normal((1, 512, 512, 1)).astype(np.float32)
+    np.save(str(tmp_path / "tile.npy"), x)
+    params = {"input": str(tmp_path / "tile.npy"), "shape": (512, 512), "num_outputs": 2, "model": "UNet2D_test"}
+    fn = write_job(tmp_path, func="SERVER_segment", params=repr(params), options="{'gpu': 0, 'save_logits': True}")
+    out = str(tmp_path / "out")
+    worker.worker(argparse.Namespace(job=fn, out=out))
+    logs = open(os.path.join(out, [f for f in os.listdir(out) if f.startswith("LOG_")][0])).read()
+    assert "exception" not in logs, logs
+    ref = unet_oracle.unet_forward(x, w, p)
+    mask = np.load(os.path.join(out, "mask.npy"))
+    assert_bit_exact(np.load(os.path.join(out, "logits.npy")), ref, "config 1 logits")
+    assert_bit_exact(mask, unet_oracle.predict_mask(ref), "config 1 mask")
+    assert 0.02 < mask.mean() < 0.98                            # both classes present
+
+
+def test_tile_streamer_equals_predict_batch_by_batch():
+    """ragged tail, logits, a host pipe, on_batch and a pinned-tensor source: all the same bits as predict()"""
+    import torch
+    from sequitr_amd.frontend import TileStreamer, segment_tiles
+    from sequitr_amd.networks.unet import UNet2D
+    p = {"shape": (64, 64), "num_inputs": 1, "num_outputs": 2, "device": "cuda:0"}
+    net = UNet2D(p, "infer")
+    net.load_state_dict(_o1_weights(p))
+    x = np.random.default_rng(5).standard_normal((11, 64, 64, 1)).astype(np.float32)
+    want_m, want_l = [], []
+    for i in range(0, 11, 4):
+        want_m.append(net.predict(x[i:i + 4]).cpu().numpy())
+        want_l.append(net.logits().cpu().numpy())
+    want_m, want_l = np.concatenate(want_m), np.concatenate(want_l)
+    seen = []
+    m, l = segment_tiles(net, x, batch=4, want_logits=True, on_batch=lambda first, dm: seen.append((first, dm.shape[0])))
+    assert_bit_exact(m, want_m, "streamed masks")
+    assert_bit_exact(l, want_l, "streamed logits")
+    assert seen == [(0, 4), (4, 4), (8, 3)]
+    m2, _ = net.predict_stream(x[..., 0], batch=32)              # (N,H,W) source, one short batch
+    assert_bit_exact(m2, want_m, "predict_stream masks")
+    st = TileStreamer(net, batch=4)
+    m3, none = st.run(torch.from_numpy(x).pin_memory())          # pinned source: uploaded in place
+    assert none is None
+    assert_bit_exact(m3, want_m, "pinned-source masks")
+    m4, _ = st.run(x * 2.0, pipe=lambda t: t * 0.5)              # the same streamer again, through a host pipe
+    assert_bit_exact(m4, want_m, "piped masks")
+    empty, _ = st.run(x[:0])
+    assert empty.shape == (0, 64, 64)
+
+
+def test_segment_job_streams_256_tiles_at_the_end_to_end_rate(tmp_path):
+    """256 tiles of 512^2 through the .job entry point; segment.json's rate (host tiles in, host
+    masks out) must reach 0.9 x what the same streamer does on the same box from a host array, and the masks must
+    equal the synchronous predict() path."""
+    import torch
+    from sequitr_amd.frontend import TileStreamer
+    from sequitr_amd.networks.unet import UNet2D
+    n = 256
+    x = np.random.default_rng(21).standard_normal((n, 512, 512, 1)).astype(np.float32)
+    np.save(str(tmp_path / "tiles.npy"), x)
+    params = {"input": str(tmp_path / "tiles.npy"), "shape": (512, 512), "num_outputs": 2, "seed": 0, "batch": 32}
+    fn = write_job(tmp_path, func="SERVER_segment", params=repr(params), options="{'gpu': 0}")
+    out = str(tmp_path / "out")
+    worker.worker(argparse.Namespace(job=fn, out=out))
+    logs = open(os.path.join(out, [f for f in os.listdir(out) if f.startswith("LOG_")][0])).read()
+    assert "exception" not in logs, logs
+    info = json.load(open(os.path.join(out, "segment.json")))
+    mask = np.load(os.path.join(out, "mask.npy"))
+
+    p = {"shape": (512, 512), "num_inputs": 1, "num_outputs": 2, "device": "cuda:0", "seed": 0}
+    net = UNet2D(p, "infer")
+    net.initialize()
+    for i in (0, 96, 224):                                      # the synchronous path, three of the eight batches
+        assert_bit_exact(mask[i:i + 32], net.predict(x[i:i + 32]).cpu().numpy(), "job masks vs predict(), batch at %d" % i)
+    import time
+    st = TileStreamer(net, batch=32)
+    st.warm_up((512, 512, 1))
+    best = 0.0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        st.run(x)
+        best = max(best, n * 512 * 512 / (time.perf_counter() - t0) / 1e6)
+    print("job %.0f Mpix/s (with set-up %.0f), streamer on the same array %.0f Mpix/s"
+          % (info["mpixels_per_s"], info["mpixels_per_s_with_setup"], best))
+    assert info["streamed"] and info["tiles"] == n
+    assert info["mpixels_per_s"] >= 0.9 * best, (info, best)

@@ -128,7 +128,8 @@ def test_weightmap2_reference_vectors_64px_and_512px():
 
 
 def test_weightmap2_native_triangulation_no_scipy_in_the_path():
-    """Round 3: ImageWeightMap2 with the library's own triangulation (the default path).
+    """Round 3 (VERDICT r2 item 8): ImageWeightMap2 with the library's own triangulation (opt-in: triangulation='native';
+    the default is the reference-equal scipy path, pinned exactly by the tests above).
       * the boundary-point kernel equals scipy's morphology (pipeline.py:516-528) bit for bit, also at the tile border;
       * the device map equals the CPU rasterisation of the SAME native triangulation to 1e-12 (pins the kernels);
       * against the reference-generated vectors: the native Delaunay triangulation is the reference's wherever the
@@ -155,40 +156,44 @@ def test_weightmap2_native_triangulation_no_scipy_in_the_path():
         P = np.column_stack(np.where(weightmap_ref.boundary_points(lab))).astype(np.int32)
         simp, _ = ops.delaunay2d_batch(torch.from_numpy(P), torch.tensor([0, len(P)], dtype=torch.int64), compact=True)
         emu, _ = weightmap_ref.image_weight_map2_raster(lab, 10., 5., vertices=simp.numpy()[:, 1:].reshape(-1, 3, 2))
-        got = device_weightmaps2(lab[None], 10., 5., device="cuda:0", dtype=torch.float64).cpu().numpy()[0]
+        got = device_weightmaps2(lab[None], 10., 5., device="cuda:0", dtype=torch.float64, triangulation="native").cpu().numpy()[0]
         assert np.abs(got - emu).max() <= 1e-12
     # against the reference-generated vector at the benchmark size
-    got = device_weightmaps2(big[None], 10., 5., device="cuda:0", dtype=torch.float64).cpu().numpy()[0, 128:384, 128:384, 0]
+    got = device_weightmaps2(big[None], 10., 5., device="cuda:0", dtype=torch.float64, triangulation="native").cpu().numpy()[0, 128:384, 128:384, 0]
     bg = big[128:384, 128:384] == 0
     err = np.abs(got - G["wm2_out_512_centre"].astype(np.float64))[bg]
     print("native WM2 vs reference: mean %.4f  frac > 0.25: %.4f  frac > 1e-5: %.4f  max %.3f"
           % (err.mean(), (err > 0.25).mean(), (err > 1e-5).mean(), err.max()))
-    assert err.mean() <= 0.05 and (err > 0.25).mean() <= 0.03 and err.max() <= 10.0 + 1e-6
+    # observed on MI355X (round 3): mean 0.0354, 2.32 % > 0.25, max 6.52 (one other diagonal next to a cell)
+    assert err.mean() <= 0.04 and (err > 0.25).mean() <= 0.026 and err.max() <= 6.6
     # a batch: every tile equals the tile run alone; tiles with fewer than three boundary points are refused loudly
     stack = np.stack([big, np.roll(big, 37, axis=1), big[::-1].copy()])
-    wb = device_weightmaps2(stack, 10., 5., device="cuda:0", dtype=torch.float64).cpu().numpy()
+    wb = device_weightmaps2(stack, 10., 5., device="cuda:0", dtype=torch.float64, triangulation="native").cpu().numpy()
     for k in range(3):
-        assert np.array_equal(wb[k], device_weightmaps2(stack[k:k + 1], 10., 5., device="cuda:0", dtype=torch.float64).cpu().numpy()[0])
+        assert np.array_equal(wb[k], device_weightmaps2(stack[k:k + 1], 10., 5., device="cuda:0", dtype=torch.float64,
+                                                        triangulation="native").cpu().numpy()[0])
     with pytest.raises(ValueError, match="three boundary points"):
-        device_weightmaps2(np.zeros((1, 64, 64), np.float32), 10., 5., device="cuda:0")
+        device_weightmaps2(np.zeros((1, 64, 64), np.float32), 10., 5., device="cuda:0", triangulation="native")
 
 
 def test_create_weightmaps_gpu_methods_write_the_reference_layout(tmp_path):
     """create_weightmaps (weightmap.py:171-205) with both GPU methods: folder weights_w0-.._sigma-.., file
-    <stem>_weights.tif, float32 -- 'edt' = ImageWeightMap, 'delaunay_gpu' = ImageWeightMap2 -- against the host
-    restatements of the same pipes."""
+    <stem>_weights.tif, float32 -- 'edt' = ImageWeightMap, 'delaunay_gpu' = ImageWeightMap2 on the reference's (scipy)
+    triangulation, 'delaunay_gpu_native' = the same on the library's own -- against the host restatements."""
     from sequitr_amd import weightmap as wmod
     from sequitr_amd import pipeline
     lab = (G["wm_in_512"][128:384, 128:384] > 0).astype(np.uint8)
     d = tmp_path / "set1" / "label"
     d.mkdir(parents=True)
     wmod.imsave(str(d / "img_0001_label.tif"), lab)
-    for method, pipe in (("edt", pipeline.ImageWeightMap(10., 5.)), ("delaunay_gpu", None)):
+    for method, pipe in (("edt", pipeline.ImageWeightMap(10., 5.)), ("delaunay_gpu", "scipy"), ("delaunay_gpu_native", None)):
         files = wmod.create_weightmaps(str(tmp_path), ["set1"], w0=10., sigma=5., method=method)
         assert files == [str(tmp_path / "set1" / "weights_w0-10.00_sigma-5.00" / "img_0001_weights.tif")]
         got = wmod.imread(files[0])
         assert got.dtype == np.float32 and got.shape == (256, 256)
-        if pipe is not None:
+        if pipe == "scipy":                                     # the default: the reference's own triangulation
+            want = weightmap_ref.image_weight_map2_raster(lab.astype(np.float32), 10., 5.)[0][..., 0].astype(np.float32)
+        elif pipe is not None:
             want = np.squeeze(pipe(lab.astype(np.float32)[..., None])).astype(np.float32)
         else:
             from sequitr_amd import ops
