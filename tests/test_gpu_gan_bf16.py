@@ -186,53 +186,79 @@ def test_weighted_conv_bf16_forward_dgrad_gate_and_wgrad(N, H, W, Cin, Cout, K, 
     assert np.allclose(db.cpu().numpy(), dy.reshape(-1, Cout).sum(0).numpy(), rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("level,alpha", [(0, 1.0), (2, 0.4), (2, 1.0)])
-def test_losses_and_gradients_bf16_storage_vs_fp64_and_mixed(level, alpha):
-    """One WGAN-GP evaluation (losses, penalty through the second-order pass, parameter gradients of both networks) with
-    bf16 storage against fp64, beside the 'mixed' form.  bf16 storage adds one rounding per stored feature value and
-    gradient value (2^-9 relative each) on top of the operand roundings the mixed form already has: the bound is the
-    mixed form's error plus a storage term, stated per quantity."""
-    from tests.test_gpu_gan import make_gan, dev
-    rng = np.random.default_rng(2)
-    res = {}
-    z = rng.standard_normal((4, 1, 1, 512)).astype(np.float32)
-    r = rng.random(4).astype(np.float32)
-    x = None
-    for dtype in ("mixed", "bf16"):
-        g = make_gan(dtype=dtype)
-        g.set_level(level)
-        if x is None:
-            x = rng.standard_normal((4,) + g.get_size(level) + (2,)).astype(np.float32)
-        with g.precision():
-            _, d_loss, g_loss = g._build_network(dev(x), dev(z), alpha, r=dev(r))
-            d_vars, g_vars = g.get_training_variables(level)
-            dg = torch.autograd.grad(d_loss, [v for _, v in d_vars], retain_graph=True, allow_unused=True)
-            gg = torch.autograd.grad(g_loss, [v for _, v in g_vars], allow_unused=True)
-        assert all(t.dtype == torch.float32 for t in dg + gg if t is not None)
-        res[dtype] = (d_loss.item(), g_loss.item(), [t.cpu().numpy() for t in dg], [t.cpu().numpy() for t in gg])
-    W = ref.to_torch(g.store.state_dict())
-    _, rd, rg = ref.losses(torch.as_tensor(x, dtype=torch.float64), torch.as_tensor(z, dtype=torch.float64), alpha,
-                           torch.as_tensor(r, dtype=torch.float64), W, g.filters, level)
-    rdg = torch.autograd.grad(rd, [W[n] for n, _ in d_vars], retain_graph=True, allow_unused=True)
-    rgg = torch.autograd.grad(rg, [W[n] for n, _ in g_vars], allow_unused=True)
-    truth = [t.numpy() for t in rdg + rgg]
-    names = [n for n, _ in d_vars + g_vars]
+def _rel(a, t):
+    a, t = np.asarray(a, np.float64), np.asarray(t, np.float64)
+    return float(np.linalg.norm((a - t).ravel()) / max(np.linalg.norm(t.ravel()), 1e-30))
 
-    def rel(a, t):
-        return float(np.linalg.norm((a.astype(np.float64) - t).ravel()) / max(np.linalg.norm(t.ravel()), 1e-30))
-    # measured (tools/r03_gan_bf16_err.py, seed 2): mean gradient error vs fp64  mixed 0.106 / 0.064 / 0.241,
-    # bf16 storage 0.146 / 0.091 / 0.239 -- at random initialisation the penalty's second-order pass through ten
-    # leaky-ReLU / pixel-norm layers turns the 2^-9 operand roundings the mixed form already has into 6-24 % of the
-    # gradient; storage adds at most half as much again.  The f32 form is at 1e-4 (tests/test_gpu_gan.py).
-    dm, gm = res["mixed"][0], res["mixed"][1]
-    db_, gb_ = res["bf16"][0], res["bf16"][1]
-    assert abs(db_ - rd.item()) <= 2.0 * abs(dm - rd.item()) + 0.02 * max(1.0, abs(rd.item())), (db_, dm, rd.item())
-    assert abs(gb_ - rg.item()) <= 2.0 * abs(gm - rg.item()) + 0.02 * max(1.0, abs(rg.item())), (gb_, gm, rg.item())
-    em = [rel(a, t) for a, t in zip(res["mixed"][2] + res["mixed"][3], truth)]
-    eb = [rel(a, t) for a, t in zip(res["bf16"][2] + res["bf16"][3], truth)]
-    for n, m, b_ in zip(names, em, eb):                         # norm-wise error of every parameter gradient: within 2.5 x the
-        assert b_ <= 2.5 * max(m, np.mean(em)) + 0.05, (n, m, b_)   # larger of its own mixed error and the mixed form's typical one
-    assert np.mean(eb) <= 1.6 * np.mean(em) + 0.01, (np.mean(em), np.mean(eb))
+
+# Absolute bounds of the HIP path against the rounding-point emulation (oracle/gan_bf16_ref.py: float64 arithmetic, bf16
+# roundings where the kernels store / round).  What is left between the two is f32 accumulation order and the rare stored
+# value that lands on the other side of a bf16 rounding boundary because of it -- amplified by the same factor that turns
+# the 2^-9 roundings themselves into 5-30 % of a gradient at random initialisation (printed beside it: fp64 vs emulation).
+GRAD_BOUND = 2e-2        # norm-wise, every parameter gradient of d_loss and g_loss
+LOSS_BOUND = 1e-3        # relative to max(1, |loss|)
+
+
+@pytest.mark.parametrize("level,alpha,levels,nb", [(0, 1.0, 3, 4), (2, 0.4, 3, 4), (2, 1.0, 3, 4), (6, 1.0, 7, 4)])
+def test_losses_and_gradients_bf16_vs_the_rounding_point_emulation(level, alpha, levels, nb):
+    """config 5 in ITS dtype against an oracle, whole graph -- d_loss, g_loss and every parameter
+    gradient of both (the penalty's second-order pass included) at levels 0, 2 and 6 (level 6: the full 7-level net,
+    filters 512 .. 8, 256x256 images).  Two evaluations of the HIP path are checked: plain autograd over the tape, and the
+    solver's own gradient path (_d_grads / _g_grads: parameter-gradient sinks, grouped weight-gradient launches, the
+    stacked D(Gz | X) pass) -- the one the training step runs."""
+    from tests.test_gpu_gan import make_gan, dev
+    from oracle import gan_bf16_ref as emu
+    rng = np.random.default_rng(2)
+    g = make_gan(dtype="bf16", num_levels=levels, batch_size=nb)
+    g.set_level(level)
+    z = rng.standard_normal((nb, 1, 1, 512)).astype(np.float32)
+    r = rng.random(nb).astype(np.float32)
+    x = rng.standard_normal((nb,) + g.get_size(level) + (2,)).astype(np.float32)
+    d_vars, g_vars = g.get_training_variables(level)
+    names = [n for n, _ in d_vars + g_vars]
+    with g.precision():
+        _, d_loss, g_loss = g._build_network(dev(x), dev(z), alpha, r=dev(r))
+        dg = torch.autograd.grad(d_loss, [v for _, v in d_vars], retain_graph=True, allow_unused=True)
+        gg = torch.autograd.grad(g_loss, [v for _, v in g_vars], allow_unused=True)
+    assert all(t.dtype == torch.float32 for t in dg + gg if t is not None)
+    tape = (d_loss.item(), g_loss.item(), [None if t is None else t.cpu().numpy() for t in dg + gg])
+    with g.precision(), F.fuse_act_gates(g._act_gates()):      # what d_solver / g_solver run in front of Adam
+        g._pack_filters()
+        _, sdg, (sd_loss, _) = g._d_grads(dev(x), dev(z), alpha, dev(r))
+        sdg = [None if t is None else t.clone() for t in sdg]
+        _, sgg, (sg_loss,) = g._g_grads(dev(x), dev(z), alpha)
+    solver = (sd_loss.item(), sg_loss.item(), [None if t is None else t.cpu().numpy() for t in list(sdg) + list(sgg)])
+
+    t64 = lambda a: torch.as_tensor(a, dtype=torch.float64)
+    sd = g.store.state_dict()
+    W = emu.to_torch(sd)
+    _, ed, eg = emu.losses(t64(x), t64(z), alpha, t64(r), W, g.filters, level)
+    edg = torch.autograd.grad(ed, [W[n] for n, _ in d_vars], retain_graph=True, allow_unused=True)
+    egg = torch.autograd.grad(eg, [W[n] for n, _ in g_vars], allow_unused=True)
+    want = [None if t is None else t.numpy() for t in edg + egg]
+    W64 = ref.to_torch(sd)
+    _, rd, rg = ref.losses(t64(x), t64(z), alpha, t64(r), W64, g.filters, level)
+    rdg = torch.autograd.grad(rd, [W64[n] for n, _ in d_vars], retain_graph=True, allow_unused=True)
+    rgg = torch.autograd.grad(rg, [W64[n] for n, _ in g_vars], allow_unused=True)
+    truth = [None if t is None else t.numpy() for t in rdg + rgg]
+
+    print("level %d alpha %.1f batch %d: d_loss fp64 %.6f emu %.6f hip %.6f (solver %.6f) | g_loss fp64 %.6f emu %.6f hip %.6f"
+          % (level, alpha, nb, rd.item(), ed.item(), tape[0], solver[0], rg.item(), eg.item(), tape[1]))
+    rounding, gap_tape, gap_solver = [], [], []
+    for n, t, w, a, b_ in zip(names, truth, want, tape[2], solver[2]):
+        assert (w is None) == (a is None) == (b_ is None), n
+        if w is None:
+            continue
+        rounding.append(_rel(w, t)), gap_tape.append(_rel(a, w)), gap_solver.append(_rel(b_, w))
+        print("  %-52s rounding alone (fp64 vs emu) %.4f | hip vs emu: tape %.5f solver %.5f"
+              % (n, rounding[-1], gap_tape[-1], gap_solver[-1]))
+    print("  mean / max: rounding alone %.4f / %.4f | hip vs emu tape %.5f / %.5f, solver %.5f / %.5f"
+          % (np.mean(rounding), max(rounding), np.mean(gap_tape), max(gap_tape), np.mean(gap_solver), max(gap_solver)))
+    for got in (tape, solver):
+        assert abs(got[0] - ed.item()) <= LOSS_BOUND * max(1.0, abs(ed.item())), (got[0], ed.item())
+        assert abs(got[1] - eg.item()) <= LOSS_BOUND * max(1.0, abs(eg.item())), (got[1], eg.item())
+    worst = max(zip(gap_tape + gap_solver, names + names))
+    assert worst[0] <= GRAD_BOUND, worst
 
 
 def test_storage_boundaries_and_dtypes():
