@@ -35,6 +35,17 @@ from torch.autograd import Function
 
 DT = torch.float64
 ROUND = True                 # False: no rounding anywhere -- must equal oracle/torch_gan_ref.py's autograd
+# OBSERVER(kind, inputs: dict, output): called by every leaf evaluation, in every pass (forward, the create_graph
+# backward, the second-order backward), with the operands it read, their storage classes and the value it stored --
+# tests replay each one through the HIP operator of the same name on the SAME operands (a comparison that does not
+# compound roundings from layer to layer, see tests/test_gpu_gan_bf16.py)
+OBSERVER = None
+
+
+def _obs(kind, out, **inputs):
+    if OBSERVER is not None:
+        OBSERVER(kind, inputs, out)
+    return out
 
 
 def q(t, s='b'):
@@ -111,7 +122,7 @@ class ConvFwd(Function):
         rt, rw, sr = conv_policy('conv', K, ci, co, _npix(x), sx, so)
         ctx.a = (ws, sx, so)
         ctx.save_for_backward(x, w)
-        return q(_conv(q(x) if rt else x, q(w * ws) if rw else w * ws, K), sr)
+        return _obs('conv', q(_conv(q(x) if rt else x, q(w * ws) if rw else w * ws, K), sr), x=x, w=w, ws=ws, sx=sx, so=so)
 
     @staticmethod
     def backward(ctx, dy):
@@ -131,7 +142,7 @@ class ConvDgrad(Function):
         rt, rw, sr = conv_policy('conv', K, co, ci, _npix(dy), so, sx)
         ctx.a = (ws, sx, so)
         ctx.save_for_backward(dy, w)
-        return q(_conv_adj(q(dy) if rt else dy, q(w * ws) if rw else w * ws, K), sr)
+        return _obs('dgrad', q(_conv_adj(q(dy) if rt else dy, q(w * ws) if rw else w * ws, K), sr), dy=dy, w=w, ws=ws, sx=sx, so=so)
 
     @staticmethod
     def backward(ctx, ddx):
@@ -150,7 +161,7 @@ class ConvWgrad(Function):
         rt, _, _ = conv_policy('wgrad', K, x.shape[-1], dy.shape[-1], _npix(x), sx, so)
         ctx.a = (K, ws, sx, so)
         ctx.save_for_backward(x, dy)
-        return _conv_wg(q(x) if rt else x, q(dy) if rt else dy, K) * ws
+        return _obs('wgrad', _conv_wg(q(x) if rt else x, q(dy) if rt else dy, K) * ws, x=x, dy=dy, K=K, ws=ws, sx=sx, so=so)
 
     @staticmethod
     def backward(ctx, ddw):
@@ -172,7 +183,7 @@ class ActBwd(Function):
     def forward(ctx, dy, y, s):
         ctx.s = s
         ctx.save_for_backward(y)
-        return q(dy * _slope(y, True), s)
+        return _obs('act_bwd', q(dy * _slope(y, True), s), dy=dy, y=y, s=s)
 
     @staticmethod
     def backward(ctx, dd):
@@ -193,7 +204,7 @@ class ConvAct(Function):
         y = q(TF.leaky_relu(pre, 0.2) if act else pre, sr)
         ctx.a = (ws, act, sx, so, tuple(b.shape))
         ctx.save_for_backward(x, w, y)
-        return y
+        return _obs('conv_act', y, x=x, w=w, b=b, ws=ws, act=act, sx=sx, so=so)
 
     @staticmethod
     def backward(ctx, dy):
@@ -202,7 +213,9 @@ class ConvAct(Function):
         dpre = ActBwd.apply(dy, y, so) if act else dy
         dx = ConvDgrad.apply(dpre, w, ws, sx, so) if ctx.needs_input_grad[0] else None
         dw = ConvWgrad.apply(x, dpre, w.shape[0], ws, sx, so) if ctx.needs_input_grad[1] else None
-        db = dpre.sum(tuple(range(dpre.dim() - 1))).reshape(bshape) if ctx.needs_input_grad[2] else None
+        db = None
+        if ctx.needs_input_grad[2]:
+            db = _obs('bias_grad', dpre.sum(tuple(range(dpre.dim() - 1))).reshape(bshape), x=x, dpre=dpre, K=w.shape[0], sx=sx, so=so)
         return dx, dw, db, None, None, None, None
 
 
@@ -216,7 +229,7 @@ class PixelNorm(Function):
     def forward(ctx, x, eps, s):
         ctx.a = (eps, s)
         ctx.save_for_backward(x)
-        return q(_pn(x, eps), s)
+        return _obs('pixelnorm', q(_pn(x, eps), s), x=x, eps=eps, s=s)
 
     @staticmethod
     def backward(ctx, g):
@@ -239,7 +252,7 @@ class PixelNormBwd(Function):
     def forward(ctx, x, g, eps, s):
         ctx.a = (eps, s)
         ctx.save_for_backward(x, g)
-        return q(_pn_vjp(x, g, eps), s)
+        return _obs('pixelnorm_bwd', q(_pn_vjp(x, g, eps), s), x=x, g=g, eps=eps, s=s)
 
     @staticmethod
     def backward(ctx, v):
@@ -250,7 +263,8 @@ class PixelNormBwd(Function):
             x_ = x.detach().requires_grad_(True)
             (dx,) = torch.autograd.grad(_pn(x_, eps), x_, g_, create_graph=True)
             dx2, dg = torch.autograd.grad(dx, (x_, g_), v.detach())
-        return q(dx2, s), q(dg, s), None, None
+        dx2, dg = _obs('pixelnorm_bwd2', (q(dx2, s), q(dg, s)), x=x, g=g, v=v, eps=eps, s=s)
+        return dx2, dg, None, None
 
 
 # ---- 2x2 pooling <-> broadcasting (gan.py:133-136, 189-192) ----------------------------------------------------------
@@ -260,7 +274,7 @@ class Pool(Function):
         ctx.a = (scale, s)
         a, b = x[:, 0::2, 0::2], x[:, 0::2, 1::2]
         c, d = x[:, 1::2, 0::2], x[:, 1::2, 1::2]
-        return q(scale * ((a + b) + (c + d)), s)
+        return _obs('pool', q(scale * ((a + b) + (c + d)), s), x=x, scale=scale, s=s)
 
     @staticmethod
     def backward(ctx, dy):
@@ -271,7 +285,7 @@ class Bcast(Function):
     @staticmethod
     def forward(ctx, x, scale, s):
         ctx.a = (scale, s)
-        return q(scale * x, s).repeat_interleave(2, 1).repeat_interleave(2, 2)
+        return _obs('bcast', q(scale * x, s).repeat_interleave(2, 1).repeat_interleave(2, 2), x=x, scale=scale, s=s)
 
     @staticmethod
     def backward(ctx, dy):
@@ -284,7 +298,7 @@ class Cast(Function):
     @staticmethod
     def forward(ctx, x, s_from, s_to):
         ctx.a = (s_from, s_to)
-        return q(x, s_to)
+        return _obs('cast', q(x, s_to), x=x, s_from=s_from, s_to=s_to)
 
     @staticmethod
     def backward(ctx, g):
@@ -389,8 +403,9 @@ def discriminator(x, W, filters):
     return dense(h, W, p + 'output/logits').reshape(-1)
 
 
-def losses(X, Z, alpha, r, W, filters, level):
-    """(Gz_raw, d_loss, g_loss) of gan.py:665-732 at `level`; W: {name: float64 tensor}"""
+def losses(X, Z, alpha, r, W, filters, level, details=None):
+    """(Gz_raw, d_loss, g_loss) of gan.py:665-732 at `level`; W: {name: float64 tensor}.  details: a dict that receives
+    'grad_norm' (N,), the per-sample |d D(mix) / d mix| -- the one-sided penalty is active only where it exceeds 1"""
     f = filters[:level + 1]
     imgs = generator(Z, W, f)
     Gz_raw = imgs[level]
@@ -407,6 +422,8 @@ def losses(X, Z, alpha, r, W, filters, level):
     Dmix = discriminator(mix, W, df)
     grad = torch.autograd.grad(Dmix.sum(), mix, create_graph=True)[0]
     gn = torch.sqrt((grad * grad).sum((1, 2, 3)))
+    if details is not None:
+        details['grad_norm'] = gn.detach().clone()
     pen = 10.0 * torch.square(torch.clamp(gn - 1.0, min=0.0))
     g_loss = torch.mean(-Dz)
     d_loss = torch.mean(-Dx + Dz + pen + 0.001 * torch.square(Dx))

