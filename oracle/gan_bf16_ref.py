@@ -306,6 +306,21 @@ class Cast(Function):
         return Cast.apply(g, s_to, s_from), None, None
 
 
+class GradStore(Function):
+    """identity on a stored tensor whose gradient arrives from SEVERAL nodes of the gradient graph (the conv output in front
+    of a pixel norm: in the second-order pass both the norm's backward and the norm's second backward send it a
+    gradient): the framework adds the bf16 contributions and stores the sum as bf16"""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _obs('grad_sum', q(g, ctx.s), g=g, s=ctx.s), None
+
+
 class Fork(Function):
     """a stored bf16 tensor with TWO differentiable consumers: the framework adds the two bf16 gradients (f32 add,
     stored as bf16)"""
@@ -340,7 +355,7 @@ def wconv(x, W, name, sx, so, act=True, norm=True):
     """weighted_conv2d (gan.py:61-99): fused conv + bias + activation, then pixel norm as a stored pass"""
     k = W[name + '/filter']
     y = ConvAct.apply(x, k, W[name + '/bias'], wscale(k), act, sx, so)
-    return PixelNorm.apply(y, 1e-8, so) if norm else y
+    return PixelNorm.apply(GradStore.apply(y, so), 1e-8, so) if norm else y
 
 
 def dense(x, W, name, act=False):

@@ -306,16 +306,17 @@ class _Replay(object):
         g = got.detach().float().cpu().double().reshape(want.shape)
         if s == 'b':
             assert got.dtype == BF, (kind, what)
-            bad = (g - want).abs() > want.abs() * 2.0 ** -7 + 1e-30
+            # one ulp of the stored value, plus the f32 accumulation error of a sum that cancels to (nearly) nothing
+            bad = (g - want).abs() > want.abs() * 2.0 ** -7 + 1e-5 * float(want.abs().max())
             frac_same = float((g == want).double().mean())
             assert not bad.any(), "%s %s: %d values off by more than one bf16 ulp" % (kind, what, int(bad.sum()))
             assert frac_same >= 0.97, "%s %s: only %.4f of the stored values identical" % (kind, what, frac_same)
-            self.worst[kind] = min(self.worst.get(kind, 1.0), frac_same)
+            self.worst[kind + ' (bf16: identical fraction)'] = min(self.worst.get(kind + ' (bf16: identical fraction)', 1.0), frac_same)
         else:
             assert got.dtype == torch.float32, (kind, what)
             err = float((g - want).norm() / want.norm().clamp_min(1e-30))
             assert err <= 5e-5, "%s %s: f32 result off by %.3e (norm-wise)" % (kind, what, err)
-            self.worst[kind] = max(self.worst.get(kind, 0.0), err)
+            self.worst[kind + ' (f32: norm-wise error)'] = max(self.worst.get(kind + ' (f32: norm-wise error)', 0.0), err)
 
     def __call__(self, kind, a, out):
         put = self.put
@@ -354,6 +355,8 @@ class _Replay(object):
         elif kind == 'cast':
             self.same(kind, ops.cast(put(a['x'], a['s_from']), BF if a['s_to'] == 'b' else torch.float32), out, a['s_to'],
                       tuple(out.shape))
+        elif kind == 'grad_sum':                                # the framework's add of bf16 gradients: nothing of ours to replay
+            self.count[kind] = self.count.get(kind, 0) + 1
         else:
             raise AssertionError("unknown leaf %r" % kind)
 
@@ -376,9 +379,8 @@ def test_level6_every_operator_instance_of_the_step_against_the_emulation():
     sd = g.store.state_dict()
     det = {}
     W = emu.to_torch(sd)
-    with torch.no_grad():                                       # make the penalty active: scale the last layer
-        probe = {}
-        emu.losses(x, z, 1.0, r, W, g.filters, level, details=probe)
+    probe = {}                                                  # make the penalty active: scale the last layer
+    emu.losses(x, z, 1.0, r, W, g.filters, level, details=probe)
     W["GAN/discriminator/output/logits/kernel"] = (W["GAN/discriminator/output/logits/kernel"].detach()
                                                    * (3.0 / float(probe["grad_norm"].min()))).requires_grad_(True)
     d_vars, g_vars = g.get_training_variables(level)
@@ -393,8 +395,7 @@ def test_level6_every_operator_instance_of_the_step_against_the_emulation():
         emu.OBSERVER = None
     assert float(det["grad_norm"].min()) > 1.05
     print("level 6 operator instances replayed:", dict(sorted(rp.count.items())))
-    print("worst per kind (bf16 results: identical fraction; f32 results: norm-wise error):",
-          {k: float("%.4g" % v) for k, v in sorted(rp.worst.items())})
+    print("worst per kind:", {k: float("%.4g" % v) for k, v in sorted(rp.worst.items())})
     c = rp.count
     assert c["conv_act"] >= 3 * 14 + 15 and c["dgrad"] >= 60 and c["wgrad"] >= 60 and c["conv"] >= 14
     assert c["pixelnorm_bwd2"] == 2 and c["pixelnorm"] >= 17 and c["pool"] >= 18 and c["bcast"] >= 18 and c["act_bwd"] >= 60
