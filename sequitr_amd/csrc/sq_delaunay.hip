@@ -83,7 +83,7 @@ inline long long orient_real(const Pt &a, const Pt &b, const Pt &c) {   // all t
 }
 // > 0: d strictly inside the circle through the counter-clockwise a, b, c.  Exact: with every coordinate below 2^15 the
 // 2x2 minors fit 64 bits (differences < 2^16, squared lengths < 2^33, minors < 2^51) and only the last three products
-// need 128; a triangle with a super vertex takes the all-128-bit form.
+// need 128; a triangle with a super vertex takes the symbolic form (in_circle_sym).
 template <bool TINY>
 inline bool in_circle(const Pt &a, const Pt &b, const Pt &c, const Pt &d, bool real) {
     if (TINY && real) {
@@ -105,6 +105,60 @@ inline bool in_circle(const Pt &a, const Pt &b, const Pt &c, const Pt &d, bool r
     return det > 0;
 }
 
+// ---- the three super vertices are AT INFINITY, symbolically ------------------------------------------------------------
+// Super vertex k sits at M * SUPER_DIR[k] for an M larger than any number that occurs: a predicate with super vertices is a
+// polynomial in M with exact integer coefficients and its sign is the sign of the highest non-zero coefficient.  (Round 3
+// used a finite M = 2^30: a hull sliver whose circumradius exceeded it -- area-1/2 lattice triples with edges beyond ~1000
+// pixels -- had a super vertex inside its circumcircle and was dropped; tiles of 512 pixels were not affected.)
+const long long SUPER_DIR[3][2] = {{-1, -1}, {1, -1}, {0, 1}};
+struct PolyM {                      // c[k] M^k, k <= 6
+    i128 c[7];
+    PolyM() { for (int k = 0; k < 7; ++k) c[k] = 0; }
+    PolyM(i128 c0, i128 c1 = 0, i128 c2 = 0) { for (int k = 0; k < 7; ++k) c[k] = 0; c[0] = c0; c[1] = c1; c[2] = c2; }
+    int sign() const {
+        for (int k = 6; k >= 0; --k)
+            if (c[k] != 0) return c[k] > 0 ? 1 : -1;
+        return 0;
+    }
+};
+inline PolyM operator*(const PolyM &a, const PolyM &b) {
+    PolyM r;
+    for (int i = 0; i < 7; ++i) {
+        if (a.c[i] == 0) continue;
+        for (int j = 0; i + j < 7; ++j) r.c[i + j] += a.c[i] * b.c[j];
+    }
+    return r;
+}
+inline PolyM operator-(const PolyM &a, const PolyM &b) {
+    PolyM r;
+    for (int k = 0; k < 7; ++k) r.c[k] = a.c[k] - b.c[k];
+    return r;
+}
+inline PolyM operator+(const PolyM &a, const PolyM &b) {
+    PolyM r;
+    for (int k = 0; k < 7; ++k) r.c[k] = a.c[k] + b.c[k];
+    return r;
+}
+// coordinate `axis` of vertex i (real: p[i]; super: M * direction) minus the real point q's, as a polynomial in M
+inline PolyM rel(const std::vector<Pt> &p, int n, int i, int axis, const Pt &q) {
+    const long long qv = axis ? q.y : q.x;
+    if (i < n) return PolyM((i128)((axis ? p[i].y : p[i].x) - qv));
+    return PolyM((i128)(-qv), (i128)SUPER_DIR[i - n][axis]);
+}
+// sign of orient(a, b, q), q real, a / b real or super
+inline int orient_sym(const std::vector<Pt> &p, int n, int ia, int ib, const Pt &q) {
+    // orient(a, b, q) = (a - q) x (b - q)
+    const PolyM ax = rel(p, n, ia, 0, q), ay = rel(p, n, ia, 1, q), bx = rel(p, n, ib, 0, q), by = rel(p, n, ib, 1, q);
+    return (ax * by - ay * bx).sign();
+}
+// q strictly inside the circle through the counter-clockwise (a, b, c), at least one of them a super vertex
+inline bool in_circle_sym(const std::vector<Pt> &p, int n, int ia, int ib, int ic, const Pt &q) {
+    const PolyM ax = rel(p, n, ia, 0, q), ay = rel(p, n, ia, 1, q), bx = rel(p, n, ib, 0, q), by = rel(p, n, ib, 1, q),
+                cx = rel(p, n, ic, 0, q), cy = rel(p, n, ic, 1, q);
+    const PolyM a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+    return (ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx)).sign() > 0;
+}
+
 struct Tri {
     int v[3];          // counter-clockwise
     int n[3];          // n[i]: triangle across the edge opposite v[i] (-1: none)
@@ -116,7 +170,6 @@ struct Tri {
 template <bool TINY>
 bool delaunay_t(const int32_t *xy, int n, std::vector<int> &out) {
     if (n < 3) return true;
-    const long long M = (long long)1 << 28;                     // super triangle: beyond every circumcircle that can border the hull
     // insertion order: along a Z curve, so that the next point is next to the last one and the walk stays short (scan
     // order jumps from cell to cell along a row: ~100 triangles per walk); vertex indices below are positions in `p`,
     // mapped back through `order` on output
@@ -133,9 +186,7 @@ bool delaunay_t(const int32_t *xy, int n, std::vector<int> &out) {
     std::sort(order.begin(), order.end(), [&](int a, int b) { return keys[a] < keys[b]; });
     std::vector<Pt> p(n + 3);
     for (int i = 0; i < n; ++i) p[i] = {xy[2 * order[i]], xy[2 * order[i] + 1]};
-    p[n] = {-4 * M, -4 * M};
-    p[n + 1] = {4 * M, -4 * M};
-    p[n + 2] = {0, 4 * M};
+    p[n] = p[n + 1] = p[n + 2] = {0, 0};                        // never read: super vertices are symbolic (orient_sym / in_circle_sym)
     std::vector<Tri> t;
     t.reserve(2 * n + 16);
     t.push_back({{n, n + 1, n + 2}, {-1, -1, -1}, true});
@@ -155,7 +206,7 @@ bool delaunay_t(const int32_t *xy, int n, std::vector<int> &out) {
             bool leave = false;
             for (int i = 0; i < 3; ++i) {
                 const int ia = c.v[(i + 1) % 3], ib = c.v[(i + 2) % 3];
-                const bool neg = (ia < n && ib < n) ? orient_real(p[ia], p[ib], q) < 0 : orient(p[ia], p[ib], q) < 0;
+                const bool neg = (ia < n && ib < n) ? orient_real(p[ia], p[ib], q) < 0 : orient_sym(p, n, ia, ib, q) < 0;
                 if (neg) { go = c.n[i]; leave = true; break; }
             }
             if (!leave) break;
@@ -177,7 +228,9 @@ bool delaunay_t(const int32_t *xy, int n, std::vector<int> &out) {
             for (int i = 0; i < 3; ++i) {
                 const int m = t[k].n[i];
                 if (m < 0 || mark[m] == stamp) continue;
-                if (in_circle<TINY>(p[t[m].v[0]], p[t[m].v[1]], p[t[m].v[2]], q, t[m].v[0] < n && t[m].v[1] < n && t[m].v[2] < n)) {
+                const bool real = t[m].v[0] < n && t[m].v[1] < n && t[m].v[2] < n;
+                if (real ? in_circle<TINY>(p[t[m].v[0]], p[t[m].v[1]], p[t[m].v[2]], q, true)
+                         : in_circle_sym(p, n, t[m].v[0], t[m].v[1], t[m].v[2], q)) {
                     mark[m] = stamp;
                     stack.push_back(m);
                 }
@@ -201,7 +254,7 @@ bool delaunay_t(const int32_t *xy, int n, std::vector<int> &out) {
         bnd_new.assign(nb, -1);
         for (int e = 0; e < nb; ++e) {
             // the cavity is star-shaped round q: never (64-bit where no super vertex is involved)
-            if ((bnd_a[e] < n && bnd_b[e] < n) ? orient_real(p[bnd_a[e]], p[bnd_b[e]], q) <= 0 : orient(p[bnd_a[e]], p[bnd_b[e]], q) <= 0)
+            if ((bnd_a[e] < n && bnd_b[e] < n) ? orient_real(p[bnd_a[e]], p[bnd_b[e]], q) <= 0 : orient_sym(p, n, bnd_a[e], bnd_b[e], q) <= 0)
                 return false;
             int id;
             if (!freelist.empty()) { id = freelist.back(); freelist.pop_back(); }

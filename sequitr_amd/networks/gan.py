@@ -271,6 +271,10 @@ class GenerativeAdverserialNetwork(object):
         self._pack_epoch = -1
         self._gflat, self._gsinks = None, None                  # flat gradient buffer + per-parameter sinks (dtype 'bf16')
         self._capture_stream = None
+        # every workspace this network's launches use (split reductions, grouped weight-gradient partials) comes from ITS
+        # arena: captured solver graphs bake the buffer's address, so it must not be the library-wide default that any other
+        # object may grow or use from another stream (ops.WorkspaceArena)
+        self.arena = ops.WorkspaceArena('GAN')
         self.dtype = params.get('dtype', 'f32')
         if self.dtype not in ('f32', 'bf16', 'mixed'):
             raise ValueError("dtype must be 'f32', 'bf16' or 'mixed', got %r" % (self.dtype,))
@@ -518,7 +522,7 @@ class GenerativeAdverserialNetwork(object):
     def d_solver(self, X, Z, alpha, r=None):
         """d_opt.minimize(d_loss, var_list=d_vars) for the current level (gan.py:649)."""
         try:
-            with self.precision(), F.fuse_act_gates(self._act_gates()):
+            with self.precision(), F.fuse_act_gates(self._act_gates()), ops.use_arena(self.arena):
                 if self._graphable(alpha) and r is None:
                     return self._solver_graphed('d', X, Z, alpha)
                 return self._d_solver(X, Z, alpha, r)
@@ -528,7 +532,7 @@ class GenerativeAdverserialNetwork(object):
     def g_solver(self, X, Z, alpha):
         """g_opt.minimize(g_loss, var_list=g_vars, global_step) for the current level (gan.py:650-651)."""
         try:
-            with self.precision(), F.fuse_act_gates(self._act_gates()):
+            with self.precision(), F.fuse_act_gates(self._act_gates()), ops.use_arena(self.arena):
                 if self._graphable(alpha):
                     return self._solver_graphed('g', X, Z, alpha)
                 return self._g_solver(X, Z, alpha)
@@ -617,6 +621,7 @@ class GenerativeAdverserialNetwork(object):
                 self._capture_stream = torch.cuda.Stream(device=self.device)
             self._pack_filters()                                # the packs are launched in FRONT of the graph, by staleness (below)
             torch.cuda.synchronize(self.device)
+            self.arena.hand_over(self._capture_stream)          # eager step's stream -> the capture stream
             g_grad, g_adam = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_grad, stream=self._capture_stream):
                 named, grads, losses = self._d_grads(sx, sz, sa, sr) if kind == 'd' else self._g_grads(sx, sz, sa)
@@ -635,6 +640,7 @@ class GenerativeAdverserialNetwork(object):
         if sr is not None:
             sr.copy_(self._mixing_r(X.shape[0]))
         self._pack_filters()                                    # whichever network's weights moved since its packs were made
+        self.arena.hand_over()                                  # the replay's launches use the arena on THIS stream
         g_grad.replay()
         self._allreduce(grads)
         g_adam.replay()

@@ -69,3 +69,19 @@ def test_degenerate_inputs():
     assert len(simp) == 1 and simp[0, 0] == 1                                  # collinear set: no triangle; the other tile has one
     with pytest.raises(Exception, match="out of range|could not be triangulated"):
         triangulate([np.array([[0, 0], [40000, 1], [2, 7]])])
+
+
+@pytest.mark.parametrize("k", [1000, 2000, 8000, 16000])
+def test_hull_slivers_with_huge_circumcircles_are_kept(k):
+    """the chain (0,0), (k,1), (2k-1,2) is an area-1/2 lattice triple with a circumradius of ~k^2 / 2 (up to 2^27 here,
+    beyond any finite super triangle round 3 could have used).  The super vertices are symbolic now: the triangles must tile
+    the convex hull exactly and agree with scipy's count."""
+    rng = np.random.default_rng(k)
+    inner = np.column_stack((rng.integers(1, 2 * k - 2, 40), rng.integers(3, 60, 40)))
+    pts = np.unique(np.concatenate([np.array([[0, 0], [k, 1], [2 * k - 1, 2]]), inner]), axis=0)
+    simp, _ = triangulate([pts])
+    tri = simp[:, 1:].reshape(-1, 3, 2).astype(object)
+    area2 = sum(abs((t[1][0] - t[0][0]) * (t[2][1] - t[0][1]) - (t[1][1] - t[0][1]) * (t[2][0] - t[0][0])) for t in tri)
+    assert area2 == round(2 * ConvexHull(pts).volume)
+    assert len(tri) == len(Delaunay(pts).simplices)
+    assert canon(simp) == set(tuple(sorted(map(tuple, pts[s].tolist()))) for s in Delaunay(pts).simplices)
