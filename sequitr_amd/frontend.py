@@ -9,6 +9,8 @@ Tiling (build-defined: the reference only ever crops fixed-size tiles, pipeline.
 length L, tiles of size T start at 0, T-2m, 2(T-2m), ... and the last one at L-T; every pixel is owned by the
 tile in which it lies at least `m` (margin) pixels from the tile border, except at the frame border.
 """
+import time
+
 import numpy as np
 import torch
 
@@ -229,8 +231,39 @@ class TileStreamer(object):
         self.pin_mask = [_pinned('ts_mask%d' % i, (B, H, W), torch.uint8) for i in range(2)]
         self.pin_logits = ([_pinned('ts_logits%d' % i, (B, H, W, n_out), torch.float32) for i in range(2)]
                            if self.want_logits else None)
-        self.s_in, self.s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.s_in = self.s_out = None                              # picked by warm_up / the first run (_pick_streams)
         self._shape = (tuple(tile_shape), n_out)
+
+    def _pick_streams(self):
+        """Copy streams whose transfers really run UNDER the network's kernels.  HIP spreads its streams over a few
+        hardware queues; a copy stream that lands on the compute stream's queue is executed in order with the kernels and
+        the pipeline falls back to the serial rate (measured on MI355X: the same three-stream loop ran at 5.45 or 6.1 ms
+        per batch depending on which streams a fresh torch.cuda.Stream() happened to be).  So: candidates are tried --
+        one batch of the network on the compute stream, an upload enqueued behind it on the candidate -- and a candidate
+        is kept when its copy finished well before the network did."""
+        dev, net = self.net.device, self.net
+        main = torch.cuda.current_stream(dev)
+        good, tried = [], []
+        self.dev_in[0].zero_()
+        for _ in range(12):
+            cand = torch.cuda.Stream(device=dev)
+            tried.append(cand)
+            e0, e1, ec = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            cand.wait_stream(main)
+            e0.record(main)
+            net.predict(self.dev_in[0])
+            e1.record(main)
+            with torch.cuda.stream(cand):
+                self.dev_in[1].copy_(self.pin_in[1], non_blocking=True)
+                ec.record(cand)
+            torch.cuda.synchronize(dev)
+            if e0.elapsed_time(ec) < 0.6 * e0.elapsed_time(e1):
+                good.append(cand)
+                if len(good) == 2:
+                    break
+        self.overlap_found = len(good)
+        pick = good + [c for c in tried if c not in good]
+        self.s_in, self.s_out = pick[0], pick[1]
 
     def warm_up(self, tile_shape):
         """allocate the staging buffers and run one batch of zeros through the network (first-launch costs:
@@ -239,6 +272,11 @@ class TileStreamer(object):
         self.dev_in[0].zero_()
         self.net.predict(self.dev_in[0])
         torch.cuda.synchronize(self.net.device)
+        if self.s_in is None:
+            self._pick_streams()
+        self.pin_in[0].zero_()
+        for _ in range(3):                                        # the stream's own allocations (masks held across batches) settle
+            self.run(self.pin_in[0])
 
     def run(self, tiles, out_masks=None, out_logits=None, pipe=None, on_batch=None):
         """tiles: (N,H,W,C) float32-convertible numpy array / memmap, or a pinned CPU float32 tensor.
@@ -265,6 +303,8 @@ class TileStreamer(object):
         if nb == 0:
             return out_masks, out_logits
         main = torch.cuda.current_stream(dev)
+        if self.s_in is None:
+            self._pick_streams()
         s_in, s_out = self.s_in, self.s_out
         up = [torch.cuda.Event() for _ in range(2)]              # H2D into dev_in[k] finished
         used = [torch.cuda.Event() for _ in range(2)]            # predict has consumed dev_in[k]
@@ -273,12 +313,19 @@ class TileStreamer(object):
             e.record(main)
         pool = ThreadPoolExecutor(self.workers + 1)
 
+        def wait_for(ev):
+            """host wait WITHOUT a blocking runtime call: a hipEventSynchronize in a worker thread keeps the launching
+            thread's next enqueue waiting until the event has fired (measured: the pipeline then runs at the serial
+            rate), so workers poll"""
+            while not ev.query():
+                time.sleep(1e-4)
+
         def count(b):
             return min(B, N - b * B)
 
         def stage_part(b, lo, hi):
             k, first = b & 1, b * B
-            up[k].synchronize()                                   # batch b-2 has left this pinned buffer
+            wait_for(up[k])                                       # batch b-2 has left this pinned buffer
             dst = self.pin_in[k].numpy()
             if pipe is None:
                 np.copyto(dst[lo:hi], tiles[first + lo:first + hi], casting='unsafe')
@@ -296,13 +343,18 @@ class TileStreamer(object):
 
         def drain(b):
             k, n, first = b & 1, count(b), b * B
-            down[k].synchronize()
+            wait_for(down[k])
             out_masks[first:first + n] = self.pin_mask[k][:n].numpy()
             if self.want_logits:
                 out_logits[first:first + n] = self.pin_logits[k][:n].numpy()
 
         staged = {0: stage(0), 1: None}
         drains = {}
+        # the device tensors a download reads are kept alive HERE until the download has been drained, instead of
+        # Tensor.record_stream: with record_stream the caching allocator cannot hand a freed mask block back until it has
+        # polled the copy stream's event, allocates fresh blocks for a while (hipMalloc synchronises the device) and the
+        # pipeline runs at the serial rate for its first dozens of batches
+        held = [None, None]
         try:
             for b in range(nb):
                 k, n = b & 1, count(b)
@@ -323,19 +375,19 @@ class TileStreamer(object):
                 done.record(main)
                 if b >= 2:
                     drains.pop(b - 2).result()                    # the host has emptied the pinned outputs [k]
+                held[k] = (mask, logits)                          # (batch b-2's tensors go: their download is over)
                 with torch.cuda.stream(s_out):
                     s_out.wait_event(done)
                     self.pin_mask[k][:n].copy_(mask, non_blocking=True)
-                    mask.record_stream(s_out)
                     if logits is not None:
                         self.pin_logits[k][:n].copy_(logits, non_blocking=True)
-                        logits.record_stream(s_out)
                     down[k].record(s_out)
                 drains[b] = pool.submit(drain, b)
                 if on_batch is not None:
                     on_batch(b * B, mask)
             for b in sorted(drains):
                 drains[b].result()
+            held[:] = [None, None]
         finally:
             pool.shutdown(wait=True)
             torch.cuda.synchronize(dev)
