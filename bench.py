@@ -1209,9 +1209,14 @@ def gan_line(args, world, rank, dist, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
+    shared_g = os.environ.get("SQ_GAN_SHARED_G", "1") != "0"     # A/B: 0 = the two solver calls, each with its own generator pass
+
     def it():
-        g.d_solver(X, Z, 1.0)
-        g.g_solver(X, Z, 1.0)
+        if shared_g:
+            g.iteration(X, Z, 1.0)                              # d_solver + g_solver on one feed, ONE generator forward pass
+        else:
+            g.d_solver(X, Z, 1.0)
+            g.g_solver(X, Z, 1.0)
 
     with WorkCounter(sq_ops) as wc:    # the first iteration is eager in every mode (it warms the graphs up): count it
         it()
@@ -1270,7 +1275,9 @@ def gan_line(args, world, rank, dist, dev):
                                                "convolutions, f32 parameters / images / losses",
                                        "mixed": "f32 tensors, bf16-multiply / f32-accumulate convolutions",
                                        "f32": "fp32"}[args.dtype] +
-                                      ("; hipGraph replay" if args.graph else "; eager launches"),
+                                      ("; hipGraph replay" if args.graph else "; eager launches") +
+                                      ("; one generator forward pass per iteration, shared by the two solver steps"
+                                       if shared_g else "; each solver step runs its own generator pass"),
                           "d_loss": g.last_losses[0], "g_loss": g.last_losses[1]},
                "roofline": rl}
         if not args.no_cpu_baseline and world == 1:

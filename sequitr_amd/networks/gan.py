@@ -441,31 +441,40 @@ class GenerativeAdverserialNetwork(object):
     def _mixing_r(self, n):
         return torch.rand((n,), generator=self._torch_rng, dtype=torch.float32, device=self.device)
 
-    def _prepare(self, X, Z, alpha, need_g_graph):
-        """Forward of gan.py:665-714 up to the three discriminator inputs."""
+    def _generated(self, Z, alpha):
+        """generator half of gan.py:665-694: (Gz_raw, Gz) -- the current level's image and its fade-in blend with the
+        up-sampled image of the level below -- with the generator's tape attached"""
         num_layers = self.current_level
         filters = self.filters[:(num_layers + 1)]
         g_layers, Gz_raw = self.generator(Z, filters, **({'levels': (-2, -1)} if self._default_g else {}))
+        Gz = F.lerp(Gz_raw, double_size(g_layers[-2]), alpha) if num_layers > 0 else Gz_raw
+        return Gz_raw, Gz
+
+    def _real(self, X, alpha):
+        """real half: X faded with its own half-resolution copy (gan.py:682-691)"""
         if tuple(X.shape[1:3]) != tuple(self.current_size):
             raise ValueError('X must already be at the current size %s (bilinear resize of the real '
                              'data is host-side IO, gan.py:682-684)' % (self.current_size,))
-        X_resized = X
-        if num_layers > 0:
-            prev_Gz = double_size(g_layers[-2])
-            Gz = F.lerp(Gz_raw, prev_Gz, alpha)
-            prev_X = ops.broadcast2x2(half_size(X_resized), 1.0)
-            X_resized = ops.lerp(X_resized, prev_X, alpha)
-        else:
-            Gz = Gz_raw
+        if self.current_level == 0:
+            return X
+        return ops.lerp(X, ops.broadcast2x2(half_size(X), 1.0), alpha)
+
+    def _prepare(self, X, Z, alpha, need_g_graph, generated=None, want_real=True):
+        """Forward of gan.py:665-714 up to the three discriminator inputs.  generated: a (Gz_raw, Gz) pair evaluated
+        earlier with the same Z, alpha and generator weights (iteration() shares one generator pass between the two
+        solver steps); want_real=False: the generator step never reads X."""
+        filters = self.filters[:(self.current_level + 1)]
+        Gz_raw, Gz = generated if generated is not None else self._generated(Z, alpha)
+        X_resized = self._real(X, alpha) if want_real else None
         if not need_g_graph:
             Gz = Gz.detach()
         return filters[::-1], Gz_raw, Gz, X_resized
 
-    def _build_network(self, X, Z, alpha, r=None, need_g_graph=True):
+    def _build_network(self, X, Z, alpha, r=None, need_g_graph=True, generated=None):
         """Losses of the current level (gan.py:665-732): returns (Gz_raw, d_loss, g_loss) with the
         autograd graph attached (d_loss w.r.t. the discriminator, g_loss w.r.t. the generator
         unless need_g_graph is False -- the discriminator step never needs it)."""
-        d_filters, Gz_raw, Gz, X_resized = self._prepare(X, Z, alpha, need_g_graph=need_g_graph)
+        d_filters, Gz_raw, Gz, X_resized = self._prepare(X, Z, alpha, need_g_graph=need_g_graph, generated=generated)
         if self.batch_d and self._default_d:
             # D(Gz) and D(X) as ONE pass over the stacked minibatches (own minibatch statistic each): the same
             # per-sample arithmetic, a third fewer launches of the small deep layers in forward and backward
@@ -539,6 +548,97 @@ class GenerativeAdverserialNetwork(object):
         finally:
             self._weights_moved('g')
 
+    def iteration(self, X, Z, alpha, r=None):
+        """d_solver(X, Z, alpha) followed by g_solver(X, Z, alpha) -- one pass of the reference's inner loop
+        (gan.py:848-851: the same feed runs d_solver, then g_solver) -- with ONE generator forward pass: the
+        discriminator step moves only discriminator weights, so the generator pass the generator step would repeat is the
+        one the discriminator step has just evaluated, bit for bit (TensorFlow evaluates it once per session.run, i.e.
+        twice).  The discriminator step reads it detached; the generator step differentiates through the kept tape.  Same
+        losses, same weights as the two calls (tests/test_gpu_gan.py); 45 launches and ~0.4 ms fewer at level 6.
+        Returns (d_loss, g_loss) device scalars."""
+        try:
+            with self.precision(), F.fuse_act_gates(self._act_gates()), ops.use_arena(self.arena):
+                if self._graphable(alpha) and r is None:
+                    return self._iteration_graphed(X, Z, alpha)
+                return self._iteration(X, Z, alpha, r)
+        finally:
+            self._weights_moved('d')
+            self._weights_moved('g')
+
+    def _iteration(self, X, Z, alpha, r=None):
+        self._pack_filters()
+        generated = self._generated(Z, alpha)
+        d_vars, grads, losses = self._d_grads(X, Z, alpha, r, generated=generated)
+        scale = self._allreduce(grads)
+        self.d_opt.apply(d_vars, grads, grad_scale=scale)
+        self._last_losses = losses
+        self._weights_moved('d')
+        self._pack_filters()                                    # the discriminator's packs follow its new weights
+        g_vars, ggrads, glosses = self._g_grads(X, Z, alpha, generated=generated)
+        scale = self._allreduce(ggrads)
+        self.g_opt.apply(g_vars, ggrads, grad_scale=scale)
+        self.global_step += 1
+        return losses[0], glosses[0]
+
+    def _iteration_graphed(self, X, Z, alpha):
+        """iteration() as four hipGraphs: (generator forward + discriminator gradients), (Adam D), (D(Gz) forward + generator
+        gradients through the FIRST graph's generator tape), (Adam G); filter packs and the two all-reduces between them,
+        outside any capture.  Call 1 is eager (warm-up), call 2 captures, later calls replay."""
+        key = ('it', self.current_level, tuple(X.shape), tuple(Z.shape))
+        entry = self._graphs.get(key)
+        if entry is None:
+            self._graphs[key] = 'warm'
+            return self._iteration(X, Z, alpha)
+        if entry == 'warm':
+            sx, sz = X.clone(), Z.clone()
+            sa = torch.full((X.shape[0],), float(alpha), dtype=torch.float32, device=self.device)
+            self._graph_alpha[key] = float(alpha)
+            sr = torch.empty((X.shape[0],), dtype=torch.float32, device=self.device)
+            if self._capture_stream is None:
+                self._capture_stream = torch.cuda.Stream(device=self.device)
+            self._pack_filters()
+            torch.cuda.synchronize(self.device)
+            self.arena.hand_over(self._capture_stream)
+            gd, ad, gg, ag = (torch.cuda.CUDAGraph() for _ in range(4))
+            with torch.cuda.graph(gd, stream=self._capture_stream):
+                generated = self._generated(sz, sa)
+                d_named, d_grads, d_losses = self._d_grads(sx, sz, sa, sr, generated=generated)
+            td, tg = self.d_opt.t, self.g_opt.t
+            d_table = self.d_opt.table(d_named, d_grads)
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(ad, stream=self._capture_stream, pool=gd.pool()):
+                self.d_opt.apply(d_named, d_grads, grad_scale=1.0 / self._world(), table=d_table)
+            with torch.cuda.graph(gg, stream=self._capture_stream, pool=gd.pool()):
+                g_named, g_grads, g_losses = self._g_grads(sx, sz, sa, generated=generated)
+            g_table = self.g_opt.table(g_named, g_grads)
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(ag, stream=self._capture_stream, pool=gd.pool()):
+                self.g_opt.apply(g_named, g_grads, grad_scale=1.0 / self._world(), table=g_table)
+            self.d_opt.t, self.g_opt.t = td, tg                 # the captures executed nothing
+            del generated                                       # (the generator step's tape has been consumed by its capture)
+            entry = self._graphs[key] = (gd, ad, gg, ag, sx, sz, sa, sr, d_grads, g_grads, d_losses, g_losses, d_table, g_table)
+        gd, ad, gg, ag, sx, sz, sa, sr, d_grads, g_grads, d_losses, g_losses = entry[:12]
+        sx.copy_(X), sz.copy_(Z)
+        if self._graph_alpha.get(key) != float(alpha):
+            sa.fill_(float(alpha))
+            self._graph_alpha[key] = float(alpha)
+        sr.copy_(self._mixing_r(X.shape[0]))
+        self._pack_filters()
+        self.arena.hand_over()
+        gd.replay()
+        self._allreduce(d_grads)
+        ad.replay()
+        self.d_opt.t += 1
+        self._last_losses = d_losses
+        self._weights_moved('d')
+        self._pack_filters()                                    # the discriminator's packs, restaged in front of the generator step
+        gg.replay()
+        self._allreduce(g_grads)
+        ag.replay()
+        self.g_opt.t += 1
+        self.global_step += 1
+        return d_losses[0], g_losses[0]
+
     # -- parameter gradients through sinks (bf16 storage): grouped weight-gradient launches, no framework adds -------------
     def _param_grads(self, loss, named):
         """torch.autograd.grad(loss, variables) for a solver step.  dtype 'bf16': the weight gradients of the bf16 feature
@@ -565,15 +665,15 @@ class GenerativeAdverserialNetwork(object):
         return tuple(grads)
 
     # the two halves of a solver step: (losses + gradients) and (Adam); the all-reduce sits between them
-    def _d_grads(self, X, Z, alpha, r):
+    def _d_grads(self, X, Z, alpha, r, generated=None):
         d_vars, _ = self.get_training_variables(self.current_level)
-        _, d_loss, g_loss = self._build_network(X, Z, alpha, r=r, need_g_graph=False)
+        _, d_loss, g_loss = self._build_network(X, Z, alpha, r=r, need_g_graph=False, generated=generated)
         grads = self._param_grads(d_loss, d_vars)               # not the block d_vars leaves out
         return d_vars, grads, (d_loss.detach(), g_loss.detach())
 
-    def _g_grads(self, X, Z, alpha):
+    def _g_grads(self, X, Z, alpha, generated=None):
         _, g_vars = self.get_training_variables(self.current_level)
-        d_filters, _, Gz, _ = self._prepare(X, Z, alpha, need_g_graph=True)
+        d_filters, _, Gz, _ = self._prepare(X, Z, alpha, need_g_graph=True, generated=generated, want_real=False)
         _, Dz = self.discriminator(Gz, d_filters)
         _, g_loss = F.wgan_losses(Dz)
         grads = self._param_grads(g_loss, g_vars)               # the pass runs THROUGH the discriminator: none of its weights
@@ -717,8 +817,7 @@ class GenerativeAdverserialNetwork(object):
                     z, x = self.build_latent(), self._next_real_batch(step_id)
                     step_id += 1
                     for _ in range(self.repeat_batch):
-                        self.d_solver(x, z, fade)
-                        self.g_solver(x, z, fade)
+                        self.iteration(x, z, fade)              # d_solver then g_solver on the same feed, one generator pass
                     logger.info('{0} {1} {2} {3}'.format(self.global_step, phase, self.get_size(n), fade))
             if self.output_dir:
                 np.savez(os.path.join(self.output_dir, self.checkpoint_name(n)), **self.store.state_dict())

@@ -539,6 +539,34 @@ def test_act_gate_fusion_gives_the_same_bits(dtype):
     assert not F.FUSE_ACT_GATES
 
 
+@pytest.mark.parametrize("dtype,graph", [("f32", False), ("bf16", False), ("bf16", True)])
+def test_iteration_shares_the_generator_pass_and_equals_the_two_solver_calls(dtype, graph):
+    """GenerativeAdverserialNetwork.iteration(X, Z, alpha): d_solver + g_solver on one feed (gan.py:848-851) with ONE generator
+    forward pass -- the discriminator step does not move generator weights, so the pass the generator step repeats is the
+    one already evaluated.  Weights and losses after three iterations (fade and stabilisation alphas) are bit-identical to
+    the separate calls, eager and as replayed hipGraphs (call 1 eager, call 2 captures, call 3 replays)."""
+    rng = np.random.default_rng(21)
+    feeds = [(dev(rng.standard_normal((4, 16, 16, 2)).astype(np.float32)), dev(rng.standard_normal((4, 1, 1, 512)).astype(np.float32)))
+             for _ in range(4)]
+    alphas = (0.5, 1.0, 1.0, 0.75)
+
+    def run(shared):
+        g = make_gan(dtype=dtype, graph=graph)
+        g.set_level(2)
+        out = []
+        for (x, z), a in zip(feeds, alphas):
+            if shared:
+                d, gl = g.iteration(x, z, a)
+            else:
+                d, gl = g.d_solver(x, z, a), g.g_solver(x, z, a)
+            out.append((float(d), float(gl)))
+        return g.store.state_dict(), out, g.global_step
+    (wa, la, sa), (wb, lb, sb) = run(True), run(False)
+    assert la == lb and sa == sb == 4
+    for k in wa:
+        assert np.array_equal(wa[k], wb[k]), k
+
+
 @pytest.mark.parametrize("dtype,level", [("f32", 0), ("f32", 2), ("bf16", 2)])
 def test_act_gates_with_an_active_penalty_give_the_ungated_gradients(dtype, level):
     """Round 4 regression: with the WGAN-GP penalty ACTIVE (|dD(mix)/dmix| > 1) the second-order pass sends from_image's
