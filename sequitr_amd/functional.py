@@ -640,26 +640,34 @@ def dot_per_sample(a, b):
     return _DotPerSample.apply(a, b)
 
 
-def lerp(a, b, alpha):
+def lerp(a, b, alpha, out=None):
     """alpha*a + (1-alpha)*b with scalar alpha (fade-in, gan.py:687-694) or a per-sample (N,)
-    tensor (r of gan.py:709-714).  One fused kernel forward; gradients are per-sample scalings."""
+    tensor (r of gan.py:709-714).  One fused kernel forward; gradients are per-sample scalings.
+    out: destination the result is written into (a contiguous view, e.g. the first half of a stacked batch)."""
     if not isinstance(alpha, torch.Tensor):
         alpha = torch.full((a.shape[0],), float(alpha), dtype=torch.float32, device=a.device)
-    return _Lerp.apply(a, b, alpha)
+    return _Lerp.apply(a, b, alpha, None if out is None else [out])
 
 
 class _Lerp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b, alpha):
+    def forward(ctx, a, b, alpha, out=None):
         ctx.save_for_backward(alpha)
-        return ops.lerp(a.contiguous(), b.contiguous(), alpha)
+        if out is None:
+            return ops.lerp(a.contiguous(), b.contiguous(), alpha)
+        # `out` ([tensor], opaque to the tape): the caller's buffer is written, and what the tape sees is a NEW tensor over
+        # the same memory -- not a view of the buffer, so no in-place-on-a-view bookkeeping (CopySlices) enters the graph
+        dst = out[0]
+        ops.lerp(a.contiguous(), b.contiguous(), alpha, out=dst)
+        return torch.empty(0, dtype=dst.dtype, device=dst.device).set_(dst.untyped_storage(), dst.storage_offset(), dst.shape,
+                                                                       dst.stride())
 
     @staticmethod
     def backward(ctx, dy):
         (alpha,) = ctx.saved_tensors
         da = _ScalePerSample.apply(dy, alpha, False) if ctx.needs_input_grad[0] else None
         db = _ScalePerSample.apply(dy, alpha, True) if ctx.needs_input_grad[1] else None
-        return da, db, None
+        return da, db, None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -845,9 +853,17 @@ def mbstd_map(x, groups=1, cells=16):
 
 
 class _WganLosses(torch.autograd.Function):
+    """stacked_n > 0: `Dz` is the (2n,) output of ONE discriminator pass over the stacked [generated; real] minibatches
+    and Dx is None -- the two halves are read in place and the backward returns ONE (2n,) gradient (two sliced views
+    cost the tape two zero fills, two copies and an add)."""
+
     @staticmethod
-    def forward(ctx, Dz, Dx, gn2):
+    def forward(ctx, Dz, Dx, gn2, stacked_n):
+        ctx.set_materialize_grads(False)                        # an unused loss's gradient arrives as None, not as a filled zero
         Dz = Dz.contiguous()
+        ctx.stacked_n = stacked_n
+        if stacked_n:
+            Dz, Dx = Dz[:stacked_n], Dz[stacked_n:]
         Dx = Dx.contiguous() if Dx is not None else None
         gn2 = gn2.contiguous() if gn2 is not None else None
         ctx.save_for_backward(Dz, Dx, gn2)
@@ -858,12 +874,23 @@ class _WganLosses(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gd, gg):
         Dz, Dx, gn2 = ctx.saved_tensors
-        dDz, dDx, dgn2 = ops.wgan_losses_bwd(Dz, Dx, gn2, gd.contiguous() if gd is not None else None,
-                                             gg.contiguous() if gg is not None else None)
-        return dDz, dDx, dgn2
+        gd = gd.contiguous() if gd is not None else None
+        gg = gg.contiguous() if gg is not None else None
+        if ctx.stacked_n:
+            n = ctx.stacked_n
+            dall = torch.empty((2 * n,), dtype=Dz.dtype, device=Dz.device)
+            _, _, dgn2 = ops.wgan_losses_bwd(Dz, Dx, gn2, gd, gg, out_dz=dall[:n], out_dx=dall[n:])
+            return dall, None, dgn2, None
+        dDz, dDx, dgn2 = ops.wgan_losses_bwd(Dz, Dx, gn2, gd, gg)
+        return dDz, dDx, dgn2, None
 
 
 def wgan_losses(Dz, Dx=None, gn2=None):
     """(d_loss, g_loss) of gan.py:715-729 from the discriminator outputs and the per-sample squared gradient norm of
     D(mix); with Dz alone: (unused, g_loss = mean(-Dz))"""
-    return _WganLosses.apply(Dz, Dx, gn2)
+    return _WganLosses.apply(Dz, Dx, gn2, 0)
+
+
+def wgan_losses_stacked(Dzx, gn2):
+    """the same from the (2n,) output of one discriminator pass over [generated; real] stacked along the batch axis"""
+    return _WganLosses.apply(Dzx, None, gn2, Dzx.shape[0] // 2)

@@ -271,6 +271,7 @@ class GenerativeAdverserialNetwork(object):
         self._pack_epoch = -1
         self._gflat, self._gsinks = None, None                  # flat gradient buffer + per-parameter sinks (dtype 'bf16')
         self._capture_stream = None
+        self._ones_cache = {}
         # every workspace this network's launches use (split reductions, grouped weight-gradient partials) comes from ITS
         # arena: captured solver graphs bake the buffer's address, so it must not be the library-wide default that any other
         # object may grow or use from another stream (ops.WorkspaceArena)
@@ -438,50 +439,73 @@ class GenerativeAdverserialNetwork(object):
     def _build_optimizers(self, level=0):
         return _Adam(self.learning_rate, 0.0, 0.99), _Adam(self.learning_rate, 0.0, 0.99)
 
+    def _ones(self, n):
+        t = self._ones_cache.get(n)
+        if t is None:
+            t = self._ones_cache[n] = torch.ones((n,), dtype=torch.float32, device=self.device)
+        return t
+
     def _mixing_r(self, n):
         return torch.rand((n,), generator=self._torch_rng, dtype=torch.float32, device=self.device)
 
+    def _stacks(self):
+        """the discriminator step evaluates D on [generated; real] as one stacked batch: at levels > 0 both halves are the
+        outputs of blend kernels, which then write straight into the halves of ONE buffer (no concatenation pass)"""
+        return self.batch_d and self._default_d and self.current_level > 0
+
     def _generated(self, Z, alpha):
-        """generator half of gan.py:665-694: (Gz_raw, Gz) -- the current level's image and its fade-in blend with the
-        up-sampled image of the level below -- with the generator's tape attached"""
+        """generator half of gan.py:665-694: (Gz_raw, Gz, stacked) -- the current level's image, its fade-in blend with
+        the up-sampled image of the level below (the generator's tape attached), and the (2n, H, W, C) buffer whose first
+        half Gz occupies (None when the step does not stack)"""
         num_layers = self.current_level
         filters = self.filters[:(num_layers + 1)]
         g_layers, Gz_raw = self.generator(Z, filters, **({'levels': (-2, -1)} if self._default_g else {}))
-        Gz = F.lerp(Gz_raw, double_size(g_layers[-2]), alpha) if num_layers > 0 else Gz_raw
-        return Gz_raw, Gz
+        if num_layers == 0:
+            return Gz_raw, Gz_raw, None
+        stacked = None
+        if self._stacks():
+            n = Gz_raw.shape[0]
+            stacked = torch.empty((2 * n,) + tuple(Gz_raw.shape[1:]), dtype=torch.float32, device=self.device)
+        Gz = F.lerp(Gz_raw, double_size(g_layers[-2]), alpha, out=None if stacked is None else stacked[:Gz_raw.shape[0]])
+        return Gz_raw, Gz, stacked
 
-    def _real(self, X, alpha):
+    def _real(self, X, alpha, out=None):
         """real half: X faded with its own half-resolution copy (gan.py:682-691)"""
         if tuple(X.shape[1:3]) != tuple(self.current_size):
             raise ValueError('X must already be at the current size %s (bilinear resize of the real '
                              'data is host-side IO, gan.py:682-684)' % (self.current_size,))
         if self.current_level == 0:
             return X
-        return ops.lerp(X, ops.broadcast2x2(half_size(X), 1.0), alpha)
+        return ops.lerp(X, ops.broadcast2x2(half_size(X), 1.0), alpha, out=out)
 
     def _prepare(self, X, Z, alpha, need_g_graph, generated=None, want_real=True):
-        """Forward of gan.py:665-714 up to the three discriminator inputs.  generated: a (Gz_raw, Gz) pair evaluated
+        """Forward of gan.py:665-714 up to the three discriminator inputs.  generated: a _generated() result evaluated
         earlier with the same Z, alpha and generator weights (iteration() shares one generator pass between the two
-        solver steps); want_real=False: the generator step never reads X."""
+        solver steps); want_real=False: the generator step never reads X.  Returns (reversed filters, Gz_raw, Gz,
+        X_resized, stacked-or-None)."""
         filters = self.filters[:(self.current_level + 1)]
-        Gz_raw, Gz = generated if generated is not None else self._generated(Z, alpha)
-        X_resized = self._real(X, alpha) if want_real else None
+        Gz_raw, Gz, stacked = generated if generated is not None else self._generated(Z, alpha)
+        X_resized = None
+        if want_real:
+            X_resized = self._real(X, alpha, out=None if stacked is None else stacked[Gz.shape[0]:])
         if not need_g_graph:
             Gz = Gz.detach()
-        return filters[::-1], Gz_raw, Gz, X_resized
+        return filters[::-1], Gz_raw, Gz, X_resized, (stacked if want_real else None)
 
     def _build_network(self, X, Z, alpha, r=None, need_g_graph=True, generated=None):
         """Losses of the current level (gan.py:665-732): returns (Gz_raw, d_loss, g_loss) with the
         autograd graph attached (d_loss w.r.t. the discriminator, g_loss w.r.t. the generator
         unless need_g_graph is False -- the discriminator step never needs it)."""
-        d_filters, Gz_raw, Gz, X_resized = self._prepare(X, Z, alpha, need_g_graph=need_g_graph, generated=generated)
+        d_filters, Gz_raw, Gz, X_resized, stacked = self._prepare(X, Z, alpha, need_g_graph=need_g_graph, generated=generated)
         if self.batch_d and self._default_d:
             # D(Gz) and D(X) as ONE pass over the stacked minibatches (own minibatch statistic each): the same
             # per-sample arithmetic, a third fewer launches of the small deep layers in forward and backward
-            n = Gz.shape[0]
-            _, Dzx = self.discriminator(torch.cat([Gz, X_resized], 0), d_filters, groups=2)
-            Dz, Dx = Dzx[:n], Dzx[n:]
+            if stacked is None or need_g_graph:
+                stacked = torch.cat([Gz, X_resized], 0)         # level 0 (no blends), or a caller that differentiates Gz here
+            _, Dzx = self.discriminator(stacked, d_filters, groups=2)
+            Dz = Dx = None
         else:
+            Dzx = None
             _, Dz = self.discriminator(Gz, d_filters)
             _, Dx = self.discriminator(X_resized, d_filters)
         if r is None:
@@ -489,9 +513,11 @@ class GenerativeAdverserialNetwork(object):
         mix = F.lerp(X_resized, Gz.detach(), r).detach().requires_grad_(True)
         _, Dmix = self.discriminator(mix, d_filters)
         with F.grads_wanted([]):                                # the input gradient only: no weight / bias gradients
-            grad = torch.autograd.grad(Dmix.sum(), mix, create_graph=True)[0]
+            # d(sum Dmix)/dmix with the ones handed in (Dmix.sum() costs a reduction, its backward a fill and an expand)
+            grad = torch.autograd.grad(Dmix, mix, grad_outputs=self._ones(Dmix.shape[0]), create_graph=True)[0]
         # one-sided penalty 10 max(|grad| - 1, 0)^2, drift 0.001 Dx^2, the two means: one launch (sq_wgan_losses_*)
-        d_loss, g_loss = F.wgan_losses(Dz, Dx, F.dot_per_sample(grad, grad))
+        gn2 = F.dot_per_sample(grad, grad)
+        d_loss, g_loss = F.wgan_losses_stacked(Dzx, gn2) if Dzx is not None else F.wgan_losses(Dz, Dx, gn2)
         return Gz_raw, d_loss, g_loss
 
     def _allreduce(self, grads):
@@ -608,6 +634,11 @@ class GenerativeAdverserialNetwork(object):
             torch.cuda.synchronize(self.device)
             with torch.cuda.graph(ad, stream=self._capture_stream, pool=gd.pool()):
                 self.d_opt.apply(d_named, d_grads, grad_scale=1.0 / self._world(), table=d_table)
+            # recording Adam marked every pack stale; the generator step must be captured with FRESH plans, or every conv of
+            # it bakes an on-demand pack launch into the graph (the replay restages them in front of the graph, as here)
+            self._weights_moved('d')
+            self._pack_filters()
+            torch.cuda.synchronize(self.device)
             with torch.cuda.graph(gg, stream=self._capture_stream, pool=gd.pool()):
                 g_named, g_grads, g_losses = self._g_grads(sx, sz, sa, generated=generated)
             g_table = self.g_opt.table(g_named, g_grads)
@@ -673,7 +704,7 @@ class GenerativeAdverserialNetwork(object):
 
     def _g_grads(self, X, Z, alpha, generated=None):
         _, g_vars = self.get_training_variables(self.current_level)
-        d_filters, _, Gz, _ = self._prepare(X, Z, alpha, need_g_graph=True, generated=generated, want_real=False)
+        d_filters, _, Gz, _, _ = self._prepare(X, Z, alpha, need_g_graph=True, generated=generated, want_real=False)
         _, Dz = self.discriminator(Gz, d_filters)
         _, g_loss = F.wgan_losses(Dz)
         grads = self._param_grads(g_loss, g_vars)               # the pass runs THROUGH the discriminator: none of its weights

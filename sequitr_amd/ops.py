@@ -836,12 +836,18 @@ def resize_nearest(x, size):
     return y
 
 
-def lerp(a, b, alpha):
-    """alpha*a + (1-alpha)*b; alpha a python float or a per-sample (N,) device tensor."""
+def lerp(a, b, alpha, out=None):
+    """alpha*a + (1-alpha)*b; alpha a python float or a per-sample (N,) device tensor.  out: a contiguous float32
+    destination of a's shape (e.g. one half of a stacked batch)."""
     _chk(a, "a"), _chk(b, "b")
     if a.shape != b.shape:
         raise ValueError("lerp operands differ in shape")
-    y = torch.empty_like(a)
+    if out is None:
+        y = torch.empty_like(a)
+    else:
+        y = _chk(out, "out")
+        if y.shape != a.shape:
+            raise ValueError("lerp: out %s does not fit %s" % (tuple(y.shape), tuple(a.shape)))
     per = a.numel() // a.shape[0]
     lib = _lib.load()
     if isinstance(alpha, torch.Tensor):
@@ -964,9 +970,10 @@ def wgan_losses(Dz, Dx=None, gn2=None):
     return out
 
 
-def wgan_losses_bwd(Dz, Dx, gn2, g_dloss, g_gloss):
-    dDz = torch.empty_like(Dz)
-    dDx = torch.empty_like(Dx) if Dx is not None else None
+def wgan_losses_bwd(Dz, Dx, gn2, g_dloss, g_gloss, out_dz=None, out_dx=None):
+    """out_dz / out_dx: contiguous destinations (the two halves of one stacked gradient tensor)"""
+    dDz = torch.empty_like(Dz) if out_dz is None else out_dz
+    dDx = (torch.empty_like(Dx) if out_dx is None else out_dx) if Dx is not None else None
     dgn2 = torch.empty_like(gn2) if gn2 is not None else None
     _lib.check(_lib.load().sq_wgan_losses_bwd_f32(_ptr(Dz), _ptr(Dx), _ptr(gn2), _ptr(g_dloss), _ptr(g_gloss), _ptr(dDz),
                                                  _ptr(dDx), _ptr(dgn2), Dz.numel(), _stream()), "sq_wgan_losses_bwd_f32")
