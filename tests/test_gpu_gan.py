@@ -298,13 +298,15 @@ def test_graphed_solver_steps_equal_eager_steps(dtype):
 
 
 def test_training_loop_with_graph_replay_across_levels(tmp_path):
-    """train() with params['graph']: every level's stabilisation phase captures its own pair of solver graphs
-    (4x4 mosaic level included); fade phases stay eager; checkpoints and global_step as in the eager loop."""
+    """train() with params['graph']: every level captures its own set of iteration graphs (generator forward + discriminator
+    gradients, Adam D, generator gradients, Adam G; 4x4 mosaic level included); the fade-in weight rides in a device tensor,
+    so fade and stabilisation phases replay the same graphs; checkpoints and global_step as in the eager loop."""
     g = make_gan(output=str(tmp_path / "o"), graph=True, dtype="bf16")
     g.train(max_steps_per_phase=3)
     assert g.global_step == 3 * 2 * 2 and all(np.isfinite(v) for v in g.last_losses)     # 2 batches per epoch cap the phase
     captured = [k for k, v in g._graphs.items() if isinstance(v, tuple)]
-    assert sorted((k[0], k[1]) for k in captured) == [("d", 0), ("d", 1), ("d", 2), ("g", 0), ("g", 1), ("g", 2)]
+    assert sorted((k[0], k[1]) for k in captured) == [("it", 0), ("it", 1), ("it", 2)]
+    assert all(len(g._graphs[k]) == 14 for k in captured)                  # four graphs + their static tensors and tables
     import os
     assert sorted(os.listdir(str(tmp_path / "o"))) == ["model_(16x16).npz", "model_(4x4).npz", "model_(8x8).npz"]
     w = g.store.state_dict()
