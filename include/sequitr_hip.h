@@ -188,7 +188,7 @@ int sq_adam_advance_dev(int32_t *state, float lr, float beta1, float beta2, void
 /* the same advance with a linear learning-rate warm-up evaluated ON THE DEVICE from the step counter:
  * lr_t = lr * min(1, t / warmup_steps) * sqrt(1 - beta2^t) / (1 - beta1^t); warmup_steps = 0 is sq_adam_advance_dev.
  * A captured training step walks the schedule by itself when replayed (the U-Net trainer's default: the reference's
- * learning_rate 0.01, sequitr/utils.py:289, diverges on step 2 of the 5-level net without it -- DESIGN.md section 8). */
+ * learning_rate 0.01, sequitr/utils.py:289, diverges on step 2 of the 5-level net without it -- HISTORY.md section 8). */
 int sq_adam_advance_warmup_dev(int32_t *state, float lr, float beta1, float beta2, int warmup_steps, void *stream);
 int sq_adam_apply_dev_f32(float *p, const float *g, float *m, float *v, int64_t n, float beta1, float beta2,
                           float eps, const int32_t *state, float grad_scale, void *stream);

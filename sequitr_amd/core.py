@@ -1,7 +1,7 @@
 """Server / back-end configuration -- mirror of sequitr/core.py (INI `server.config`,
 sections config / tensorflow / cpu / gpu; core.py:34-106).
 
-Differences, all documented in DESIGN.md: Python 3 ``configparser``; a missing
+Differences, all documented in HISTORY.md (section 8): Python 3 ``configparser``; a missing
 ``server.config`` is not an error (the reference logs through an undefined logger,
 core.py:60-63); ``DEFAULT_GPUS`` defaults to the 8 GPUs of one MI355X node.
 The ``tensorflow`` section keeps its name for file compatibility; it now configures the

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
                 for (int r = 0; r < 4; ++r)
                     gv[r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(grsrc, offs[r], 0, 0));
                 // waited for inside the same branch: otherwise "loaded but never consumed" is a path to the compiler
-                // and the main loop's prefetch gets guarded by waits that drain the stores
+                // and the main loop's prefetch gets guarded by waits that drain the stores (HISTORY.md 4a)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
             }
 #pragma unroll
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
         __builtin_amdgcn_s_setprio(3);
         // the prefetch has landed -- stated OUTSIDE the `has_next` branch: hipcc does not correlate the two tests, keeps the
         // prefetch registers marked as pending loads round the back edge and otherwise guards the next issue() with
-        // s_waitcnt vmcnt(n), which at run time waits for the epilogue's stores (sq_conv_f32_v2.hip)
+        // s_waitcnt vmcnt(n), which at run time waits for the epilogue's stores (sq_conv_f32_v2.hip, HISTORY.md 4a)
         __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0); expcnt / lgkmcnt untouched
         if (has_next) {
             __syncthreads();

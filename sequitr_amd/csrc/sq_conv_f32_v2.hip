@@ -25,10 +25,10 @@
 #include "sq_common.h"
 
 #ifndef SQ_TILE_INTERLEAVE
-#define SQ_TILE_INTERLEAVE 1    // block b takes tiles b, b+G, b+2G, ...; 0: a contiguous run per block (A/B switch)
+#define SQ_TILE_INTERLEAVE 1    // block b takes tiles b, b+G, b+2G, ...; 0: a contiguous run per block (A/B switch, HISTORY.md 4a)
 #endif
 #ifndef SQ_STORE_PERMUTE
-#define SQ_STORE_PERMUTE 0      // 1: lane-contiguous stores through ds_bpermute (A/B switch: no measurable difference)
+#define SQ_STORE_PERMUTE 0      // 1: lane-contiguous stores through ds_bpermute (A/B switch: no measurable difference, HISTORY.md 4a)
 #endif
 
 struct SqConvEpi {

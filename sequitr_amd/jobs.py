@@ -241,7 +241,7 @@ def SERVER_train(params, options):
     (.npy (N,H,W[,1]); when absent computed with ImageWeightMap(w0, sigma), sequitr/pipeline.py:455-479, on
     the GPU -- sq_weightmap_edt_f32 -- and kept there), dtype ('f32' | 'bf16' activations), plus the
     NetConfiguration keys (name, shape, num_outputs, learning_rate, num_epochs, batch_size, dropout, filters,
-    bridge, warm_start ...) and warmup_steps (linear learning-rate warm-up).
+    bridge, warm_start ...) and warmup_steps (linear learning-rate warm-up, HISTORY.md section 8).
     Deviation from the reference's defaults: without params['learning_rate'] the step uses train.DEFAULT_LEARNING_RATE
     (0.003) ramped over train.DEFAULT_WARMUP_STEPS (40), not NetConfiguration's 0.01 (sequitr/utils.py:289), which
     diverges on this net under Adam; the values used are written to net.config and train.json.
@@ -291,7 +291,7 @@ def SERVER_train(params, options):
     net_p.setdefault('shape', tuple(x.shape[1:3]))
     net_p['dropout'] = float(params.get('dropout', 0.4))
     # learning_rate: the job's own value when it gives one; otherwise the trainer's default, NOT NetConfiguration's 0.01
-    # (sequitr/utils.py:289), which diverges on the 5-level net under Adam (train.DEFAULT_LEARNING_RATE)
+    # (sequitr/utils.py:289), which diverges on the 5-level net under Adam (train.DEFAULT_LEARNING_RATE, HISTORY.md section 8)
     trainer = UNetTrainer(net_p, learning_rate=params.get('learning_rate'), warmup_steps=params.get('warmup_steps'))
     # net.config must record the hyper-parameters that were USED (it is what a warm start or an audit reads): the
     # trainer's learning rate and warm-up, not NetConfiguration's untouched defaults

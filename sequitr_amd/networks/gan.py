@@ -8,7 +8,7 @@ Same module-level leaf functions (``k_leaky_relu_alpha``, ``pixel_norm``, ``weig
 replaced by eager HIP kernel launches and ``scope.VariableStore``; variable names are the
 reference's (``GAN/generator/latent/conv/filter`` ...).
 
-What differs on purpose: the data source is a ``.npy`` stack or synthetic
+What differs on purpose (HISTORY.md section 8): the data source is a ``.npy`` stack or synthetic
 tiles instead of a TFRecord (TFRecord IO is out of scope); checkpoints are ``model_(HxW).npz``;
 ``predict`` uses its ``latent`` argument (the reference feeds an undefined global, gan.py:923);
 every forward and gradient op, including the minibatch-stdev statistic and the (N,)-sized loss
@@ -582,13 +582,17 @@ class GenerativeAdverserialNetwork(object):
         twice).  The discriminator step reads it detached; the generator step differentiates through the kept tape.  Same
         losses, same weights as the two calls (tests/test_gpu_gan.py); 45 launches and ~0.4 ms fewer at level 6.
         Returns (d_loss, g_loss) device scalars."""
+        self._d_marked = False
         try:
             with self.precision(), F.fuse_act_gates(self._act_gates()), ops.use_arena(self.arena):
                 if self._graphable(alpha) and r is None:
                     return self._iteration_graphed(X, Z, alpha)
                 return self._iteration(X, Z, alpha, r)
         finally:
-            self._weights_moved('d')
+            # the discriminator's packs were restaged right after ITS update, in the middle of the iteration, and stay valid
+            # into the next one; only the generator's weights have moved since
+            if not self._d_marked:
+                self._weights_moved('d')
             self._weights_moved('g')
 
     def _iteration(self, X, Z, alpha, r=None):
@@ -599,6 +603,7 @@ class GenerativeAdverserialNetwork(object):
         self.d_opt.apply(d_vars, grads, grad_scale=scale)
         self._last_losses = losses
         self._weights_moved('d')
+        self._d_marked = True
         self._pack_filters()                                    # the discriminator's packs follow its new weights
         g_vars, ggrads, glosses = self._g_grads(X, Z, alpha, generated=generated)
         scale = self._allreduce(ggrads)
@@ -662,6 +667,7 @@ class GenerativeAdverserialNetwork(object):
         self.d_opt.t += 1
         self._last_losses = d_losses
         self._weights_moved('d')
+        self._d_marked = True
         self._pack_filters()                                    # the discriminator's packs, restaged in front of the generator step
         gg.replay()
         self._allreduce(g_grads)

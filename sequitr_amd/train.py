@@ -17,7 +17,7 @@ from .parallel import FlatBucket, allreduce_sum_
 
 
 # Defaults from the round-3 probe on the BASELINE config-3 net (tools/r03_lr_probe.py, profiles/r03_lr_probe.txt,
-# DESIGN.md section 8): Adam's first update is +-lr on EVERY weight whatever the gradient's size; at the reference's
+# HISTORY.md section 8): Adam's first update is +-lr on EVERY weight whatever the gradient's size; at the reference's
 # learning_rate 0.01 (sequitr/utils.py:289 -- a NetConfiguration field whose optimiser is absent upstream) that is 40 %
 # of a deep-layer weight (sigma 0.024) and the multiplicative bridges carry it to a loss of 1.8e15 on step 2; lr 0.003
 # still jumps to 4e5, lr 0.001 to 11, and a 20-step ramp to 7 (f32, step 15).  With lr 0.003 ramped linearly over the
@@ -38,7 +38,7 @@ class UNetTrainer(object):
         if learning_rate is None:
             learning_rate = params.get('learning_rate', DEFAULT_LEARNING_RATE)
         self.lr, self.b1, self.b2, self.eps = float(learning_rate), beta1, beta2, epsilon
-        # linear learning-rate warm-up over the first `warmup_steps` optimiser steps, walked on the device
+        # linear learning-rate warm-up over the first `warmup_steps` optimiser steps, walked on the device (HISTORY.md section 8)
         self.warmup_steps = int(params.get('warmup_steps', DEFAULT_WARMUP_STEPS) if warmup_steps is None else warmup_steps)
         self.group = group
         self.step_count = 0
@@ -65,7 +65,7 @@ class UNetTrainer(object):
         self.last_loss = None
         # Every workspace this trainer's launches use (split-K partials of the weight gradients, head / loss partials)
         # comes from ITS arena: one buffer, one owner stream, never freed while a captured graph may hold its address
-        # (ops.WorkspaceArena; DESIGN 4b "the round-2 memory access fault").
+        # (ops.WorkspaceArena; HISTORY.md 4b "the round-2 memory access fault").
         self.arena = ops.WorkspaceArena('UNetTrainer')
         # Adam's step counter lives on the device ({step, lr_t bits}) so a captured step replays correctly.
         self.step_state = torch.zeros(2, dtype=torch.int32, device=dev)
