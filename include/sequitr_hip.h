@@ -658,6 +658,12 @@ int sq_wgrad1x1_small_bf16(const float *a, const void *b, float *m, float *asum,
  * y (N,H,W,Cout) and ypool (N,H/2,W/2,Cout) == sq_sumpool2x2_bf16(y, 0.25).  K = 3, even H and W. */
 int sq_conv2d_nhwc_fwd_avgpool_bf16(const void *x, const void *wp, const float *bias, void *y, void *ypool, int N, int H, int W,
                                     int Cin, int Cout, int act, void *stream);
+/* weighted_conv2d with norm=True (gan.py:86-97: conv -> bias -> activation -> pixel_norm, one op upstream) from one kernel:
+ * y (N,H,W,Cout) = act(conv3x3(x, wp) + bias) and ynorm = pixel_norm(y, eps) of the STORED y (== sq_pixelnorm_fwd_bf16(y) up
+ * to the f32 rounding of the per-pixel factor: the squares are added in another order).  One block holds all channels of a
+ * pixel: Cout % 8 == 0, Cout <= 64 (the generator's 32x32 .. 256x256 levels).  y may be NULL (only ynorm is wanted). */
+int sq_conv2d_nhwc_fwd_pixelnorm_bf16(const void *x, const void *wp, const float *bias, void *y, void *ynorm, int N, int H, int W,
+                                      int Cin, int Cout, int act, float eps, void *stream);
 int sq_conv2d_nhwc_dgrad_actgate_bf16(const void *dy, const void *wp_t, const void *gate, int act, void *dx, int N, int H,
                                       int W, int Cin, int Cout, int K, void *stream);
 int sq_conv2d_nhwc_mosaic_bf16(const void *x, const void *wp, const float *bias, const void *gate, void *y, int Nimg, int h,

@@ -168,6 +168,7 @@ SIGNATURES = {
     "sq_wgrad1x1_small_workspace_bf16": (c_int64, [c_int64, c_int, c_int]),
     "sq_wgrad1x1_small_bf16": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_float, c_void_p]),
     "sq_conv2d_nhwc_fwd_avgpool_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "sq_conv2d_nhwc_fwd_pixelnorm_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),
     "sq_conv2d_nhwc_dgrad_actgate_bf16": (c_int, [c_void_p] * 3 + [c_int, c_void_p] + [c_int] * 6 + [c_void_p]),
     "sq_conv2d_nhwc_mosaic_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_int64, c_void_p]),
     "sq_conv2d_nhwc_wgrad_scaled_bf16": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),

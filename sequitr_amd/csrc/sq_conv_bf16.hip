@@ -81,7 +81,15 @@ struct SqDropEpi {
     __bf16 *f_y1 = nullptr;
     unsigned char *f_mask = nullptr;
     unsigned mos_mh = 0, mos_mw = 0;                            // ceil(2^16 / (h+1)), ceil(2^16 / (w+1)): q = (v * m) >> 16, exact for
-};                                                              // v < 2^13 at pitches <= 9 (set by the entry point)
+                                                                // v < 2^13 at pitches <= 9 (set by the entry point)
+    // FORM_PN: weighted_conv2d's pixel norm (gan.py:49-51, 96-97) in the epilogue.  One block holds ALL Cout <= 64 channels of
+    // a pixel (gridDim.y == 1): pn_y (N,H,W,Cout) = bf16(v * r), r = 1 / sqrt(mean_c v^2 + pn_eps) of the STORED values
+    // v = bf16(act(conv + bias)) -- what sq_pixelnorm_fwd_bf16 computes from y (its sum of squares is added in another order:
+    // equal to f32 rounding of r).  y itself is written when pn_store_y (a backward pass will read it).
+    __bf16 *pn_y = nullptr;
+    float pn_eps = 0.f;
+    int pn_store_y = 1;
+};
 
 template <int BN, int KS, int KC>
 struct CfgB {
@@ -204,7 +212,8 @@ __global__ __launch_bounds__(256) void pack_weights_multi_bf16_kernel(const floa
 //         each walking all 16 channel chunks alone (one block per CU at best, 22 - 28 us of exposed round trips)
 //   8 FP: FORM_PL whose input is made in the block from the single-channel image (SqDropEpi::f_*): conv_block of down0 with
 //         its max pool as ONE launch (16 channels)
-enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4, FORM_GF = 5, FORM_GB = 6, FORM_SK = 7, FORM_FP = 8 };
+//   9 PN: pixel norm of the output in the same epilogue (SqDropEpi::pn_*): the generator's conv -> leaky -> pixel_norm
+enum { FORM_PLAIN = 0, FORM_JN = 1, FORM_PL = 2, FORM_MK = 3, FORM_MG = 4, FORM_GF = 5, FORM_GB = 6, FORM_SK = 7, FORM_FP = 8, FORM_PN = 9 };
 template <int BN, int KS, int KC, typename TIO, int FORM = FORM_PLAIN, bool MOS = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     const TIO *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
@@ -215,7 +224,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
     constexpr bool FP = FORM == FORM_FP;
     static_assert(!FP || (BN == 16 && KS == 3 && KC == 16 && sizeof(TIO) == 2 && !MOS), "FORM_FP is the 16-channel level-0 block");
     constexpr bool JN = FORM == FORM_JN, PL = FORM == FORM_PL || FP, MK = FORM == FORM_MK, MG = FORM == FORM_MG;
-    constexpr bool GF = FORM == FORM_GF, GB = FORM == FORM_GB, SK = FORM == FORM_SK;
+    constexpr bool GF = FORM == FORM_GF, GB = FORM == FORM_GB, SK = FORM == FORM_SK, PN = FORM == FORM_PN;
+    static_assert(!PN || (sizeof(TIO) == 2 && !MOS), "FORM_PN: bf16 tensors, plain addressing");
     constexpr bool F32IO = sizeof(TIO) == 4;                    // f32 activations in HBM, bf16 in LDS
     constexpr int ES = (int)sizeof(TIO), XV = F32IO ? 2 : 1;    // 16-byte loads per 8-channel LDS item
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -554,6 +564,58 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(
             }
             return;
         }
+        if constexpr (PN) {
+            // pass 1: the stored values v = bf16(act(acc + bias)) (kept in the accumulator registers) and their squares per
+            // pixel row; the four kg lanes of a pixel hold its Cout channels between them
+            float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nb = 0; nb < NR; ++nb) {
+                const int co = n0 + nb * 16 + 4 * kg;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (HOIST_BIAS) bv = bvr[nb];
+                else if (bias && co < Cout) bv = *reinterpret_cast<const float4 *>(bias + co);
+                const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = co < Cout ? (float)(__bf16)actf(acc[r][nb][j] + bq[j]) : 0.f;
+                        acc[r][nb][j] = v;
+                        ss[r] = __builtin_fmaf(v, v, ss[r]);
+                    }
+            }
+            const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(drop.pn_y, 0, (int)(io_pixels * Cout * 2), 0x00020000);
+            const float invC = 1.0f / (float)Cout;
+            float rn[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ss[r] += __shfl_xor(ss[r], 16);
+                ss[r] += __shfl_xor(ss[r], 32);
+                rn[r] = 1.0f / __builtin_sqrtf(ss[r] * invC + drop.pn_eps);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NR; ++nb) {
+                const int co = n0 + nb * 16 + 4 * kg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gy = ty * TH + 4 * wv + r;
+                    const bool ok = gy < H && gx < W && co < Cout;
+                    const unsigned off = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 2) : OOB;
+                    bf16x4 o, q;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = (__bf16)acc[r][nb][j];
+                        q[j] = (__bf16)(acc[r][nb][j] * rn[r]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
+                        __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, o), yrsrc, drop.pn_store_y ? off : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(
+                        __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, q), nrsrc, off, 0, 0);
+                    acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int nb = 0; nb < NR; ++nb) {
             const int co = n0 + nb * 16 + 4 * kg;
@@ -872,6 +934,7 @@ int launch(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N, int
         }
         if (drop.j_g) return launch<BN, KS, KC, TIO, FORM_JN>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
         if (drop.pool) return launch<BN, KS, KC, TIO, FORM_PL>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
+        if (drop.pn_y) return launch<BN, KS, KC, TIO, FORM_PN>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
         if (drop.mask)
             return gate ? launch<BN, KS, KC, TIO, FORM_MG>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop)
                         : launch<BN, KS, KC, TIO, FORM_MK>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
@@ -918,7 +981,7 @@ int dispatch_bn(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N
     const int64_t ntiles = (int64_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH) * N;
     int bn = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16);
     static const int narrow = [] { const char *e = getenv("SQ_CONV_BF16_NARROW"); return e ? atoi(e) : 1; }();
-    while (narrow && bn > 16 && ntiles * ((Cout + bn - 1) / bn) < 2 * 256) bn >>= 1;
+    while (narrow && bn > 16 && !drop.pn_y && ntiles * ((Cout + bn - 1) / bn) < 2 * 256) bn >>= 1;   // (FORM_PN: one block per pixel's channels)
     if (bn == 64) return launch<64, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
     if (bn == 32) return launch<32, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
     return launch<16, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
@@ -1261,6 +1324,21 @@ extern "C" int sq_conv2d_nhwc_fwd_avgpool_bf16(const void *x, const void *wp, co
     d.pool = reinterpret_cast<__bf16 *>(ypool);
     d.pool_avg = 1;
     return conv_fwd_bf16_impl(x, wp, bias, y, N, H, W, Cin, Cout, 3, act, stream, nullptr, d);
+}
+
+// weighted_conv2d with norm=True (gan.py:86-97) on bf16 tensors: y (N,H,W,Cout) = act(conv3x3 + bias) AND ynorm = pixel_norm(y, eps)
+// of the stored y from one kernel (the generator's blocks at Cout <= 64, the levels whose tensors are largest).  y may be NULL:
+// then only ynorm is written (inference, or a forward pass nobody differentiates).  Cout % 8 == 0, Cout <= 64.
+extern "C" int sq_conv2d_nhwc_fwd_pixelnorm_bf16(const void *x, const void *wp, const float *bias, void *y, void *ynorm, int N,
+                                                 int H, int W, int Cin, int Cout, int act, float eps, void *stream) {
+    SQ_REQUIRE(ynorm && Cout % 8 == 0 && Cout <= 64, "sq_conv2d_nhwc_fwd_pixelnorm_bf16: ynorm, Cout %% 8 == 0, Cout <= 64 (Cout=%d)", Cout);
+    SQ_REQUIRE(eps >= 0.f, "sq_conv2d_nhwc_fwd_pixelnorm_bf16: eps must not be negative");
+    SQ_REQUIRE_ALIGNED(ynorm);
+    SqDropEpi d{0u, 1.f, 0u, nullptr};
+    d.pn_y = reinterpret_cast<__bf16 *>(ynorm);
+    d.pn_eps = eps;
+    d.pn_store_y = y != nullptr;
+    return conv_fwd_bf16_impl(x, wp, bias, y ? y : ynorm, N, H, W, Cin, Cout, 3, act, stream, nullptr, d);
 }
 
 // conv + bias + ReLU with the sign mask of the output beside it (mask: N*H*W*Cout/8 bytes, bit c & 7 of byte

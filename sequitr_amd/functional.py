@@ -313,12 +313,17 @@ class _Conv2d(torch.autograd.Function):
     """Fused forward kernel: act(conv2d(x, w*wscale) + bias)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, act, wscale, gate):
+    def forward(ctx, x, w, bias, act, wscale, gate, pn=None):
         ctx.gate = gate
         # x = the activation output of the conv in front (it hangs its ActGate on x): this conv is x's only consumer
         # (gan.py:149-316 wiring), so in first-order passes its dgrad kernel applies act'(x) in the epilogue
         ctx.in_gate = _gate_of(x) if gate is not None or FUSE_ACT_GATES else None
-        y = ops.conv2d(x, w, bias, act=act, wscale=wscale)
+        if pn is not None and ops.conv2d_pixelnorm_takes(x, w):
+            # the pixel norm that follows (weighted_conv2d's norm=True) comes out of the same kernel; it is handed to
+            # pixel_norm() through `pn` (a one-slot list the tape does not see), which returns it instead of launching
+            y, pn[1] = ops.conv2d_pixelnorm(x, w, bias, act=act, wscale=wscale, eps=pn[0])
+        else:
+            y = ops.conv2d(x, w, bias, act=act, wscale=wscale)
         ctx.act, ctx.wscale, ctx.has_bias = act, wscale, bias is not None
         ctx.w_id, ctx.bias_id = _pid(w), _pid(bias)
         ctx.sinks = (grad_sink(w), grad_sink(bias)) if wscale == 1.0 else (None, None)
@@ -332,7 +337,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.gate is not None:
             ctx.gate.applied = False
         dpre = _ActBwd.apply(dy, y, ctx.act) if (y is not None and not gated) else dy.contiguous()
-        return _conv_backward(ctx, x, w, dpre) + (None, None, None)
+        return _conv_backward(ctx, x, w, dpre) + (None, None, None, None)
 
 
 def _conv_backward(ctx, x, w, dpre):
@@ -407,11 +412,16 @@ def conv2d_avgpool(x, w, bias=None, act=None, wscale=1.0):
     return avgpool2x2(conv2d(x, w, bias, act, wscale))
 
 
-def conv2d(x, w, bias=None, act=None, wscale=1.0):
+def conv2d(x, w, bias=None, act=None, wscale=1.0, pixelnorm_eps=None):
+    """pixelnorm_eps: the caller will apply pixel_norm(y, eps) next (weighted_conv2d's norm=True, gan.py:96-97): where the fused
+    kernel exists the normalised tensor is produced with y and pixel_norm(y) returns it without a launch"""
     gate = ActGate(act) if (FUSE_ACT_GATES and ops.ACT[act]) else None
-    y = _Conv2d.apply(x, w, bias, act, float(wscale), gate)
+    pn = [float(pixelnorm_eps), None] if pixelnorm_eps is not None else None
+    y = _Conv2d.apply(x, w, bias, act, float(wscale), gate, pn)
     if gate is not None:
         y._sq_act_gate = gate
+    if pn is not None and pn[1] is not None:
+        y._sq_pn = (pn[0], pn[1])
     return y
 
 
@@ -468,9 +478,11 @@ def cast(x, dtype):
 # ---------------------------------------------------------------------------------------------
 class _PixelNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps, gate):
+    def forward(ctx, x, eps, gate, ready=None):
         ctx.eps, ctx.gate = eps, gate
         ctx.save_for_backward(x)
+        if ready is not None:                                   # [tensor]: the conv that produced x normalised it in its epilogue
+            return ready[0]
         return ops.pixelnorm(x, eps)
 
     @staticmethod
@@ -486,8 +498,8 @@ class _PixelNorm(torch.autograd.Function):
                 ctx.gate.shared = True
             elif not ctx.gate.shared:
                 ctx.gate.applied = True                         # x = act(conv): act'(x) rides in this kernel (ActGate)
-                return ops.pixelnorm_bwd(x, dy.contiguous(), ctx.eps, act=ctx.gate.act), None, None
-        return _PixelNormBwd.apply(x, dy, ctx.eps), None, None
+                return ops.pixelnorm_bwd(x, dy.contiguous(), ctx.eps, act=ctx.gate.act), None, None, None
+        return _PixelNormBwd.apply(x, dy, ctx.eps), None, None, None
 
 
 class _PixelNormBwd(torch.autograd.Function):
@@ -507,7 +519,11 @@ class _PixelNormBwd(torch.autograd.Function):
 
 
 def pixel_norm(x, epsilon=1e-8):
-    return _PixelNorm.apply(x, float(epsilon), _gate_of(x))
+    # the conv that produced x may have normalised it in its epilogue (conv2d(pixelnorm_eps=)): the result rides on x ONCE --
+    # it is taken off here, or x -> result -> PixelNorm node -> saved x would be a reference cycle the collector cannot see
+    pn = x.__dict__.pop('_sq_pn', None) if hasattr(x, '__dict__') else None
+    ready = [pn[1]] if (pn is not None and pn[0] == float(epsilon)) else None
+    return _PixelNorm.apply(x, float(epsilon), _gate_of(x), ready)
 
 
 # ---------------------------------------------------------------------------------------------

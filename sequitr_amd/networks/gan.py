@@ -69,7 +69,10 @@ def weighted_conv2d(inputs=None, filters=None, kernel_size=[3, 3], padding="same
     wscale = float(np.sqrt(np.float32(2.0 / float(kh * kw * filters))))
     if pool and not norm:
         return F.conv2d_avgpool(inputs, kernels, bias.view(-1), act=_act_name(activation), wscale=wscale)
-    out = F.conv2d(inputs, kernels, bias.view(-1), act=_act_name(activation), wscale=wscale)
+    # norm: the pixel norm leaves the conv's own epilogue where that kernel exists (bf16 features, Cout <= 64); pixel_norm() then
+    # returns the tensor it is handed instead of launching
+    out = F.conv2d(inputs, kernels, bias.view(-1), act=_act_name(activation), wscale=wscale,
+                   pixelnorm_eps=1e-8 if norm else None)
     if norm:
         out = pixel_norm(out)
     return F.avgpool2x2(out) if pool else out

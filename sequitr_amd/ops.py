@@ -881,6 +881,15 @@ def conv2d_avgpool(x, w, bias=None, act=None, wscale=1.0):
     return _gb().conv2d_avgpool(x, w, bias, act, wscale)
 
 
+def conv2d_pixelnorm_takes(x, w):
+    return x.dtype == _BF16 and _gb().conv2d_pixelnorm_takes(x, w)
+
+
+def conv2d_pixelnorm(x, w, bias=None, act=None, wscale=1.0, eps=1e-8, want_y=True):
+    """(y, pixel_norm(y, eps)), y = act(conv3x3(x, w * wscale) + bias), from one kernel (bf16 features, Cout <= 64)"""
+    return _gb().conv2d_pixelnorm(x, w, bias, act, wscale, eps, want_y)
+
+
 def cast(x, dtype):
     """float32 <-> bfloat16 copy (the GAN's two storage boundaries)"""
     return _gb().cast(x, dtype)

@@ -338,3 +338,32 @@ def conv2d_avgpool(x, w, bias=None, act=None, wscale=1.0):
     _lib.check(_lib.load().sq_conv2d_nhwc_fwd_avgpool_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(p), N, H, W, Cin, Cout,
                                                           ACT[act], _stream()), "sq_conv2d_nhwc_fwd_avgpool_bf16")
     return y, p
+
+
+USE_CONV_PN = __import__('os').environ.get("SQ_CONV_PN", "1") != "0"      # A/B switch: 0 = conv and pixel norm as two launches
+
+
+def conv2d_pixelnorm_takes(x, w):
+    """can conv2d_pixelnorm fuse this layer?  bf16 features, a 3x3 filter, all output channels in one block (Cout <= 64) and
+    images the plain (non-mosaic) kernel takes"""
+    return (USE_CONV_PN and x.dtype == BF16 and x.dim() == 4 and w.dim() == 4 and w.shape[0] == 3 and w.shape[1] == 3
+            and x.shape[3] % 8 == 0 and w.shape[3] % 8 == 0 and w.shape[3] <= 64 and w.shape[2] == x.shape[3]
+            and not (ops.USE_MOSAIC and x.shape[2] < 16))
+
+
+def conv2d_pixelnorm(x, w, bias=None, act=None, wscale=1.0, eps=1e-8, want_y=True):
+    """(y or None, pixel_norm(y)) with y = act(conv3x3(x, w * wscale) + bias): weighted_conv2d(norm=True) (gan.py:86-97) from one
+    kernel; want_y=False skips the store of y (nobody will differentiate through the norm)."""
+    if not conv2d_pixelnorm_takes(x, w):
+        raise _lib.SequitrHipError("conv2d_pixelnorm: needs bf16 features, a 3x3 filter, Cout <= 64 and image sides >= 16")
+    _feat(x, "x"), _chk(w, "w", dtype=F32)
+    if bias is not None:
+        _chk(bias, "bias", dtype=F32)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    wp = ops._packed_filter(w, 3, Cin, Cout, wscale, False)
+    y = torch.empty((N, H, W, Cout), dtype=BF16, device=x.device) if want_y else None
+    yn = torch.empty((N, H, W, Cout), dtype=BF16, device=x.device)
+    _lib.check(_lib.load().sq_conv2d_nhwc_fwd_pixelnorm_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(yn), N, H, W, Cin, Cout,
+                                                            ACT[act], float(eps), _stream()), "sq_conv2d_nhwc_fwd_pixelnorm_bf16")
+    return y, yn

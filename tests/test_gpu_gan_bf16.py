@@ -186,6 +186,53 @@ def test_weighted_conv_bf16_forward_dgrad_gate_and_wgrad(N, H, W, Cin, Cout, K, 
     assert np.allclose(db.cpu().numpy(), dy.reshape(-1, Cout).sum(0).numpy(), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 32, 32, 128, 64), (3, 64, 48, 64, 32), (2, 128, 128, 32, 16), (1, 256, 256, 16, 8),
+                                             (2, 16, 16, 8, 8), (1, 40, 24, 16, 24)])
+def test_pixel_norm_in_the_conv_epilogue(N, H, W, Cin, Cout):
+    """sq_conv2d_nhwc_fwd_pixelnorm_bf16 (SURVEY 8b "pixelnorm epilogue flag"; gan.py:86-97 is conv -> bias -> activation ->
+    pixel_norm as ONE op): y is the plain conv's y bit for bit, ynorm is the stand-alone pixel norm of that y up to the f32
+    rounding of the per-pixel factor (the squares are added in another order: at most one bf16 ulp, nearly all identical) and
+    one ulp from fp64 on the stored y; want_y=False writes the same ynorm; through the tape (F.conv2d(pixelnorm_eps=) ->
+    F.pixel_norm) the forward launches ONE kernel and the gradients are those of the two-op graph."""
+    rng = np.random.default_rng(N + H + Cin + Cout)
+    xg, _ = rb(rng, (N, H, W, Cin))
+    w = torch.as_tensor(rng.standard_normal((3, 3, Cin, Cout)), dtype=torch.float32).cuda()
+    b = torch.as_tensor(rng.standard_normal(Cout) * 0.1, dtype=torch.float32).cuda()
+    ws = float(np.sqrt(np.float32(2.0 / (9 * Cout))))
+    assert ops.conv2d_pixelnorm_takes(xg, w)
+    y_ref = ops.conv2d(xg, w, b, act="leaky", wscale=ws)
+    n_ref = ops.pixelnorm(y_ref, 1e-8)
+    y, yn = ops.conv2d_pixelnorm(xg, w, b, act="leaky", wscale=ws, eps=1e-8)
+    assert torch.equal(y, y_ref)
+    y64 = y.double().cpu()
+    want = y64 * torch.rsqrt((y64 * y64).mean(-1, keepdim=True) + 1e-8)
+    one_ulp(yn, want, "fused pixel norm vs fp64 on the stored y", 0.98)
+    same = (yn == n_ref).double().mean().item()
+    assert same > 0.995 and (yn.float() - n_ref.float()).abs().max().item() <= 2.0 ** -7 * n_ref.float().abs().max().item(), same
+    none, yn2 = ops.conv2d_pixelnorm(xg, w, b, act="leaky", wscale=ws, eps=1e-8, want_y=False)
+    assert none is None and torch.equal(yn2, yn)
+    # through the tape
+    calls = []
+    orig = ops.pixelnorm
+    try:
+        ops.pixelnorm = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        xr = xg.clone().requires_grad_(True)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        with ops.mixed_precision(True, store_bf16=True):
+            out = F.pixel_norm(F.conv2d(xr, wr, br, act="leaky", wscale=ws, pixelnorm_eps=1e-8), 1e-8)
+            assert not calls and torch.equal(out, yn)
+            g = torch.as_tensor(rng.standard_normal(tuple(out.shape)), dtype=torch.float32).to(BF).cuda()
+            gx, gw, gb_ = torch.autograd.grad(out, [xr, wr, br], g)
+            x2 = xg.clone().requires_grad_(True)
+            w2, b2 = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            out2 = F.pixel_norm(F.conv2d(x2, w2, b2, act="leaky", wscale=ws), 1e-8)
+            assert len(calls) == 1
+            hx, hw, hb = torch.autograd.grad(out2, [x2, w2, b2], g)
+    finally:
+        ops.pixelnorm = orig
+    assert torch.equal(gx, hx) and torch.equal(gw, hw) and torch.equal(gb_, hb)     # the backward reads y only
+
+
 def _rel(a, t):
     a, t = np.asarray(a, np.float64), np.asarray(t, np.float64)
     return float(np.linalg.norm((a - t).ravel()) / max(np.linalg.norm(t.ravel()), 1e-30))
@@ -325,6 +372,14 @@ class _Replay(object):
             b = put(a['b'].reshape(-1), 'f') if kind == 'conv_act' else None
             y = ops.conv2d(x, w, b, act=('leaky' if a.get('act') else None), wscale=a['ws'])
             self.same(kind, y, out, a['so'], "%s -> %d" % (tuple(x.shape), w.shape[3]))
+            if kind == 'conv_act' and a['sx'] == 'b' and ops.conv2d_pixelnorm_takes(x, w):
+                # where the product runs the layer as conv + pixel norm from ONE kernel: both outputs against the emulation
+                from oracle import gan_bf16_ref as emu
+                y1, yn = ops.conv2d_pixelnorm(x, w, b, act=('leaky' if a.get('act') else None), wscale=a['ws'], eps=1e-8)
+                self.same('conv_act+pixelnorm (fused)', y1, out, 'b', "y %s" % (tuple(x.shape),))
+                # (the norm of the kernel's OWN stored y: a y value one ulp off the emulation's moves its pixel's factor)
+                self.same('conv_act+pixelnorm (fused)', yn, emu.q(emu._pn(y1.detach().float().cpu().double(), 1e-8)), 'b',
+                          "ynorm %s" % (tuple(x.shape),))
         elif kind == 'dgrad':
             dy, w = put(a['dy'], a['so']), put(a['w'], 'f')
             self.same(kind, ops.conv_dgrad_raw(dy, w, a['ws']), out, a['sx'], "%s -> %d" % (tuple(dy.shape), w.shape[2]))
