@@ -219,6 +219,24 @@ class TileStreamer(object):
         self.net, self.B, self.want_logits = net, int(batch), bool(want_logits)
         self.workers = max(1, int(workers))
         self._shape = None
+        self._pool = None                                          # host threads (staging, draining), kept between runs
+
+    def _threads(self):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(self.workers + 1, thread_name_prefix='sq_stream')
+        return self._pool
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                          # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def _buffers(self, tile_shape, n_out):
         """pinned + device buffers for one tile shape (kept between runs: hipHostMalloc is slow)"""
@@ -284,7 +302,6 @@ class TileStreamer(object):
         when None).  pipe: callable applied to every (H,W,C) tile on the host (ImagePipeline).  on_batch(first,
         device_masks): called on the launching thread after each batch is queued (centroids from the masks in HBM).
         Returns (out_masks, out_logits)."""
-        from concurrent.futures import ThreadPoolExecutor
         net, B, dev = self.net, self.B, self.net.device
         N = int(tiles.shape[0])
         tile_shape = tuple(int(s) for s in tiles.shape[1:])
@@ -311,7 +328,7 @@ class TileStreamer(object):
         down = [torch.cuda.Event() for _ in range(2)]            # D2H into the pinned outputs [k] finished
         for e in up + used + down:
             e.record(main)
-        pool = ThreadPoolExecutor(self.workers + 1)
+        pool = self._threads()
 
         def wait_for(ev):
             """host wait WITHOUT a blocking runtime call: a hipEventSynchronize in a worker thread keeps the launching
@@ -389,7 +406,8 @@ class TileStreamer(object):
                 drains[b].result()
             held[:] = [None, None]
         finally:
-            pool.shutdown(wait=True)
+            for f in list(drains.values()) + [f for fs in staged.values() if fs for f in fs]:
+                f.cancel()                                        # (only after an exception: nothing is left otherwise)
             torch.cuda.synchronize(dev)
         return out_masks, out_logits
 

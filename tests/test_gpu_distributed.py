@@ -81,7 +81,7 @@ def test_unet_rank_averaged_gradients_equal_global_batch_gradients():
         assert float(np.mean(np.abs(ws[k] - w0[k]) > 1e-6)) <= 0.01, k
 
 
-def _gan_worker(rank, world, port, ret):
+def _gan_worker(rank, world, port, ret, shared=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -95,19 +95,33 @@ def _gan_worker(rank, world, port, ret):
         for _ in range(3):                                     # eager warm step, capture, replay
             z = torch.from_numpy(rng.standard_normal((4, 1, 1, 512)).astype(np.float32)).cuda()
             x = torch.from_numpy(rng.standard_normal((4, 8, 8, 2)).astype(np.float32)).cuda()
-            g.d_solver(x, z, 1.0)
-            g.g_solver(x, z, 1.0)
+            if shared:
+                g.iteration(x, z, 1.0)                         # one generator pass, four graphs, an all-reduce per solver between them
+            else:
+                g.d_solver(x, z, 1.0)
+                g.g_solver(x, z, 1.0)
         ret[rank] = g.store.state_dict()
     finally:
         dist.destroy_process_group()
 
 
-def test_gan_replicas_stay_identical_with_graph_replay_and_allreduce():
+@pytest.mark.parametrize("shared", [False, True])
+def test_gan_replicas_stay_identical_with_graph_replay_and_allreduce(shared):
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_gan_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_gan_worker, args=(world, _free_port(), ret, shared), nprocs=world, join=True)
     w0, w1 = ret[0], ret[1]
     assert all(np.array_equal(w0[k], w1[k]) for k in w0) and all(np.isfinite(v).all() for v in w0.values())
+
+
+def test_gan_iteration_equals_the_two_solver_calls_under_data_parallelism():
+    """the shared-generator iteration and the two solver calls: the same replicas after three all-reduced iterations"""
+    world, out = 2, []
+    for shared in (False, True):
+        ret = mp.Manager().dict()
+        mp.spawn(_gan_worker, args=(world, _free_port(), ret, shared), nprocs=world, join=True)
+        out.append(dict(ret[0]))
+    assert all(np.array_equal(out[0][k], out[1][k]) for k in out[0])
 
 
 CFG4 = {"shape": (512, 512), "dropout": 0.0, "device": "cuda:0", "seed": 0, "dtype": "bf16"}
