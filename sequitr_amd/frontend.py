@@ -227,14 +227,14 @@ class TileStreamer(object):
             self._pool = ThreadPoolExecutor(self.workers + 1, thread_name_prefix='sq_stream')
         return self._pool
 
-    def close(self):
+    def close(self, wait=True):
         if self._pool is not None:
-            self._pool.shutdown(wait=True)
+            self._pool.shutdown(wait=wait)
             self._pool = None
 
     def __del__(self):
         try:
-            self.close()
+            self.close(wait=False)
         except Exception:                                          # noqa: BLE001 -- interpreter shutdown
             pass
 
