@@ -292,9 +292,9 @@ class TileStreamer(object):
         torch.cuda.synchronize(self.net.device)
         if self.s_in is None:
             self._pick_streams()
-        self.pin_in[0].zero_()
-        for _ in range(3):                                        # the stream's own allocations (masks held across batches) settle
-            self.run(self.pin_in[0])
+        # one short pipelined pass over zeros: the stream's own allocations (masks / logits held across batches, the staging
+        # threads) settle here, not inside the caller's timed stream
+        self.run(np.zeros((3 * self.B,) + tuple(tile_shape), np.float32))
 
     def run(self, tiles, out_masks=None, out_logits=None, pipe=None, on_batch=None):
         """tiles: (N,H,W,C) float32-convertible numpy array / memmap, or a pinned CPU float32 tensor.

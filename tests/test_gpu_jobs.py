@@ -304,12 +304,16 @@ def test_segment_job_streams_256_tiles_at_the_end_to_end_rate(tmp_path):
     import time
     st = TileStreamer(net, batch=32)
     st.warm_up((512, 512, 1))
-    best = 0.0
-    for _ in range(3):
+    rates = []
+    for _ in range(5):
         t0 = time.perf_counter()
         st.run(x)
-        best = max(best, n * 512 * 512 / (time.perf_counter() - t0) / 1e6)
-    print("job %.0f Mpix/s (with set-up %.0f), streamer on the same array %.0f Mpix/s"
-          % (info["mpixels_per_s"], info["mpixels_per_s_with_setup"], best))
+        rates.append(n * 512 * 512 / (time.perf_counter() - t0) / 1e6)
+    best = max(rates)
+    print("job %.0f Mpix/s (with set-up %.0f), streamer on the same array: %s Mpix/s"
+          % (info["mpixels_per_s"], info["mpixels_per_s_with_setup"], " ".join("%.0f" % v for v in rates)))
     assert info["streamed"] and info["tiles"] == n
-    assert info["mpixels_per_s"] >= 0.9 * best, (info, best)
+    # the job's ONE pass over the stack against the best of five passes of the same streamer: 0.9 x; the
+    # job reads its tiles through a memmap of the .npy file, the comparison from an array in memory
+    assert info["mpixels_per_s"] >= 0.9 * best, (info, rates)
+    assert best >= 1200.0, rates                               # and the stream itself runs near the compute rate (1567)
