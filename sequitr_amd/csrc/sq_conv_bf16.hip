@@ -982,12 +982,8 @@ int dispatch_bn(const TIO *x, const __bf16 *wp, const float *bias, TIO *y, int N
     int bn = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16);
     static const int narrow = [] { const char *e = getenv("SQ_CONV_BF16_NARROW"); return e ? atoi(e) : 1; }();
     while (narrow && bn > 16 && !drop.pn_y && ntiles * ((Cout + bn - 1) / bn) < 2 * 256) bn >>= 1;   // (FORM_PN: one block per pixel's channels)
-    if (drop.mos_h && !drop.pn_y) {                             // experiment switch: block width of the mosaic launches
-        if (const char *fb = getenv("SQ_MOS_BN")) {
-            const int f = atoi(fb);
-            if ((f == 16 || f == 32 || f == 64) && f <= ((Cout + 15) / 16) * 16) bn = f;
-        }
-    }
+    static const int force_bn = [] { const char *e = getenv("SQ_MOS_BN"); return e ? atoi(e) : 0; }();   // experiment switch: block width of the mosaic launches
+    if (drop.mos_h && !drop.pn_y && (force_bn == 16 || force_bn == 32 || force_bn == 64) && force_bn <= ((Cout + 15) / 16) * 16) bn = force_bn;
     if (bn == 64) return launch<64, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
     if (bn == 32) return launch<32, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
     return launch<16, KS, KC, TIO>(x, wp, bias, y, N, H, W, Cin, Cout, act, st, gate, drop);
@@ -1237,10 +1233,8 @@ extern "C" int sq_conv2d_nhwc_mosaic_bf16(const void *x, const void *wp, const f
     static const int sk_on = [] { const char *e = getenv("SQ_CONV_SPLITK"); return e ? atoi(e) : 1; }();
     if (sk_on && workspace && Cout % 4 == 0 && blocks < 256 && nchunk >= 4)
         while (S < 8 && nchunk % (2 * S) == 0 && nchunk / (2 * S) >= 2 && blocks * S < 512 && slice * 2 * S <= workspace_bytes) S *= 2;
-    if (const char *fs = getenv("SQ_MOS_S")) {                  // experiment switch: force the split (1, 2, 4, 8)
-        const int f = atoi(fs);
-        if (f >= 1 && workspace && nchunk % f == 0 && slice * f <= workspace_bytes) S = f;
-    }
+    static const int force_s = [] { const char *e = getenv("SQ_MOS_S"); return e ? atoi(e) : 0; }();   // experiment switch (tools/r04_mosaic_sweep.py)
+    if (force_s >= 1 && workspace && nchunk % force_s == 0 && slice * force_s <= workspace_bytes) S = force_s;
     if (S == 1)
         return conv_fwd_bf16_impl(x, wp, gate ? nullptr : bias, y, 1, H, W, Cin, Cout, 3, gate ? (int)SQ_ACT_NONE : act, stream, gate, d);
     SQ_REQUIRE_ALIGNED(workspace);
