@@ -186,20 +186,24 @@ def SERVER_segment_frames(params, options):
         net.load_state_dict(utils.load_model_weights(model_dir))
     else:
         net.initialize()
-    masks = np.empty((F, H, W), np.uint8)
     per_frame = {}
+    want_centroids = bool(options.get('centroids'))
+    masks = np.empty((F, H, W), np.uint8) if want_centroids else None
 
-    def sink(first, m):
+    def sink(first, m):                                        # centroids need the masks while they are in HBM
+        from .centroids import mask_centroids
         masks[first:first + m.shape[0]] = m.cpu().numpy()
-        if options.get('centroids'):
-            from .centroids import mask_centroids
-            for k, coords in enumerate(mask_centroids(m)):
-                coords[:, 0] = first + k
-                per_frame[first + k] = coords
+        for k, coords in enumerate(mask_centroids(m)):
+            coords[:, 0] = first + k
+            per_frame[first + k] = coords
 
     t0 = time.time()
-    segment_frames(net, frames, tile=tile, margin=int(params.get('margin', 32)),
-                   frames_per_batch=int(params.get('frames_per_batch', 4)), on_masks=sink)
+    # without centroids the masks come back through segment_frames' own double-buffered download (batch i-1 drains
+    # while batch i runs); with them every batch is visited on the device first
+    out = segment_frames(net, frames, tile=tile, margin=int(params.get('margin', 32)),
+                         frames_per_batch=int(params.get('frames_per_batch', 4)), on_masks=sink if want_centroids else None)
+    if not want_centroids:
+        masks = out
     torch.cuda.synchronize()
     dt = time.time() - t0
     np.save(os.path.join(out_dir, 'mask.npy'), masks)
