@@ -449,6 +449,12 @@ int sq_conv2d_nhwc_wgrad_bf16(const void *x, const void *dy, float *dw, float *d
 int sq_convT2x2s2_wgrad_bf16(const void *x, const void *g, float *dw, float *db, float *workspace, int N, int H, int W,
                              int Cin, int Cout, void *stream);
 
+/* The concatenation in front of the discriminator's dense head (gan.py:213-226: tf.concat([conv, minibatch_stdev], -1) then
+ * reshape) with bf16 features: flat f32 (npix, C + 1) = [float(conv (npix, C)), mb (npix)] in one pass, and its adjoint
+ * (dconv rounded to bf16, dmb f32) -- each is the other's derivative, so the WGAN-GP second-order pass stays closed. */
+int sq_head_concat_fwd_bf16(const void *conv, const float *mb, float *flat, int64_t npix, int C, void *stream);
+int sq_head_concat_bwd_bf16(const float *dflat, void *dconv, float *dmb, int64_t npix, int C, void *stream);
+
 /* bf16 <-> f32 casts (RNE), n % 4 == 0 */
 int sq_cast_f32_to_bf16(const float *x, void *y, int64_t n, void *stream);
 int sq_cast_bf16_to_f32(const void *x, float *y, int64_t n, void *stream);

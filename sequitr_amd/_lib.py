@@ -131,6 +131,8 @@ SIGNATURES = {
     "sq_convT2x2s2_wgrad_bf16": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "sq_cast_f32_to_bf16": (c_int, [c_void_p] * 2 + [c_int64, c_void_p]),
     "sq_cast_bf16_to_f32": (c_int, [c_void_p] * 2 + [c_int64, c_void_p]),
+    "sq_head_concat_fwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
+    "sq_head_concat_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_void_p]),
     "sq_maxpool2x2_fwd_bf16": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "sq_maxpool2x2_bwd_bf16": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "sq_conv_pack_weights_multi_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

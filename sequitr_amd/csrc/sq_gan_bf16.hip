@@ -433,6 +433,31 @@ inline int small_blocks(int64_t npix) {
     return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
 }
 
+// The discriminator's output block (gan.py:213-226): concat([conv (N,P,C) features, minibatch-stdev map (N,P,1)], -1) flattened to
+// (N, P (C+1)) float32 rows for the dense layer -- from the bf16 conv output and the f32 map in ONE pass (it was a cast, a
+// concatenation and, in every backward pass, two slice copies, a cast and the zero fills of the slices' gradients)
+__global__ __launch_bounds__(256) void head_concat_fwd_kernel(const __bf16 *__restrict__ conv, const float *__restrict__ mb,
+                                                               float *__restrict__ flat, int64_t npix, int C) {
+    const int64_t total = npix * (C + 1);
+    SQ_GRID_STRIDE(i, total) {
+        const int64_t pix = i / (C + 1);
+        const int c = (int)(i - pix * (C + 1));
+        flat[i] = c < C ? (float)conv[pix * C + c] : mb[pix];
+    }
+}
+// its adjoint: dconv (N,P,C) = bf16(dflat[..., :C]), dmb (N,P) = dflat[..., C]
+__global__ __launch_bounds__(256) void head_concat_bwd_kernel(const float *__restrict__ dflat, __bf16 *__restrict__ dconv,
+                                                               float *__restrict__ dmb, int64_t npix, int C) {
+    const int64_t total = npix * (C + 1);
+    SQ_GRID_STRIDE(i, total) {
+        const int64_t pix = i / (C + 1);
+        const int c = (int)(i - pix * (C + 1));
+        const float v = dflat[i];
+        if (c < C) dconv[pix * C + c] = (__bf16)v;
+        else dmb[pix] = v;
+    }
+}
+
 }  // namespace
 
 #define SQ_ST(s) reinterpret_cast<hipStream_t>(s)
@@ -572,4 +597,18 @@ extern "C" int sq_wgrad1x1_small_bf16(const float *a, const void *b, float *m, f
     hipLaunchKernelGGL(wgrad1x1_small_bf16_finish_kernel, dim3((total * G + 255) / 256), dim3(256), 0, st, workspace, m, asum, nb, nm,
                        total, G, scale);
     return sq_check_launch("sq_wgrad1x1_small_bf16(finish)");
+}
+
+// concat([float32(conv), mb[..., None]], -1) over the last axis: conv bf16 (npix, C), mb f32 (npix) -> flat f32 (npix, C + 1)
+extern "C" int sq_head_concat_fwd_bf16(const void *conv, const float *mb, float *flat, int64_t npix, int C, void *stream) {
+    SQ_REQUIRE(conv && mb && flat && npix > 0 && C > 0, "sq_head_concat_fwd_bf16: bad arguments");
+    hipLaunchKernelGGL(head_concat_fwd_kernel, dim3(grid_for(npix * (C + 1))), dim3(256), 0, SQ_ST(stream), BF(conv), mb, flat, npix, C);
+    return sq_check_launch("sq_head_concat_fwd_bf16");
+}
+// the adjoint split: dflat f32 (npix, C + 1) -> dconv bf16 (npix, C) (rounded to nearest even) and dmb f32 (npix)
+extern "C" int sq_head_concat_bwd_bf16(const float *dflat, void *dconv, float *dmb, int64_t npix, int C, void *stream) {
+    SQ_REQUIRE(dflat && dconv && dmb && npix > 0 && C > 0, "sq_head_concat_bwd_bf16: bad arguments");
+    hipLaunchKernelGGL(head_concat_bwd_kernel, dim3(grid_for(npix * (C + 1))), dim3(256), 0, SQ_ST(stream), dflat,
+                       reinterpret_cast<__bf16 *>(dconv), dmb, npix, C);
+    return sq_check_launch("sq_head_concat_bwd_bf16");
 }

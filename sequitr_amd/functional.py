@@ -76,7 +76,11 @@ class grad_sinks(object):
 def _sink_wgrad(x, dy, K, wscale, w_id, bias_id=None, want_bias=False):
     """queue dW (+ db) of a conv for the grouped launch, destination = the parameters' sinks; False: not applicable here"""
     sk = _SINKS
-    if sk is None or torch.is_grad_enabled() or x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or x.dim() != 4:
+    if sk is None or torch.is_grad_enabled() or x.dim() != 4:
+        return False
+    if x.dtype == torch.float32 and dy.dtype == torch.float32:
+        return _sink_dense_wgrad(sk, x, dy, K, wscale, w_id, bias_id, want_bias)
+    if x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
         return False
     from . import ops_bf16 as ob
     q = ob._QUEUE[0]
@@ -98,6 +102,29 @@ def _sink_wgrad(x, dy, K, wscale, w_id, bias_id=None, want_bias=False):
         if sb is None:
             return False
     q.push(x.contiguous(), dy.contiguous(), K, sw, sb, dw_scale=wscale, mosaic=mosaic)
+    sk.touched.add(w_id)
+    if sb is not None:
+        sk.touched.add(bias_id)
+    return True
+
+
+def _sink_dense_wgrad(sk, x, dy, K, wscale, w_id, bias_id, want_bias):
+    """a dense layer in row form (F.dense: x (1,1,M,Kin), dY (1,1,M,N), few rows, long reduction -- the discriminator's
+    8208 -> 512 layer gets three contributions per step): its weight-gradient kernel writes the parameter's sink directly, the
+    first contribution of a pass overwriting and later ones accumulating (sq_dense_wgrad_f32's accumulate bits), instead of
+    three (Kin, N) tensors summed by framework adds"""
+    if K != 1 or x.shape[0] != 1 or x.shape[1] != 1 or not ops.USE_DENSE:
+        return False
+    M, Kin, N = x.shape[2], x.shape[3], dy.shape[3]
+    sw = sk.map.get(w_id)
+    if M > 128 or Kin * N < (1 << 16) or sw is None or sw.numel() != Kin * N:
+        return False
+    sb = sk.map.get(bias_id) if want_bias else None
+    if want_bias and (sb is None or sb.numel() != N):
+        return False
+    acc = (1 if w_id in sk.touched else 0) | (2 if (want_bias and bias_id in sk.touched) else 0)
+    ops.dense_wgrad(x.reshape(M, Kin), dy.reshape(M, N).contiguous(), want_bias=want_bias, dw_scale=wscale, dw_out=sw.view(Kin, N),
+                    db_out=sb.view(N) if sb is not None else None, accumulate=acc)
     sk.touched.add(w_id)
     if sb is not None:
         sk.touched.add(bias_id)
@@ -866,6 +893,37 @@ class _MbStdMapBwd(torch.autograd.Function):
 def mbstd_map(x, groups=1, cells=16):
     """(N, cells) map holding the minibatch statistic of each of `groups` stacked minibatches; differentiable twice"""
     return _MbStdMap.apply(x, int(groups), int(cells))
+
+
+class _HeadConcat(torch.autograd.Function):
+    """concat([float(conv), mb], -1) flattened per sample (the discriminator's output block, gan.py:213-226) on bf16 features:
+    one kernel instead of cast + cat, and ONE adjoint kernel (_HeadSplit) instead of two slice copies, a cast and the slices'
+    zero-filled gradients.  Linear: the two are each other's derivatives."""
+
+    @staticmethod
+    def forward(ctx, conv, mb):
+        ctx.shapes = (tuple(conv.shape), tuple(mb.shape))
+        return ops._gb().head_concat(conv.contiguous(), mb.contiguous())
+
+    @staticmethod
+    def backward(ctx, dflat):
+        return _HeadSplit.apply(dflat, ctx.shapes[0], ctx.shapes[1])
+
+
+class _HeadSplit(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dflat, conv_shape, mb_shape):
+        return ops._gb().head_split(dflat.contiguous(), conv_shape, mb_shape)
+
+    @staticmethod
+    def backward(ctx, ddconv, ddmb):
+        return _HeadConcat.apply(ddconv, ddmb), None, None
+
+
+def head_concat(conv, mb):
+    """(N, P (C + 1)) float32 rows of the discriminator's dense head from the bf16 conv output (N,h,w,C) and the (N, P) f32
+    minibatch-stdev map"""
+    return _HeadConcat.apply(conv, mb)
 
 
 class _WganLosses(torch.autograd.Function):

@@ -139,8 +139,11 @@ def discriminator_network(x, filters, groups=1):
         mbstd = minibatch_stdev(x, groups)
         conv = weighted_conv2d(inputs=x, filters=filters[-1], kernel_size=[3, 3],
                                activation=k_leaky_relu_alpha, name='conv', norm=False)
-        conv = torch.cat([F.cast(conv, torch.float32), mbstd], dim=-1)   # the dense head is f32 (bf16 storage ends here)
-        pool_flat = conv.reshape(-1, 4 * 4 * (filters[-1] + 1))
+        if conv.dtype == torch.bfloat16:                        # bf16 storage ends here: cast + concat + flatten in one pass
+            pool_flat = F.head_concat(conv, mbstd.reshape(mbstd.shape[0], 16))
+        else:
+            conv = torch.cat([F.cast(conv, torch.float32), mbstd], dim=-1)   # the dense head is f32
+            pool_flat = conv.reshape(-1, 4 * 4 * (filters[-1] + 1))
         hidden = dense(pool_flat, filters[-1], activation=k_leaky_relu_alpha, name='dense')
         logits = dense(hidden, 1, name='logits')
     return conv_layers, logits.reshape(-1)

@@ -265,18 +265,21 @@ def dense(x, w, bias=None, act=None, wscale=1.0):
     return y
 
 
-def dense_wgrad(x, dy, want_bias=True, dw_scale=1.0, shape4=False):
+def dense_wgrad(x, dy, want_bias=True, dw_scale=1.0, shape4=False, dw_out=None, db_out=None, accumulate=0):
     """(dW (K,N) * dw_scale, db (N) or None) of y = x @ w + b for a few rows: x (M,K), dY (M,N), M <= 128 (sq_dense_wgrad_f32);
-    shape4: dW as the (1,1,K,N) filter of the 1x1 conv F.dense runs the layer as."""
+    shape4: dW as the (1,1,K,N) filter of the 1x1 conv F.dense runs the layer as.  dw_out / db_out: contiguous float32
+    destinations (a parameter's gradient sink); accumulate: bit 0 -- dW is ADDED to dw_out's contents, bit 1 -- db to db_out's."""
     _chk(x, "x", ndim=2), _chk(dy, "dy", ndim=2)
     M, K = x.shape
     N = dy.shape[1]
     if dy.shape[0] != M:
         raise ValueError("dense_wgrad: x %s and dy %s differ in rows" % (tuple(x.shape), tuple(dy.shape)))
-    dw = torch.empty((1, 1, K, N) if shape4 else (K, N), dtype=torch.float32, device=x.device)
-    db = torch.empty((N,), dtype=torch.float32, device=x.device) if want_bias else None
-    _lib.check(_lib.load().sq_dense_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), M, K, N, float(dw_scale), 0, _stream()),
-               "sq_dense_wgrad_f32")
+    dw = _grad_out(dw_out, (K, N), x.device) if dw_out is not None else torch.empty(
+        (1, 1, K, N) if shape4 else (K, N), dtype=torch.float32, device=x.device)
+    db = (_grad_out(db_out, (N,), x.device) if db_out is not None else torch.empty((N,), dtype=torch.float32, device=x.device)) \
+        if want_bias else None
+    _lib.check(_lib.load().sq_dense_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), M, K, N, float(dw_scale), int(accumulate),
+                                             _stream()), "sq_dense_wgrad_f32")
     return dw, db
 
 

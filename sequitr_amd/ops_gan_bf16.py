@@ -367,3 +367,31 @@ def conv2d_pixelnorm(x, w, bias=None, act=None, wscale=1.0, eps=1e-8, want_y=Tru
     _lib.check(_lib.load().sq_conv2d_nhwc_fwd_pixelnorm_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(yn), N, H, W, Cin, Cout,
                                                             ACT[act], float(eps), _stream()), "sq_conv2d_nhwc_fwd_pixelnorm_bf16")
     return y, yn
+
+
+def head_concat(conv, mb):
+    """flat (N, P (C + 1)) f32 = concat([float(conv (N,...,C) bf16), mb (N, P) f32 as one more channel], -1) flattened per sample"""
+    _feat(conv, "conv"), _chk(mb, "mb", dtype=F32)
+    C = conv.shape[-1]
+    npix = conv.numel() // C
+    if mb.numel() != npix:
+        raise ValueError("head_concat: %d map values for %d pixels" % (mb.numel(), npix))
+    N = conv.shape[0]
+    flat = torch.empty((N, (npix // N) * (C + 1)), dtype=F32, device=conv.device)
+    _lib.check(_lib.load().sq_head_concat_fwd_bf16(_ptr(conv), _ptr(mb), _ptr(flat), npix, C, _stream()), "sq_head_concat_fwd_bf16")
+    return flat
+
+
+def head_split(dflat, conv_shape, mb_shape):
+    """the adjoint of head_concat: (dconv bf16 of conv_shape, dmb f32 of mb_shape) from dflat (N, P (C + 1)) f32"""
+    _chk(dflat, "dflat", dtype=F32)
+    C = conv_shape[-1]
+    npix = 1
+    for d in conv_shape[:-1]:
+        npix *= int(d)
+    if dflat.numel() != npix * (C + 1):
+        raise ValueError("head_split: dflat %s does not fit %s" % (tuple(dflat.shape), tuple(conv_shape)))
+    dconv = torch.empty(tuple(conv_shape), dtype=BF16, device=dflat.device)
+    dmb = torch.empty(tuple(mb_shape), dtype=F32, device=dflat.device)
+    _lib.check(_lib.load().sq_head_concat_bwd_bf16(_ptr(dflat), _ptr(dconv), _ptr(dmb), npix, C, _stream()), "sq_head_concat_bwd_bf16")
+    return dconv, dmb

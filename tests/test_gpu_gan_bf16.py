@@ -233,6 +233,42 @@ def test_pixel_norm_in_the_conv_epilogue(N, H, W, Cin, Cout):
     assert torch.equal(gx, hx) and torch.equal(gw, hw) and torch.equal(gb_, hb)     # the backward reads y only
 
 
+def test_head_concat_and_dense_gradient_sinks():
+    """F.head_concat (the discriminator's cast + concat + flatten in one pass) against the framework ops it replaces, forward,
+    backward and the second-order pass through its adjoint; and the dense layers' weight gradients written into the
+    parameters' sinks (first contribution overwrites, later ones accumulate) against the framework's sum of three."""
+    rng = np.random.default_rng(31)
+    N, C = 6, 64
+    conv_g, conv = rb(rng, (N, 4, 4, C))
+    mb = torch.as_tensor(rng.standard_normal((N, 16)), dtype=torch.float32).cuda()
+    flat = F.head_concat(conv_g, mb)
+    want = torch.cat([conv_g.float(), mb.reshape(N, 4, 4, 1)], -1).reshape(N, 16 * (C + 1))
+    assert flat.dtype == torch.float32 and torch.equal(flat, want)
+    cg, mg = conv_g.clone().requires_grad_(True), mb.clone().requires_grad_(True)
+    g = torch.as_tensor(rng.standard_normal((N, 16 * (C + 1))), dtype=torch.float32).cuda().requires_grad_(True)
+    dconv, dmb = torch.autograd.grad(F.head_concat(cg, mg), [cg, mg], g, create_graph=True)
+    gv = g.detach().reshape(N, 4, 4, C + 1)
+    assert dconv.dtype == BF and torch.equal(dconv, gv[..., :C].to(BF)) and torch.equal(dmb, gv[..., C].reshape(N, 16))
+    v1 = torch.as_tensor(rng.standard_normal((N, 4, 4, C)), dtype=torch.float32).to(BF).cuda()
+    v2 = torch.as_tensor(rng.standard_normal((N, 16)), dtype=torch.float32).cuda()
+    (dg,) = torch.autograd.grad([dconv, dmb], [g], [v1, v2])    # d/d(dflat) of the split = the concat of the two cotangents
+    assert torch.equal(dg, torch.cat([v1.float(), v2.reshape(N, 4, 4, 1)], -1).reshape(N, -1))
+    # dense sinks: three contributions to one (Kin, N) kernel and its bias
+    M, Kin, Nout = 8, 1040, 64
+    w = torch.as_tensor(rng.standard_normal((Kin, Nout)) * 0.05, dtype=torch.float32).cuda().requires_grad_(True)
+    b = torch.zeros(Nout, device="cuda").requires_grad_(True)
+    xs = [torch.as_tensor(rng.standard_normal((M, Kin)), dtype=torch.float32).cuda() for _ in range(3)]
+
+    def loss():
+        return sum((F.dense(x, w, b, act="leaky") * (k + 1.0)).sum() for k, x in enumerate(xs))
+    ref_w, ref_b = torch.autograd.grad(loss(), [w, b])
+    sinks = {id(w): torch.full((Kin, Nout), 7.0, device="cuda"), id(b): torch.full((Nout,), 7.0, device="cuda")}
+    with F.grad_sinks(sinks) as sk:
+        got = torch.autograd.grad(loss(), [w, b], allow_unused=True)
+    assert got[0] is None and got[1] is None and sk.touched == {id(w), id(b)}
+    assert torch.allclose(sinks[id(w)], ref_w, rtol=1e-5, atol=1e-5) and torch.allclose(sinks[id(b)], ref_b, rtol=1e-5, atol=1e-4)
+
+
 def _rel(a, t):
     a, t = np.asarray(a, np.float64), np.asarray(t, np.float64)
     return float(np.linalg.norm((a - t).ravel()) / max(np.linalg.norm(t.ravel()), 1e-30))
