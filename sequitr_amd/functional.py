@@ -679,7 +679,25 @@ def scale_per_sample(x, s, one_minus=False):
     return _ScalePerSample.apply(x, s, one_minus)
 
 
+class _SqNormPerSample(torch.autograd.Function):
+    """out[n] = sum_i a[n,i]^2: dot_per_sample(a, a) as a ONE-input op -- with two inputs the tape sends `a` two equal gradients
+    (two per-sample scalings of an image-sized tensor and the framework's add of them); here one scaling by 2 dout"""
+
+    @staticmethod
+    def forward(ctx, a):
+        a = a.contiguous()
+        ctx.save_for_backward(a)
+        return ops.dot_per_sample(a, a)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (a,) = ctx.saved_tensors
+        return _ScalePerSample.apply(a, dout + dout, False)
+
+
 def dot_per_sample(a, b):
+    if a is b:
+        return _SqNormPerSample.apply(a)
     return _DotPerSample.apply(a, b)
 
 
