@@ -295,6 +295,12 @@ int sq_mbstd_map_bwd_f32(const float *x, const float *dy, float *dx, float *work
                          int64_t per_sample, int cells, void *stream);
 int sq_mbstd_map_bwd2_f32(const float *x, const float *dy, const float *v, float *ddy, float *dx2, float *workspace,
                           int groups, int n, int64_t per_sample, int cells, void *stream);
+/* the same three with the feature tensors (x, v, dx, dx2) in bf16 storage -- f32 arithmetic, results rounded once; y, dy, ddy f32 */
+int sq_mbstd_map_fwd_bf16(const void *x, float *y, float *workspace, int groups, int n, int64_t per_sample, int cells, void *stream);
+int sq_mbstd_map_bwd_bf16(const void *x, const float *dy, void *dx, float *workspace, int groups, int n, int64_t per_sample,
+                          int cells, void *stream);
+int sq_mbstd_map_bwd2_bf16(const void *x, const float *dy, const void *v, float *ddy, void *dx2, float *workspace, int groups,
+                           int n, int64_t per_sample, int cells, void *stream);
 /* WGAN-GP loss algebra of gan.py:715-729 in one launch: out2 = {d_loss, g_loss} from Dz, Dx (N) and gn2 (N) = squared
  * norm of dD(mix)/dmix per sample (one-sided penalty, lambda 10, eps drift 0.001 Dx^2); Dx = gn2 = NULL: g_loss only.
  * bwd: g_dloss / g_gloss = upstream gradients (device scalars, NULL = 0) -> dDz, dDx, dgn2. */

@@ -108,6 +108,9 @@ SIGNATURES = {
     "sq_mbstd_map_fwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int64, c_int, c_void_p]),
     "sq_mbstd_map_bwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int64, c_int, c_void_p]),
     "sq_mbstd_map_bwd2_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int64, c_int, c_void_p]),
+    "sq_mbstd_map_fwd_bf16": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int64, c_int, c_void_p]),
+    "sq_mbstd_map_bwd_bf16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int64, c_int, c_void_p]),
+    "sq_mbstd_map_bwd2_bf16": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int64, c_int, c_void_p]),
     "sq_wgan_losses_fwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "sq_wgan_losses_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_void_p]),
     "sq_dense_wgrad_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_float, c_int, c_void_p]),

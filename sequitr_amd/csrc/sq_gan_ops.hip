@@ -516,12 +516,15 @@ __device__ __forceinline__ float mb_block_sum(float v, float *red) {
 
 // stage 1, grid (MB_B, groups): block b sums its positions' batch variances (and, with v, its share of
 // A = sum_ij V_ij (x_ij - mu_j)) -> partials[g][b] = {var sum, A}
-__global__ __launch_bounds__(MB_BT) void mbstd_stats_kernel(const float *__restrict__ x, const float *__restrict__ v,
+// TX: storage type of the feature tensors x / v / dx / dx2 (float, or __bf16 under the GAN's bf16 storage: the arithmetic is
+// f32 either way and a bf16 result is the f32 value rounded once -- what a separate cast kernel did); dy / ddy stay f32
+template <typename TX>
+__global__ __launch_bounds__(MB_BT) void mbstd_stats_kernel(const TX *__restrict__ x, const TX *__restrict__ v,
                                                             float *__restrict__ partials, int n, int64_t P) {
     __shared__ float red[MB_BT];
     const int g = blockIdx.y;
-    const float *xg = x + (int64_t)g * n * P;
-    const float *vg = v ? v + (int64_t)g * n * P : nullptr;
+    const TX *xg = x + (int64_t)g * n * P;
+    const TX *vg = v ? v + (int64_t)g * n * P : nullptr;
     float acc = 0.f, aa = 0.f;
     for (int64_t p = (int64_t)blockIdx.x * MB_BT + threadIdx.x; p < P; p += (int64_t)MB_B * MB_BT) {
         // eight samples' loads in flight at a time (same order of the sums): one load per trip was a chain of 2 n round trips
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(MB_BT) void mbstd_stats_kernel(const float *__restr
         for (int i0 = 0; i0 < n; i0 += 8) {
             float xv[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) xv[k] = i0 + k < n ? xg[(int64_t)(i0 + k) * P + p] : 0.f;
+            for (int k = 0; k < 8; ++k) xv[k] = i0 + k < n ? (float)xg[(int64_t)(i0 + k) * P + p] : 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) mu += xv[k];
         }
@@ -539,8 +542,8 @@ __global__ __launch_bounds__(MB_BT) void mbstd_stats_kernel(const float *__restr
             float xv[8], vv[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                xv[k] = i0 + k < n ? xg[(int64_t)(i0 + k) * P + p] : mu;
-                vv[k] = (vg && i0 + k < n) ? vg[(int64_t)(i0 + k) * P + p] : 0.f;
+                xv[k] = i0 + k < n ? (float)xg[(int64_t)(i0 + k) * P + p] : mu;
+                vv[k] = (vg && i0 + k < n) ? (float)vg[(int64_t)(i0 + k) * P + p] : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -585,31 +588,33 @@ __global__ __launch_bounds__(MB_BT) void mbstd_map_fill_kernel(const float *__re
     for (int e = threadIdx.x; e < n * cells; e += MB_BT) y[(int64_t)g * n * cells + e] = s;
 }
 
-__global__ __launch_bounds__(MB_BT) void mbstd_map_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
-                                                              const float *__restrict__ partials, float *__restrict__ dx, int n,
+template <typename TX>
+__global__ __launch_bounds__(MB_BT) void mbstd_map_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ dy,
+                                                              const float *__restrict__ partials, TX *__restrict__ dx, int n,
                                                               int64_t P, int cells) {
     __shared__ float red[MB_BT];
     const int g = blockIdx.y;
-    const float *xg = x + (int64_t)g * n * P;
+    const TX *xg = x + (int64_t)g * n * P;
     float s, A;
     mb_fold(partials, g, P, &s, &A);
     const float ds = mb_group_dy_sum(dy + (int64_t)g * n * cells, n * cells, red);
     const float k = ds / ((float)P * (float)n) / s;
     for (int64_t p = (int64_t)blockIdx.x * MB_BT + threadIdx.x; p < P; p += (int64_t)MB_B * MB_BT) {
         float mu = 0.f;
-        for (int i = 0; i < n; ++i) mu += xg[(int64_t)i * P + p];
+        for (int i = 0; i < n; ++i) mu += (float)xg[(int64_t)i * P + p];
         mu /= (float)n;
-        for (int i = 0; i < n; ++i) dx[((int64_t)g * n + i) * P + p] = k * (xg[(int64_t)i * P + p] - mu);
+        for (int i = 0; i < n; ++i) dx[((int64_t)g * n + i) * P + p] = (TX)(k * ((float)xg[(int64_t)i * P + p] - mu));
     }
 }
 
-__global__ __launch_bounds__(MB_BT) void mbstd_map_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ dy,
-                                                               const float *__restrict__ v, const float *__restrict__ partials,
-                                                               float *__restrict__ ddy, float *__restrict__ dx2, int n, int64_t P,
+template <typename TX>
+__global__ __launch_bounds__(MB_BT) void mbstd_map_bwd2_kernel(const TX *__restrict__ x, const float *__restrict__ dy,
+                                                               const TX *__restrict__ v, const float *__restrict__ partials,
+                                                               float *__restrict__ ddy, TX *__restrict__ dx2, int n, int64_t P,
                                                                int cells) {
     __shared__ float red[MB_BT];
     const int g = blockIdx.y;
-    const float *xg = x + (int64_t)g * n * P, *vg = v + (int64_t)g * n * P;
+    const TX *xg = x + (int64_t)g * n * P, *vg = v + (int64_t)g * n * P;
     float s, A;
     mb_fold(partials, g, P, &s, &A);
     const float ds = mb_group_dy_sum(dy + (int64_t)g * n * cells, n * cells, red);
@@ -621,11 +626,11 @@ __global__ __launch_bounds__(MB_BT) void mbstd_map_bwd2_kernel(const float *__re
     const float k1 = ds * c / s, k2 = A * c / (s * s);
     for (int64_t p = (int64_t)blockIdx.x * MB_BT + threadIdx.x; p < P; p += (int64_t)MB_B * MB_BT) {
         float mu = 0.f, vb = 0.f;
-        for (int i = 0; i < n; ++i) { mu += xg[(int64_t)i * P + p]; vb += vg[(int64_t)i * P + p]; }
+        for (int i = 0; i < n; ++i) { mu += (float)xg[(int64_t)i * P + p]; vb += (float)vg[(int64_t)i * P + p]; }
         mu /= (float)n;
         vb /= (float)n;
         for (int i = 0; i < n; ++i)
-            dx2[((int64_t)g * n + i) * P + p] = k1 * ((vg[(int64_t)i * P + p] - vb) - k2 * (xg[(int64_t)i * P + p] - mu));
+            dx2[((int64_t)g * n + i) * P + p] = (TX)(k1 * (((float)vg[(int64_t)i * P + p] - vb) - k2 * ((float)xg[(int64_t)i * P + p] - mu)));
     }
 }
 
@@ -671,38 +676,79 @@ __global__ __launch_bounds__(MB_T) void wgan_losses_bwd_kernel(const float *__re
 
 extern "C" int64_t sq_mbstd_map_workspace(int groups) { return groups > 0 ? (int64_t)groups * MB_B * 2 * 4 : -1; }
 
+namespace {
+template <typename TX>
+int mbstd_map_fwd_t(const TX *x, float *y, float *workspace, int groups, int n, int64_t per_sample, int cells, void *stream,
+                    const char *what) {
+    hipLaunchKernelGGL(mbstd_stats_kernel<TX>, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, (const TX *)nullptr, workspace, n,
+                       per_sample);
+    int rc = sq_check_launch(what);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mbstd_map_fill_kernel, dim3(groups), dim3(MB_BT), 0, SQ_ST(stream), workspace, y, n, per_sample, cells);
+    return sq_check_launch(what);
+}
+template <typename TX>
+int mbstd_map_bwd_t(const TX *x, const float *dy, TX *dx, float *workspace, int groups, int n, int64_t per_sample, int cells,
+                    void *stream, const char *what) {
+    hipLaunchKernelGGL(mbstd_stats_kernel<TX>, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, (const TX *)nullptr, workspace, n,
+                       per_sample);
+    int rc = sq_check_launch(what);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mbstd_map_bwd_kernel<TX>, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, dy, workspace, dx, n, per_sample,
+                       cells);
+    return sq_check_launch(what);
+}
+template <typename TX>
+int mbstd_map_bwd2_t(const TX *x, const float *dy, const TX *v, float *ddy, TX *dx2, float *workspace, int groups, int n,
+                     int64_t per_sample, int cells, void *stream, const char *what) {
+    hipLaunchKernelGGL(mbstd_stats_kernel<TX>, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, v, workspace, n, per_sample);
+    int rc = sq_check_launch(what);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mbstd_map_bwd2_kernel<TX>, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, dy, v, workspace, ddy, dx2, n,
+                       per_sample, cells);
+    return sq_check_launch(what);
+}
+}  // namespace
+
 extern "C" int sq_mbstd_map_fwd_f32(const float *x, float *y, float *workspace, int groups, int n, int64_t per_sample,
                                     int cells, void *stream) {
     SQ_REQUIRE(x && y && workspace && groups > 0 && n > 0 && per_sample > 0 && cells > 0, "sq_mbstd_map_fwd_f32: bad arguments");
-    hipLaunchKernelGGL(mbstd_stats_kernel, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, (const float *)nullptr,
-                       workspace, n, per_sample);
-    int rc = sq_check_launch("sq_mbstd_map_fwd_f32(stats)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(mbstd_map_fill_kernel, dim3(groups), dim3(MB_BT), 0, SQ_ST(stream), workspace, y, n, per_sample, cells);
-    return sq_check_launch("sq_mbstd_map_fwd_f32");
+    return mbstd_map_fwd_t<float>(x, y, workspace, groups, n, per_sample, cells, stream, "sq_mbstd_map_fwd_f32");
 }
 extern "C" int sq_mbstd_map_bwd_f32(const float *x, const float *dy, float *dx, float *workspace, int groups, int n,
                                     int64_t per_sample, int cells, void *stream) {
     SQ_REQUIRE(x && dy && dx && workspace && groups > 0 && n > 0 && per_sample > 0 && cells > 0,
                "sq_mbstd_map_bwd_f32: bad arguments");
-    hipLaunchKernelGGL(mbstd_stats_kernel, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, (const float *)nullptr,
-                       workspace, n, per_sample);
-    int rc = sq_check_launch("sq_mbstd_map_bwd_f32(stats)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(mbstd_map_bwd_kernel, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, dy, workspace, dx, n,
-                       per_sample, cells);
-    return sq_check_launch("sq_mbstd_map_bwd_f32");
+    return mbstd_map_bwd_t<float>(x, dy, dx, workspace, groups, n, per_sample, cells, stream, "sq_mbstd_map_bwd_f32");
 }
 extern "C" int sq_mbstd_map_bwd2_f32(const float *x, const float *dy, const float *v, float *ddy, float *dx2,
                                      float *workspace, int groups, int n, int64_t per_sample, int cells, void *stream) {
     SQ_REQUIRE(x && dy && v && ddy && dx2 && workspace && groups > 0 && n > 0 && per_sample > 0 && cells > 0,
                "sq_mbstd_map_bwd2_f32: bad arguments");
-    hipLaunchKernelGGL(mbstd_stats_kernel, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, v, workspace, n, per_sample);
-    int rc = sq_check_launch("sq_mbstd_map_bwd2_f32(stats)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(mbstd_map_bwd2_kernel, dim3(MB_B, groups), dim3(MB_BT), 0, SQ_ST(stream), x, dy, v, workspace, ddy, dx2,
-                       n, per_sample, cells);
-    return sq_check_launch("sq_mbstd_map_bwd2_f32");
+    return mbstd_map_bwd2_t<float>(x, dy, v, ddy, dx2, workspace, groups, n, per_sample, cells, stream, "sq_mbstd_map_bwd2_f32");
+}
+// the same three on bf16 FEATURE tensors (x, v, dx, dx2 bf16; the map y, dy, ddy f32): the statistic is taken of the values the
+// tensor stores, the gradients are the f32 results rounded once -- no cast launches around the statistic
+extern "C" int sq_mbstd_map_fwd_bf16(const void *x, float *y, float *workspace, int groups, int n, int64_t per_sample, int cells,
+                                     void *stream) {
+    SQ_REQUIRE(x && y && workspace && groups > 0 && n > 0 && per_sample > 0 && cells > 0, "sq_mbstd_map_fwd_bf16: bad arguments");
+    return mbstd_map_fwd_t<__bf16>(reinterpret_cast<const __bf16 *>(x), y, workspace, groups, n, per_sample, cells, stream,
+                                   "sq_mbstd_map_fwd_bf16");
+}
+extern "C" int sq_mbstd_map_bwd_bf16(const void *x, const float *dy, void *dx, float *workspace, int groups, int n,
+                                     int64_t per_sample, int cells, void *stream) {
+    SQ_REQUIRE(x && dy && dx && workspace && groups > 0 && n > 0 && per_sample > 0 && cells > 0,
+               "sq_mbstd_map_bwd_bf16: bad arguments");
+    return mbstd_map_bwd_t<__bf16>(reinterpret_cast<const __bf16 *>(x), dy, reinterpret_cast<__bf16 *>(dx), workspace, groups, n,
+                                   per_sample, cells, stream, "sq_mbstd_map_bwd_bf16");
+}
+extern "C" int sq_mbstd_map_bwd2_bf16(const void *x, const float *dy, const void *v, float *ddy, void *dx2, float *workspace,
+                                      int groups, int n, int64_t per_sample, int cells, void *stream) {
+    SQ_REQUIRE(x && dy && v && ddy && dx2 && workspace && groups > 0 && n > 0 && per_sample > 0 && cells > 0,
+               "sq_mbstd_map_bwd2_bf16: bad arguments");
+    return mbstd_map_bwd2_t<__bf16>(reinterpret_cast<const __bf16 *>(x), dy, reinterpret_cast<const __bf16 *>(v), ddy,
+                                    reinterpret_cast<__bf16 *>(dx2), workspace, groups, n, per_sample, cells, stream,
+                                    "sq_mbstd_map_bwd2_bf16");
 }
 extern "C" int sq_wgan_losses_fwd_f32(const float *Dz, const float *Dx, const float *gn2, float *out2, int N, void *stream) {
     SQ_REQUIRE(Dz && out2 && N > 0 && ((Dx == nullptr) == (gn2 == nullptr)), "sq_wgan_losses_fwd_f32: bad arguments");

@@ -116,7 +116,8 @@ def minibatch_stdev(x, groups=1):
     constant feature map (N,4,4,1): one workgroup per minibatch (sq_mbstd_map_*_f32, differentiable twice).
     groups > 1: x is `groups` minibatches stacked along the batch axis, each gets its own statistic
     (the reference evaluates the discriminator once per minibatch; see _build_network)."""
-    x = F.cast(x, torch.float32)          # bf16 storage: the statistic (32 x 16 x 512 values) is taken of the f32 copy
+    # bf16 storage: the kernels read the bf16 features themselves (f32 arithmetic) and hand back bf16 gradients -- what the
+    # f32 copy and the casts of its gradients gave, bit for bit, without their launches
     return F.mbstd_map(x, groups, 16).reshape(x.shape[0], 4, 4, 1)
 
 

@@ -934,38 +934,45 @@ def mbstd(x):
 
 
 def mbstd_map(x, groups=1, cells=16):
-    """minibatch-stdev feature map (gan.py:204-212): x (G*n, ...) -> (G*n, cells) filled with each group's statistic"""
-    _chk(x, "x")
+    """minibatch-stdev feature map (gan.py:204-212): x (G*n, ...) f32 or bf16 -> (G*n, cells) f32 filled with each group's
+    statistic"""
+    bf = x.dtype == _BF16
+    _chk(x, "x", dtype=x.dtype if bf else torch.float32)
     N = x.shape[0]
     if N % groups:
         raise ValueError("mbstd_map: batch %d is not %d equal groups" % (N, groups))
     y = torch.empty((N, cells), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     ws = _workspace(lib.sq_mbstd_map_workspace(groups), x.device)
-    _lib.check(lib.sq_mbstd_map_fwd_f32(_ptr(x), _ptr(y), _ptr(ws), groups, N // groups, x.numel() // N, cells, _stream()),
-               "sq_mbstd_map_fwd_f32")
+    fn = lib.sq_mbstd_map_fwd_bf16 if bf else lib.sq_mbstd_map_fwd_f32
+    _lib.check(fn(_ptr(x), _ptr(y), _ptr(ws), groups, N // groups, x.numel() // N, cells, _stream()), "sq_mbstd_map_fwd")
     return y
 
 
 def mbstd_map_bwd(x, dy, groups=1):
-    _chk(x, "x"), _chk(dy, "dy")
+    """dx (x's dtype: bf16 features get a bf16 gradient, the f32 value rounded once)"""
+    bf = x.dtype == _BF16
+    _chk(x, "x", dtype=x.dtype if bf else torch.float32), _chk(dy, "dy")
     N = x.shape[0]
     dx = torch.empty_like(x)
     lib = _lib.load()
     ws = _workspace(lib.sq_mbstd_map_workspace(groups), x.device)
-    _lib.check(lib.sq_mbstd_map_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), _ptr(ws), groups, N // groups, x.numel() // N,
-                                       dy.numel() // N, _stream()), "sq_mbstd_map_bwd_f32")
+    fn = lib.sq_mbstd_map_bwd_bf16 if bf else lib.sq_mbstd_map_bwd_f32
+    _lib.check(fn(_ptr(x), _ptr(dy), _ptr(dx), _ptr(ws), groups, N // groups, x.numel() // N, dy.numel() // N, _stream()),
+               "sq_mbstd_map_bwd")
     return dx
 
 
 def mbstd_map_bwd2(x, dy, v, groups=1):
-    _chk(x, "x"), _chk(dy, "dy"), _chk(v, "v")
+    bf = x.dtype == _BF16
+    _chk(x, "x", dtype=x.dtype if bf else torch.float32), _chk(dy, "dy"), _chk(v, "v", dtype=x.dtype if bf else torch.float32)
     N = x.shape[0]
     ddy, dx2 = torch.empty_like(dy), torch.empty_like(x)
     lib = _lib.load()
     ws = _workspace(lib.sq_mbstd_map_workspace(groups), x.device)
-    _lib.check(lib.sq_mbstd_map_bwd2_f32(_ptr(x), _ptr(dy), _ptr(v), _ptr(ddy), _ptr(dx2), _ptr(ws), groups, N // groups,
-                                        x.numel() // N, dy.numel() // N, _stream()), "sq_mbstd_map_bwd2_f32")
+    fn = lib.sq_mbstd_map_bwd2_bf16 if bf else lib.sq_mbstd_map_bwd2_f32
+    _lib.check(fn(_ptr(x), _ptr(dy), _ptr(v), _ptr(ddy), _ptr(dx2), _ptr(ws), groups, N // groups, x.numel() // N, dy.numel() // N,
+                  _stream()), "sq_mbstd_map_bwd2")
     return ddy, dx2
 
 

@@ -233,6 +233,23 @@ def test_pixel_norm_in_the_conv_epilogue(N, H, W, Cin, Cout):
     assert torch.equal(gx, hx) and torch.equal(gw, hw) and torch.equal(gb_, hb)     # the backward reads y only
 
 
+def test_minibatch_stdev_on_bf16_features_equals_the_f32_kernels_round_the_casts():
+    """sq_mbstd_map_{fwd,bwd,bwd2}_bf16: the statistic and its two derivatives straight from bf16 features -- the bits the f32
+    kernels gave between a cast of x to f32 and casts of the gradients back to bf16"""
+    rng = np.random.default_rng(17)
+    for N, groups in ((8, 2), (6, 1)):
+        xg, _ = rb(rng, (N, 4, 4, 64))
+        dy = torch.as_tensor(rng.standard_normal((N, 16)), dtype=torch.float32).cuda()
+        vg, _ = rb(rng, (N, 4, 4, 64))
+        xf, vf = xg.float(), vg.float()
+        assert torch.equal(ops.mbstd_map(xg, groups, 16), ops.mbstd_map(xf, groups, 16))
+        dx = ops.mbstd_map_bwd(xg, dy, groups)
+        assert dx.dtype == BF and torch.equal(dx, ops.mbstd_map_bwd(xf, dy, groups).to(BF))
+        ddy, dx2 = ops.mbstd_map_bwd2(xg, dy, vg, groups)
+        rdy, rx2 = ops.mbstd_map_bwd2(xf, dy, vf, groups)
+        assert dx2.dtype == BF and torch.equal(ddy, rdy) and torch.equal(dx2, rx2.to(BF))
+
+
 def test_head_concat_and_dense_gradient_sinks():
     """F.head_concat (the discriminator's cast + concat + flatten in one pass) against the framework ops it replaces, forward,
     backward and the second-order pass through its adjoint; and the dense layers' weight gradients written into the
