@@ -23,6 +23,7 @@
 //     tensor (537 MB per 32-tile batch) is never written or re-read and the HBM-bound convT launch disappears.
 #include <stdlib.h>
 #include "sq_common.h"
+#include "sq_conv_epi.h"
 
 #ifndef SQ_TILE_INTERLEAVE
 #define SQ_TILE_INTERLEAVE 1    // block b takes tiles b, b+G, b+2G, ...; 0: a contiguous run per block (A/B switch, HISTORY.md 4a)
@@ -31,23 +32,6 @@
 #define SQ_STORE_PERMUTE 0      // 1: lane-contiguous stores through ds_bpermute (A/B switch: no measurable difference, HISTORY.md 4a)
 #endif
 
-struct SqConvEpi {
-    float *pooled;          // (N,H/2,W/2,Cout) or NULL
-    const float *head_w;    // (Cout, head_c) 1x1 head or NULL (needs Cout == 16)
-    const float *head_b;    // (head_c) or NULL
-    float *logits;          // (N,H,W,head_c)
-    uint8_t *mask;          // (N,H,W) or NULL
-    int head_c;
-    int store_y;
-    const float *first_w;   // FIRST only: (3,3,1,16) and (16)
-    const float *first_b;
-    const float *up_x;      // UP only: low-resolution input (N,H/2,W/2,32)
-    const float *up_w;      //          transpose-conv kernel (2,2,16,32) and bias (16)
-    const float *up_b;
-    int up_bridge;          //          SQ_BRIDGE_*: merged = bridge(convT(up_x), x)
-    const float *x2;        // concat bridge (unet.py:196-197): channels [Cin/2, Cin) of the input come from this second
-                            // tensor (N,H,W,Cin/2), channels [0, Cin/2) from x: tf.concat([upscale, skip], -1) never exists
-};
 
 namespace {
 
@@ -682,6 +666,10 @@ int sq_conv_mfma_v2(const float *x, const float *w, const float *bias, float *y,
                     int Cin, int Cout, int K, float wscale, int act, hipStream_t st) {
     SqConvEpi epi = {};
     epi.store_y = 1;
+    if (Cin == 16 && Cout == 16 && K == 3 && wscale == 1.0f) {
+        const int r = sq_conv_l0_launch(0, x, w, bias, y, N, H, W, act, epi, st);
+        if (r != SQ_L0_NOT_MINE) return r;
+    }
     if (Cin % 16 == 0)
         return K == 3 ? dispatch_bn<3, 16>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st)
                       : dispatch_bn<1, 16>(x, w, bias, y, N, H, W, Cin, Cout, wscale, act, epi, st);
@@ -725,6 +713,10 @@ extern "C" int sq_conv3x3_pool_fwd_f32(const float *x, const float *w, const flo
     SqConvEpi epi = {};
     epi.store_y = 1;
     epi.pooled = pooled;
+    if (Cin == 16 && Cout == 16) {
+        const int r = sq_conv_l0_launch(0, x, w, bias, y, N, H, W, act, epi, reinterpret_cast<hipStream_t>(stream));
+        if (r != SQ_L0_NOT_MINE) return r;
+    }
     return dispatch_bn<3, 16>(x, w, bias, y, N, H, W, Cin, Cout, 1.0f, act, epi, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -743,6 +735,10 @@ extern "C" int sq_conv3x3_head_fwd_f32(const float *x, const float *w, const flo
     SqConvEpi epi = {};
     epi.store_y = 0;
     epi.head_w = head_w; epi.head_b = head_b; epi.logits = logits; epi.mask = mask; epi.head_c = head_c;
+    if (Cin == 16) {
+        const int r = sq_conv_l0_launch(0, x, w, bias, nullptr, N, H, W, act, epi, reinterpret_cast<hipStream_t>(stream));
+        if (r != SQ_L0_NOT_MINE) return r;
+    }
     return launch_v2<16, 3, 16, false>(x, w, bias, nullptr, N, H, W, Cin, 16, 1.0f, act, epi,
                                        reinterpret_cast<hipStream_t>(stream));
 }
@@ -763,6 +759,10 @@ extern "C" int sq_conv3x3_first_block_fwd_f32(const float *x, const float *w1, c
     epi.store_y = 1;
     epi.pooled = pooled;
     epi.first_w = w1; epi.first_b = b1;
+    {
+        const int r = sq_conv_l0_launch(1, x, w2, b2, y, N, H, W, SQ_ACT_RELU, epi, reinterpret_cast<hipStream_t>(stream));
+        if (r != SQ_L0_NOT_MINE) return r;
+    }
     return launch_v2<16, 3, 16, true>(x, w2, b2, y, N, H, W, 1, 16, 1.0f, SQ_ACT_RELU, epi,
                                       reinterpret_cast<hipStream_t>(stream));
 }
@@ -785,6 +785,10 @@ extern "C" int sq_convT_conv3x3_fwd_f32(const float *x_low, const float *wt, con
     SqConvEpi epi = {};
     epi.store_y = 1;
     epi.up_x = x_low; epi.up_w = wt; epi.up_b = bt; epi.up_bridge = bridge;
+    {
+        const int r = sq_conv_l0_launch(2, skip, w, bias, y, N, H, W, act, epi, reinterpret_cast<hipStream_t>(stream));
+        if (r != SQ_L0_NOT_MINE) return r;
+    }
     return launch_v2<16, 3, 16, 2>(skip, w, bias, y, N, H, W, 16, 16, 1.0f, act, epi,
                                    reinterpret_cast<hipStream_t>(stream));
 }

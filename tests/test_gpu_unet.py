@@ -70,6 +70,45 @@ def test_fused_kernels_individually_bit_exact():
         assert_bit_exact(mask.cpu().numpy(), co.argmax_u8(r), "fused head mask C=%d" % hc)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 80), (1, 16, 16), (3, 32, 48), (1, 96, 96)])
+def test_level0_kernel_family_bit_exact(shape):
+    """sq_conv_f32_l0.hip (16 -> 16 channels, H and W multiples of 16: filter in registers, channel-transposed halo
+    image, head from registers, FIRST / UP with two barriers per tile) against the C oracle, bit for bit: tiles on the
+    image border and interior tiles (their loads take the unchecked path), one tile and several tiles per image."""
+    from oracle import c_oracle as co
+    from tests.util import rand_weights
+    N, H, W = shape
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    w, b = rand_weights(41, (3, 3, 16, 16)), rand_weights(42, (16,), 0.1)
+    x = tiles(43, N, H, W, 16)
+    r = co.conv2d(x, w, b, act="relu")
+    assert_bit_exact(ops.conv2d(dev(x), dev(w), dev(b), act="relu").cpu().numpy(), r, "plain 16->16")
+    y, p = ops.conv3x3_pool(dev(x), dev(w), dev(b))
+    assert_bit_exact(y.cpu().numpy(), r, "conv+pool y")
+    assert_bit_exact(p.cpu().numpy(), co.maxpool2x2(r), "conv+pool pooled")
+    hw, hb = rand_weights(44, (1, 1, 16, 2)), rand_weights(45, (2,), 0.1)
+    rl = co.conv2d(r, hw, hb, act=None)
+    logits, mask = ops.conv3x3_head(dev(x), dev(w), dev(b), dev(hw), dev(hb))
+    assert_bit_exact(logits.cpu().numpy(), rl, "head logits")
+    assert_bit_exact(mask.cpu().numpy(), co.argmax_u8(rl), "head mask")
+    x1 = tiles(46, N, H, W, 1)
+    w1, b1 = rand_weights(47, (3, 3, 1, 16), 0.5), rand_weights(48, (16,), 0.1)
+    r1 = co.conv2d(co.conv2d(x1, w1, b1, act="relu"), w, b, act="relu")
+    y, p = ops.conv3x3_first_block(dev(x1), dev(w1), dev(b1), dev(w), dev(b))
+    assert_bit_exact(y.cpu().numpy(), r1, "first block y")
+    assert_bit_exact(p.cpu().numpy(), co.maxpool2x2(r1), "first block pooled")
+    y, p = ops.conv3x3_first_block(dev(x1), dev(w1), dev(b1), dev(w), dev(b), want_pool=False)
+    assert p is None
+    assert_bit_exact(y.cpu().numpy(), r1, "first block y (no pool)")
+    rng = np.random.default_rng(H + W)
+    xl = rng.standard_normal((N, H // 2, W // 2, 32)).astype(np.float32)
+    wt, bt = rand_weights(49, (2, 2, 16, 32), 0.2), rand_weights(50, (16,), 0.1)
+    for bridge in ("eltwise_mul", "eltwise_add", "eltwise_sub", None):
+        y = ops.convT_conv3x3(dev(xl), dev(wt), dev(bt), dev(x), bridge, dev(w), dev(b), act="relu")
+        merged = co.convT2x2s2(xl, wt, bt, skip=x if bridge else None, bridge=bridge)
+        assert_bit_exact(y.cpu().numpy(), co.conv2d(merged, w, b, act="relu"), "fused up block (%s)" % bridge)
+
+
 def test_lazy_init_equals_host_init():
     """variables created lazily during build() draw the same stream as init_unet_weights."""
     params = {"shape": (32, 32), "seed": 7, "device": "cuda:0"}
