@@ -15,9 +15,10 @@
 //     per-lane offset: no bounds arithmetic; the tile coordinates advance by carries, not by division;
 //   * the epilogue is compiled per kind (store / store + 2x2 max-pool / 1x1 head + argmax) with ReLU as v_max;
 //   * the 1x1 head runs from registers: the accumulators' [channel quad][pixel] layout is transposed across the
-//     wave's four 16-lane rows with v_permlane16_swap / v_permlane32_swap (4 instructions per output row, no LDS, no
-//     wave barrier), the four rows of a wave run as four independent MFMA chains whose A operands place the head
-//     outputs of row r in lane row r, and all 64 lanes store their pixel's two logits as one 8-byte store;
+//     wave's four 16-lane rows with v_permlane16_swap / v_permlane32_swap (16 instructions, no LDS image, no wave
+//     barrier) so that every lane owns one pixel with its 16 channels, the head is 16 v_mfma_f32_4x4x1 (one channel
+//     each, 2 passes) instead of 16 v_mfma_f32_16x16x4 (8 passes, 14 of 16 rows zero), and all 64 lanes store their
+//     pixel's two logits as one 8-byte store;
 //   * FIRST (conv1 of down0 on the fly): the 20 x 20 input patch is double-buffered in LDS and fetched two tiles
 //     ahead, so a tile costs two block barriers instead of three;
 //   * UP (transpose conv + bridge on the fly): the low-resolution patch is fetched two tiles ahead and committed at the
@@ -28,6 +29,9 @@
 #include "sq_common.h"
 #include "sq_conv_epi.h"
 
+#ifndef SQ_L0_OCC
+#define SQ_L0_OCC 4                  // resident blocks per CU of the plain / FIRST forms (A/B switch)
+#endif
 #ifndef SQ_L0_UP_OCC
 #define SQ_L0_UP_OCC 2               // resident blocks per CU of the UP form: 190 registers unspilled; at 3 (168) the prefetch registers spill: 625 vs 486 us
 #endif
@@ -72,7 +76,7 @@ __device__ __forceinline__ void row_transpose(float &a0, float &a1, float &a2, f
 __device__ __forceinline__ float relu(float v) { return __builtin_fmaxf(v, 0.0f); }   // NaN -> 0, -0 -> +0 like (v > 0 ? v : 0)
 
 template <int MODE, int EPI, int BRIDGE>
-__global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : 4)) void conv_l0_kernel(const L0Args a) {
+__global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC)) void conv_l0_kernel(const L0Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xs = smem;
     float *xin = smem + XS_FLOATS;              // FIRST: two 20 x 20 patches
@@ -390,8 +394,11 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : 4)) void conv_l
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
         a.epi.pooled, 0, EPI == EPI_POOL ? (int)((size_t)a.N * Hl * Wl * 16 * 4) : 0, 0x00020000);
     const int pvoff = (((2 * wv) * Wl + (li >> 1)) * 16 + 4 * kk) * 4;
-    // head: A[m = head output][k = channel 4 s + kk] (rows 2..15 zero): the outputs of every row land in lane row 0
-    float ah[4] = {0.f, 0.f, 0.f, 0.f};
+    // head (16 -> 2 channels per pixel) on v_mfma_f32_4x4x1_16b_f32: 16 blocks of (4 outputs x 4 pixels), one channel
+    // per instruction = one fmaf per output, 2 passes instead of the 8 of a 16x16x4 whose 14 other rows would be zeros.
+    // Block b = lanes 4b .. 4b+3: lane l supplies B = channel c of ITS pixel and A = head_w[c][l % 4] (0 for l % 4 >= 2),
+    // and ends with D[output i][its pixel] in register i.  The A values are a 4 x 16 table in LDS, read once per tile.
+    float *hws = smem + XS_FLOATS;
     float hb0 = 0.f, hb1 = 0.f;
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
         a.epi.logits, 0, EPI == EPI_HEAD ? (int)((size_t)a.N * H * W * 2 * 4) : 0, 0x00020000);
@@ -399,8 +406,8 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : 4)) void conv_l
         a.epi.mask, 0, (EPI == EPI_HEAD && a.epi.mask) ? (int)((size_t)a.N * H * W) : 0, 0x00020000);
     const int gvoff = ((4 * wv + kk) * W + li) * 8, mvoff = (4 * wv + kk) * W + li;
     if constexpr (EPI == EPI_HEAD) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ah[s] = li < 2 ? a.epi.head_w[(4 * s + kk) * 2 + li] : 0.f;
+        static_assert(MODE == M_PLAIN, "the head table sits right behind the halo image");
+        if (tid < 64) hws[tid] = (tid >> 4) < 2 ? a.epi.head_w[(tid & 15) * 2 + (tid >> 4)] : 0.f;   // [l % 4][channel]; visible after the prologue's barrier
         if (a.epi.head_b) { hb0 = a.epi.head_b[0]; hb1 = a.epi.head_b[1]; }
     }
     auto epilogue = [&](const Pos &p) {
@@ -438,18 +445,19 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : 4)) void conv_l
         }
         if constexpr (EPI == EPI_HEAD) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) row_transpose(o[r][0], o[r][1], o[r][2], o[r][3]);   // o[r][s] = channel 4 s + kk of pixel li
-            f32x4 z[4];
+            for (int j = 0; j < 4; ++j) row_transpose(o[0][j], o[1][j], o[2][j], o[3][j]);
+            // lane row g now holds the 16 channels of pixel (row g, column li): o[r][j] = channel 4 r + j
+            float4 hq[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int r = 0; r < 4; ++r) hq[r] = *reinterpret_cast<const float4 *>(hws + (lane & 3) * 16 + 4 * r);
+            f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    z[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[s], o[r][s], s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : z[r], 0, 0, 0);
-            // lane row 0 holds output j of the wave's row r in z[r][j]: the same transpose hands lane row g the outputs of row g
-            float z0 = z[0][0], z0b = z[1][0], z0c = z[2][0], z0d = z[3][0];
-            float z1 = z[0][1], z1b = z[1][1], z1c = z[2][1], z1d = z[3][1];
-            row_transpose(z0, z0b, z0c, z0d);
-            row_transpose(z1, z1b, z1c, z1d);
+            for (int r = 0; r < 4; ++r) {
+                const float hv[4] = {hq[r].x, hq[r].y, hq[r].z, hq[r].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z = __builtin_amdgcn_mfma_f32_4x4x1f32(hv[j], o[r][j], z, 0, 0, 0);
+            }
+            const float z0 = z[0], z1 = z[1];
             const float v0 = a.epi.head_b ? z0 + hb0 : z0, v1 = a.epi.head_b ? z1 + hb1 : z1;
             const int pbase = (p.n * H + p.ty * TH) * W + p.tx * TW;
             const float lg[2] = {v0, v1};
@@ -545,7 +553,7 @@ template <int MODE, int EPI, int BRIDGE = 0>
 int launch_l0(const L0Args &a0, hipStream_t st) {
     static bool attr_set = false;
     auto kern = conv_l0_kernel<MODE, EPI, BRIDGE>;
-    constexpr int lds = (XS_FLOATS + (MODE == M_FIRST ? 2 * IN_FLOATS : (MODE == M_UP ? UP_FLOATS : 0))) * 4;
+    constexpr int lds = (XS_FLOATS + (MODE == M_FIRST ? 2 * IN_FLOATS : (MODE == M_UP ? UP_FLOATS : 0)) + (EPI == EPI_HEAD ? 64 : 0)) * 4;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             sq_set_error("conv_l0: cannot reserve %d bytes of LDS", lds);
@@ -557,7 +565,7 @@ int launch_l0(const L0Args &a0, hipStream_t st) {
     a.tiles_x = a.W / TW;
     a.tiles_y = a.H / TH;
     a.ntiles = a.tiles_x * a.tiles_y * a.N;
-    const int want = 256 * (MODE == M_UP ? SQ_L0_UP_OCC : 4);
+    const int want = 256 * (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC);
     const int G = a.ntiles < want ? a.ntiles : want;
     const int per_image = a.tiles_x * a.tiles_y;
     a.gn = G / per_image;
