@@ -7,6 +7,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#define SQ_NOT_MINE 1   /* internal: a specialised launcher declines a shape, the caller takes the generic kernel */
+
 void sq_set_error(const char *fmt, ...);
 
 #define SQ_REQUIRE(cond, ...)            \

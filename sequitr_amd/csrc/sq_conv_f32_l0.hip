@@ -43,7 +43,7 @@ constexpr int PS = 24;                          // floats per halo pixel: [kk][s
 constexpr int XS_FLOATS = HP * PS;              // 7776 floats = 31104 B
 constexpr int XITEMS = HP * 4, XSLOTS = 6;      // 1296 float4 of a halo over 256 threads
 constexpr int IN_W = 20, IN_FLOATS = IN_W * IN_W;
-constexpr int UP_W = 10, UP_CIN = 32, UP_PS = UP_CIN + 2, UP_FLOATS = UP_W * UP_W * UP_PS;
+constexpr int UP_W = 10, UP_CIN = 32, UP_PS = 40, UP_FLOATS = UP_W * UP_W * UP_PS;   // [pixel][16-channel half][kk][s] + 8 of padding
 constexpr unsigned OOB = 0x80000000u;
 
 enum { EPI_STORE = 0, EPI_POOL = 1, EPI_HEAD = 2 };
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC)) voi
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xs = smem;
     float *xin = smem + XS_FLOATS;              // FIRST: two 20 x 20 patches
-    float *xl = smem + XS_FLOATS;               // UP: the 10 x 10 x 32 low-resolution patch, pixel stride 34
+    float *xl = smem + XS_FLOATS;               // UP: the 10 x 10 x 32 low-resolution patch, channel-transposed like the halo image
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC)) voi
             const int j = blk * 16 + li, jc = j < 81 ? j : 80;
             const int hy = 2 * (jc / 9) + oy, hx = 2 * (jc % 9) + ox;
             srel[blk] = j < 81 ? ((hy * W + hx) * 16 + 4 * kk) * 4 : (int)OOB;
-            const unsigned usrc = (((hy + 1) >> 1) * UP_W + ((hx + 1) >> 1)) * UP_PS + kk;
+            const unsigned usrc = (((hy + 1) >> 1) * UP_W + ((hx + 1) >> 1)) * UP_PS + 4 * kk;
             const unsigned udst = j < 81 ? (hy * HWD + hx) * PS + 4 * kk : 0xFFFFu;
             upk[blk] = usrc | (udst << 16);
         }
@@ -312,42 +312,58 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC)) voi
             }
         }
     };
-    float *lw = xl + (tid >> 3) * UP_PS + (tid & 7) * 4;
+    float *lw = xl + (tid >> 3) * UP_PS + ((tid & 7) >> 2) * 16 + (tid & 3);    // channel 4 q + j -> [half q / 4][kk = j][s = q % 4]
     auto commit_low = [&]() {
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
             if (sl < 3 || tid < UP_W * UP_W * 8 - 768) {
                 float *d = lw + sl * 32 * UP_PS;
-                *reinterpret_cast<float2 *>(d) = make_float2(lr[sl].x, lr[sl].y);
-                *reinterpret_cast<float2 *>(d + 2) = make_float2(lr[sl].z, lr[sl].w);
+                d[0] = lr[sl].x; d[4] = lr[sl].y; d[8] = lr[sl].z; d[12] = lr[sl].w;
             }
         }
     };
     auto up_conv = [&](const Pos &p) {
         const bool inner = interior(p);
 #pragma unroll
-        for (int blk = 0; blk < 6; ++blk) {
-            const float *src = xl + (upk[blk] & 0xFFFFu);
-            f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int bp = 0; bp < 6; bp += 2) {                          // two class blocks at a time: two independent MFMA chains
+            float4 bl[2][2];
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s8], src[4 * s8], c1, 0, 0, 0);
-            const float u[4] = {c1[0] + upb.x, c1[1] + upb.y, c1[2] + upb.z, c1[3] + upb.w};
-            const float sk[4] = {sr[blk].x, sr[blk].y, sr[blk].z, sr[blk].w};
-            float m[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                m[e] = BRIDGE == SQ_BRIDGE_ADD ? u[e] + sk[e]
-                     : (BRIDGE == SQ_BRIDGE_MUL ? u[e] * sk[e] : (BRIDGE == SQ_BRIDGE_SUB ? u[e] - sk[e] : u[e]));
-            if (!inner) {                                            // outside the image = the conv's zero padding
-                const int j = blk * 16 + li, jc = j < 81 ? j : 80;
-                const int hy = 2 * (jc / 9) + (((wv >> 1) + 1) & 1), hx = 2 * (jc % 9) + (((wv & 1) + 1) & 1);
-                const int gy = p.ty * TH - 1 + hy, gx = p.tx * TW - 1 + hx;
-                const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) m[e] = inside ? m[e] : 0.f;
+            for (int t = 0; t < 2; ++t) {
+                const float *src = xl + (upk[bp + t] & 0xFFFFu);
+                bl[t][0] = *reinterpret_cast<const float4 *>(src);
+                bl[t][1] = *reinterpret_cast<const float4 *>(src + 16);
             }
-            row_transpose(m[0], m[1], m[2], m[3]);
-            if ((upk[blk] >> 16) != 0xFFFFu) *reinterpret_cast<float4 *>(xs + (upk[blk] >> 16)) = make_float4(m[0], m[1], m[2], m[3]);
+            f32x4 c1[2];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float4 q = bl[t][s8 >> 2];
+                    const float b = (s8 & 3) == 0 ? q.x : ((s8 & 3) == 1 ? q.y : ((s8 & 3) == 2 ? q.z : q.w));
+                    c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s8], b, s8 == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : c1[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int blk = bp + t;
+                const float u[4] = {c1[t][0] + upb.x, c1[t][1] + upb.y, c1[t][2] + upb.z, c1[t][3] + upb.w};
+                const float sk[4] = {sr[blk].x, sr[blk].y, sr[blk].z, sr[blk].w};
+                float m[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    m[e] = BRIDGE == SQ_BRIDGE_ADD ? u[e] + sk[e]
+                         : (BRIDGE == SQ_BRIDGE_MUL ? u[e] * sk[e] : (BRIDGE == SQ_BRIDGE_SUB ? u[e] - sk[e] : u[e]));
+                if (!inner) {                                        // outside the image = the conv's zero padding
+                    const int j = blk * 16 + li, jc = j < 81 ? j : 80;
+                    const int hy = 2 * (jc / 9) + (((wv >> 1) + 1) & 1), hx = 2 * (jc % 9) + (((wv & 1) + 1) & 1);
+                    const int gy = p.ty * TH - 1 + hy, gx = p.tx * TW - 1 + hx;
+                    const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] = inside ? m[e] : 0.f;
+                }
+                row_transpose(m[0], m[1], m[2], m[3]);
+                if ((upk[blk] >> 16) != 0xFFFFu) *reinterpret_cast<float4 *>(xs + (upk[blk] >> 16)) = make_float4(m[0], m[1], m[2], m[3]);
+            }
         }
     };
 

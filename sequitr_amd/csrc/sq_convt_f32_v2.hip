@@ -1,0 +1,272 @@
+// conv_transpose_layer + bridge of the decoder's levels 1..3 (sequitr/networks/unet.py:299-322, 336-338) in f32: the
+// 2x2 stride-2 transpose convolution as the GEMM  D[rho][p] = chain_c fmaf(Wt[rho][c], x[p][c])  (rho = (2a + b) Cout + o,
+// c ascending: the chain of convT2x2_mfma_f32_kernel in sq_convt_loss.hip and of the oracle, bit for bit), + bias, then
+// the bridge with the skip tensor.  Rebuilt on what the level-0 kernels of this round showed (sq_conv_f32_l0.hip): what
+// a SIMD issues BESIDE its MFMAs is what it loses, and a streaming epilogue needs its loads in flight early.
+//   * persistent blocks walk (pixel tile, row tile) work; a block tile is 128 rows x 128 input pixels, a wave owns
+//     64 x 64 of it = 16 accumulators: 16 MFMAs per pair of operand fragments instead of 4;
+//   * both operands are staged CHANNEL-TRANSPOSED ([row][16-channel half][kk][s] = channel 16 half + 4 s + kk, 40
+//     floats per row): one ds_read_b128 is a lane's operand for four k steps, conflict-free (10 li + kk covers the 16
+//     slots of a bank row in each of the instruction's lane groups) -- 16 LDS reads per 128 MFMAs instead of 160;
+//   * T14 split staging across chunks AND tiles: the global loads of the next 32-channel chunk (or of the next tile's
+//     first chunk) are in flight under this chunk's MFMAs;
+//   * all sixteen 16-byte bridge operands of a lane are requested before the tile's LAST chunk is multiplied and are in
+//     registers when the epilogue starts; the stores drain under the next tile's MFMAs;
+//   * output addresses are a per-lane pixel part + a per-lane class part (both 32-bit), one pair of divisions per tile.
+// Takes Cin % 32 == 0, Cout % 32 == 0, tensors < 2 GiB; anything else stays with the 64 x 64 kernel (also the A/B
+// reference: SQ_CONVT_V2=0).
+#include <stdlib.h>
+#include "sq_common.h"
+
+#ifndef SQ_CT_FRAG_DBUF
+#define SQ_CT_FRAG_DBUF 0
+#endif
+
+namespace {
+
+constexpr int BM = 128, BN = 128, KCH = 32;
+constexpr int RS = 40;                          // floats per staged row: [half][kk][s] + 8 of padding
+constexpr int AS_FLOATS = BM * RS, XS_FLOATS2 = BN * RS;
+constexpr unsigned OOB = 0x80000000u;
+
+typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+
+struct CtArgs {
+    const float *x, *w, *bias, *skip;
+    float *y;
+    int P, H, W, Cin, Cout;
+    int mtiles, ntiles;                         // row tiles (4 Cout / 128), pixel tiles
+};
+
+template <int BRIDGE>
+__global__ __launch_bounds__(256, 2) void convT2x2_v2_kernel(const CtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *as = smem;
+    float *xs = smem + AS_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int wm = wv >> 1, wn = wv & 1;        // the wave's 64 x 64 quadrant
+    const int Cin = a.Cin, Cout = a.Cout, H = a.H, W = a.W;
+    const int G = (int)gridDim.x;
+    const int vb = (int)sq_xcd_remap(blockIdx.x, gridDim.x);
+    const int total = a.mtiles * a.ntiles;
+    if (vb >= total) return;
+    const int t_count = (total - vb + G - 1) / G;
+    const int nchunk = Cin / KCH;
+    const int nitems = t_count * nchunk;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x), 0, (int)((size_t)a.P * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.w), 0, (int)((size_t)4 * Cout * Cin * 4), 0x00020000);
+    const int out_bytes = (int)((size_t)a.P * 4 * Cout * 4);
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.skip), 0, BRIDGE != SQ_BRIDGE_NONE ? out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
+
+    // staging: 128 rows x 8 float4 of a chunk over 256 threads = 4 per thread and operand; thread -> (row, quad) in
+    // memory order
+    const int srow = tid >> 3, sq = tid & 7;
+    const int grel = (srow * Cin + sq * 4) * 4;                     // + 32 rows per slot
+    float *cwa = as + srow * RS + (sq >> 2) * 16 + (sq & 3);        // channel 4 q + j -> [half q / 4][kk = j][s = q % 4]
+    float *cwx = xs + srow * RS + (sq >> 2) * 16 + (sq & 3);
+    float4 ar[4], br[4];
+    auto issue = [&](int mt, int nt, int cc) {
+        const int abase = (mt * BM * Cin + cc) * 4, xbase = (nt * BN * Cin + cc) * 4;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, grel + it * 32 * Cin * 4, abase, 0);
+            ar[it] = *reinterpret_cast<const float4 *>(&v);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                            // pixels past P read as zeros (buffer range check)
+            // the tile offset sits in the VGPR offset: that is the one the range check sees
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, grel + it * 32 * Cin * 4 + xbase, 0, 0);
+            br[it] = *reinterpret_cast<const float4 *>(&v);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            float *d = cwa + it * 32 * RS;
+            d[0] = ar[it].x; d[4] = ar[it].y; d[8] = ar[it].z; d[12] = ar[it].w;
+            float *e = cwx + it * 32 * RS;
+            e[0] = br[it].x; e[4] = br[it].y; e[8] = br[it].z; e[12] = br[it].w;
+        }
+    };
+
+    f32x4 acc[4][4];
+    const float *fa = as + (64 * wm + li) * RS + 4 * kk;
+    const float *fb = xs + (64 * wn + li) * RS + 4 * kk;
+    auto load_frags = [&](int half, float4 (&fa4)[4], float4 (&fb4)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa4[i] = *reinterpret_cast<const float4 *>(fa + i * 16 * RS + half * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fb4[i] = *reinterpret_cast<const float4 *>(fb + i * 16 * RS + half * 16);
+    };
+    auto mfma_half = [&](const float4 (&fa4)[4], const float4 (&fb4)[4], bool first) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const float av = s == 0 ? fa4[mi].x : (s == 1 ? fa4[mi].y : (s == 2 ? fa4[mi].z : fa4[mi].w));
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const float bvv = s == 0 ? fb4[ni].x : (s == 1 ? fb4[ni].y : (s == 2 ? fb4[ni].z : fb4[ni].w));
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        av, bvv, (first && s == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- epilogue geometry: offset = pixel part [ni] + class part [mi] (bytes) ----------------------------------------
+    int pixoff[4], clsoff[4];
+    float4 bq[4], sk[4][4];
+    auto geometry = [&](int mt, int nt) {
+        const int p0 = nt * BN + 64 * wn + li;
+        // ONE division pair per tile; the other three column blocks by carrying 16 pixels forward
+        unsigned pu = (unsigned)(p0 < a.P ? p0 : 0), t = pu / (unsigned)W;
+        int jj = (int)(pu - t * (unsigned)W);
+        unsigned n32 = t / (unsigned)H;
+        int ii = (int)(t - n32 * (unsigned)H);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int p = p0 + 16 * ni;
+            pixoff[ni] = p < a.P ? (int)((((n32 * 2 * H + 2 * ii) * (2 * W)) + 2 * jj) * Cout * 4) : (int)OOB;
+            jj += 16;
+            while (jj >= W) {
+                jj -= W;
+                if (++ii == H) { ii = 0; ++n32; }
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int rho = mt * BM + 64 * wm + 16 * mi + 4 * kk;
+            const int ab = rho / Cout, o = rho - ab * Cout;
+            clsoff[mi] = (((ab >> 1) * 2 * W + (ab & 1)) * Cout + o) * 4;
+            bq[mi] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto issue_skip = [&]() {
+        if constexpr (BRIDGE != SQ_BRIDGE_NONE) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const unsigned off = pixoff[ni] == (int)OOB ? OOB : (unsigned)(pixoff[ni] + clsoff[mi]);
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
+                    sk[mi][ni] = *reinterpret_cast<const float4 *>(&v);
+                }
+        }
+    };
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 v = acc[mi][ni];
+                if (a.bias) { v[0] += bq[mi].x; v[1] += bq[mi].y; v[2] += bq[mi].z; v[3] += bq[mi].w; }
+                if constexpr (BRIDGE == SQ_BRIDGE_ADD) { v[0] += sk[mi][ni].x; v[1] += sk[mi][ni].y; v[2] += sk[mi][ni].z; v[3] += sk[mi][ni].w; }
+                if constexpr (BRIDGE == SQ_BRIDGE_MUL) { v[0] *= sk[mi][ni].x; v[1] *= sk[mi][ni].y; v[2] *= sk[mi][ni].z; v[3] *= sk[mi][ni].w; }
+                if constexpr (BRIDGE == SQ_BRIDGE_SUB) { v[0] -= sk[mi][ni].x; v[1] -= sk[mi][ni].y; v[2] -= sk[mi][ni].z; v[3] -= sk[mi][ni].w; }
+                const unsigned off = pixoff[ni] == (int)OOB ? OOB : (unsigned)(pixoff[ni] + clsoff[mi]);
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&v), yrsrc, off, 0, 0);
+            }
+    };
+
+    // ---- the item loop: item = (tile, 32-channel chunk); tiles of one pixel tile are neighbours in the walk ----------
+    int tile = vb, chunk = 0;
+    issue(tile % a.mtiles, tile / a.mtiles, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
+    commit();
+    __syncthreads();
+    for (int it = 0; it < nitems; ++it) {
+        int ntile = tile, nchk = chunk + 1;
+        if (nchk == nchunk) { nchk = 0; ntile = tile + G; }
+        const bool has_next = it + 1 < nitems;
+        const bool last = chunk == nchunk - 1;
+        if (last) {                                                 // the bridge operands, in flight under this chunk's MFMAs
+            geometry(tile % a.mtiles, tile / a.mtiles);
+            issue_skip();
+        }
+        if (has_next) issue(ntile % a.mtiles, ntile / a.mtiles, nchk * KCH);
+        {
+#if SQ_CT_FRAG_DBUF
+            float4 fa0[4], fb0[4], fa1[4], fb1[4];
+            load_frags(0, fa0, fb0);
+            load_frags(1, fa1, fb1);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(fa0, fb0, chunk == 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(fa1, fb1, false);
+            __builtin_amdgcn_s_setprio(3);
+#else
+            // one fragment set (32 registers), the second half's reads behind the first half's MFMAs: with the sixteen
+            // bridge operands in flight the double-buffered form spills (267 registers wanted)
+            float4 fa0[4], fb0[4];
+            load_frags(0, fa0, fb0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(fa0, fb0, chunk == 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(1, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(fa0, fb0, false);
+            __builtin_amdgcn_s_setprio(3);
+#endif
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                         // prefetch + bridge operands have landed
+        if (has_next) {
+            __syncthreads();                                        // every wave is done reading this item's images
+            commit();
+        }
+        if (last) epilogue();
+        if (has_next) __syncthreads();
+        tile = ntile;
+        chunk = nchk;
+    }
+}
+
+template <int BRIDGE>
+int launch_ct(const CtArgs &a, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = convT2x2_v2_kernel<BRIDGE>;
+    constexpr int lds = (AS_FLOATS + XS_FLOATS2) * 4;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            sq_set_error("convT2x2_v2: cannot reserve %d bytes of LDS", lds);
+            return SQ_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    const int total = a.mtiles * a.ntiles;
+    int G = total < 512 ? total : 512;
+    if (G > a.mtiles) G -= G % a.mtiles;                            // the row tiles of one pixel tile start together
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, a);
+    return sq_check_launch("sq_convT2x2s2_nhwc_fwd_f32(v2)");
+}
+
+}  // namespace
+
+// internal entry used by sq_convT2x2s2_nhwc_fwd_f32 (sq_convt_loss.hip); SQ_NOT_MINE when the shape is not this kernel's
+int sq_convT_v2_launch(const float *x, const float *w, const float *bias, const float *skip, float *y, int N, int H,
+                       int W, int Cin, int Cout, int bridge, hipStream_t st) {
+    const char *e = getenv("SQ_CONVT_V2");
+    if (e && e[0] == '0') return SQ_NOT_MINE;
+    const size_t P = (size_t)N * H * W;
+    if (Cin % 32 != 0 || Cout % 32 != 0) return SQ_NOT_MINE;
+    if (P * 4 * Cout * 4 >= ((size_t)1 << 31) || P * Cin * 4 >= ((size_t)1 << 31)) return SQ_NOT_MINE;
+    CtArgs a = {};
+    a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.y = y;
+    a.P = (int)P; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.mtiles = 4 * Cout / BM;
+    a.ntiles = (int)((P + BN - 1) / BN);
+    switch (bridge) {
+        case SQ_BRIDGE_ADD: return launch_ct<SQ_BRIDGE_ADD>(a, st);
+        case SQ_BRIDGE_MUL: return launch_ct<SQ_BRIDGE_MUL>(a, st);
+        case SQ_BRIDGE_SUB: return launch_ct<SQ_BRIDGE_SUB>(a, st);
+        default: return launch_ct<SQ_BRIDGE_NONE>(a, st);
+    }
+}

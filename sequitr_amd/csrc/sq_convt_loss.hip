@@ -203,6 +203,9 @@ inline int64_t ce_blocks(int64_t npix) {
 
 }  // namespace
 
+int sq_convT_v2_launch(const float *x, const float *w, const float *bias, const float *skip, float *y, int N, int H,
+                       int W, int Cin, int Cout, int bridge, hipStream_t st);
+
 extern "C" int sq_convT2x2s2_nhwc_fwd_f32(const float *x, const float *w, const float *bias,
                                           const float *skip, float *y, int N, int H, int W, int Cin,
                                           int Cout, int bridge, void *stream) {
@@ -215,6 +218,10 @@ extern "C" int sq_convT2x2s2_nhwc_fwd_f32(const float *x, const float *w, const 
     SQ_REQUIRE_ALIGNED(x); SQ_REQUIRE_ALIGNED(w); SQ_REQUIRE_ALIGNED(y);
     if (bias) SQ_REQUIRE_ALIGNED(bias);
     if (skip) SQ_REQUIRE_ALIGNED(skip);
+    {
+        const int r = sq_convT_v2_launch(x, w, bias, skip, y, N, H, W, Cin, Cout, bridge, reinterpret_cast<hipStream_t>(stream));
+        if (r != SQ_NOT_MINE) return r;
+    }
     const int64_t P = (int64_t)N * H * W;
     dim3 grid((unsigned)((P + 63) / 64), (unsigned)((4 * Cout + 63) / 64));
     static const int kch = [] { const char *e = getenv("SQ_CONVT_KCH"); return e ? atoi(e) : 32; }();   // A/B switch

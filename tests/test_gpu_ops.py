@@ -86,6 +86,21 @@ def test_convT_bridge_bit_exact(Cin, Cout, bridge):
     assert_bit_exact(got, ref, "convT %s" % bridge)
 
 
+@pytest.mark.parametrize("Cin,Cout,N,H,W", [(64, 32, 2, 192, 192), (128, 64, 1, 192, 192), (256, 128, 1, 72, 100)])
+def test_convT_persistent_kernel_many_tiles_bit_exact(Cin, Cout, N, H, W):
+    """sq_convt_f32_v2.hip (128 x 128 block tiles, channel-transposed operands, persistent blocks): more tiles than
+    blocks (a block walks several tiles and prefetches across the seam), one / two / four row tiles per pixel tile, a
+    ragged last pixel tile -- against the C oracle, bit for bit."""
+    x = tiles(14, N, H, W, Cin)
+    w = rand_weights(15, (2, 2, Cout, Cin), 0.2)
+    b = rand_weights(16, (Cout,), 0.1)
+    skip = tiles(17, N, 2 * H, 2 * W, Cout)
+    for bridge in ("eltwise_mul", None):
+        ref = co.convT2x2s2(x, w, b, skip=skip if bridge else None, bridge=bridge)
+        got = ops.convT2x2s2(dev(x), dev(w), dev(b), skip=dev(skip) if bridge else None, bridge=bridge).cpu().numpy()
+        assert_bit_exact(got, ref, "convT v2 %s" % bridge)
+
+
 def test_bridge_standalone():
     a, b = tiles(8, 1, 8, 8, 16), tiles(9, 1, 8, 8, 16)
     for kind, f in (("eltwise_add", np.add), ("eltwise_mul", np.multiply), ("eltwise_sub", np.subtract)):
