@@ -23,6 +23,6 @@ struct SqConvEpi {
 #define SQ_L0_NOT_MINE 1
 // the level-0 (16 -> 16 channel) kernel family of sq_conv_f32_l0.hip: returns SQ_L0_NOT_MINE when the shape is not its own
 // (the caller then launches the generic kernel), otherwise the launch status
-// mode: 0 plain, 1 FIRST (x = the single-channel image), 2 UP (x = the skip tensor)
+// mode: 0 plain, 1 FIRST (x = the single-channel image), 2 UP (x = the skip tensor); cout: 16, or 32 for the plain form
 int sq_conv_l0_launch(int mode, const float *x, const float *w, const float *bias, float *y, int N, int H, int W,
-                      int act, const SqConvEpi &epi, hipStream_t st);
+                      int cout, int act, const SqConvEpi &epi, hipStream_t st);

@@ -75,8 +75,10 @@ __device__ __forceinline__ void row_transpose(float &a0, float &a1, float &a2, f
 
 __device__ __forceinline__ float relu(float v) { return __builtin_fmaxf(v, 0.0f); }   // NaN -> 0, -0 -> +0 like (v > 0 ? v : 0)
 
-template <int MODE, int EPI, int BRIDGE>
-__global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC)) void conv_l0_kernel(const L0Args a) {
+template <int MODE, int EPI, int BRIDGE, int NB>            // NB: output channels / 16 (2: the 16 -> 32 first conv of level 1)
+__global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : (NB == 2 ? 2 : SQ_L0_OCC))) void conv_l0_kernel(const L0Args a) {
+    static_assert(NB == 1 || (NB == 2 && MODE == M_PLAIN && EPI == EPI_STORE), "32 output channels: the plain form only");
+    constexpr int CO = 16 * NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xs = smem;
     float *xin = smem + XS_FLOATS;              // FIRST: two 20 x 20 patches
@@ -93,16 +95,20 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC)) voi
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.x), 0, (int)((size_t)a.N * H * W * (MODE == M_FIRST ? 1 : 16) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        a.y, 0, a.y ? (int)((size_t)a.N * H * W * 16 * 4) : 0, 0x00020000);
+        a.y, 0, a.y ? (int)((size_t)a.N * H * W * CO * 4) : 0, 0x00020000);
 
     // ---- the filter, once per launch: A[m = output channel li][k = channel 4 s + kk] of tap t ---------------------
-    float af[9][4];
+    float af[9][4][NB];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) af[t][s] = a.w[(t * 16 + 4 * s + kk) * 16 + li];
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias) bv = *reinterpret_cast<const float4 *>(a.bias + 4 * kk);
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) af[t][s][nb] = a.w[(t * 16 + 4 * s + kk) * CO + nb * 16 + li];
+    float4 bv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        bv[nb] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + nb * 16 + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto decode = [&](int tile) {
         Pos p;
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC)) voi
 
     // ---- the 3x3 convolution of one tile: the wave walks halo rows h = 4 wv .. 4 wv + 5; row h feeds tap row ky of
     // output row r = h - ky.  Per output row the order is ky, kx, channel: the chain of the oracle ------------------
-    f32x4 acc[4];
+    f32x4 acc[4][NB];
     const float *xb = xs + ((4 * wv) * HWD + li) * PS + 4 * kk;
     auto mfma_phase = [&]() {
         float4 bq[2][3];
@@ -395,8 +401,10 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC)) voi
                         const int r = h - ky;
                         if (r < 0 || r > 3) continue;
                         const bool first = ky == 0 && kx == 0 && s == 0;
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 3 + kx][s], b[s],
-                                                                      first ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[r], 0, 0, 0);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 3 + kx][s][nb], b[s],
+                                                                              first ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[r][nb], 0, 0, 0);
                     }
                 }
             }
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC)) voi
     };
 
     // ---- epilogues ---------------------------------------------------------------------------------------------------
-    const int yvoff = (((4 * wv) * W + li) * 16 + 4 * kk) * 4;
+    const int yvoff = (((4 * wv) * W + li) * CO + 4 * kk) * 4;
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
         a.epi.pooled, 0, EPI == EPI_POOL ? (int)((size_t)a.N * Hl * Wl * 16 * 4) : 0, 0x00020000);
     const int pvoff = (((2 * wv) * Wl + (li >> 1)) * 16 + 4 * kk) * 4;
@@ -427,11 +435,24 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC)) voi
         if (a.epi.head_b) { hb0 = a.epi.head_b[0]; hb1 = a.epi.head_b[1]; }
     }
     auto epilogue = [&](const Pos &p) {
+        if constexpr (NB > 1) {                  // 32 output channels: two 16-byte stores per pixel row and lane
+            const int tbase = (((p.n * H + p.ty * TH) * W + p.tx * TW) * CO) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const f32x4 t = (f32x4){relu(acc[r][nb][0] + bv[nb].x), relu(acc[r][nb][1] + bv[nb].y),
+                                            relu(acc[r][nb][2] + bv[nb].z), relu(acc[r][nb][3] + bv[nb].w)};
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&t), yrsrc,
+                                                           yvoff + tbase + r * W * CO * 4 + nb * 64, 0, 0);
+                }
+            return;
+        }
         float o[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            o[r][0] = relu(acc[r][0] + bv.x); o[r][1] = relu(acc[r][1] + bv.y);
-            o[r][2] = relu(acc[r][2] + bv.z); o[r][3] = relu(acc[r][3] + bv.w);
+            o[r][0] = relu(acc[r][0][0] + bv[0].x); o[r][1] = relu(acc[r][0][1] + bv[0].y);
+            o[r][2] = relu(acc[r][0][2] + bv[0].z); o[r][3] = relu(acc[r][0][3] + bv[0].w);
         }
         if constexpr (EPI != EPI_HEAD) {
             const int tbase = (((p.n * H + p.ty * TH) * W + p.tx * TW) * 16) * 4;
@@ -565,10 +586,10 @@ inline bool l0_enabled() {                                          // SQ_CONV_L
     return !(e && e[0] == '0');
 }
 
-template <int MODE, int EPI, int BRIDGE = 0>
+template <int MODE, int EPI, int BRIDGE = 0, int NB = 1>
 int launch_l0(const L0Args &a0, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv_l0_kernel<MODE, EPI, BRIDGE>;
+    auto kern = conv_l0_kernel<MODE, EPI, BRIDGE, NB>;
     constexpr int lds = (XS_FLOATS + (MODE == M_FIRST ? 2 * IN_FLOATS : (MODE == M_UP ? UP_FLOATS : 0)) + (EPI == EPI_HEAD ? 64 : 0)) * 4;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -581,7 +602,7 @@ int launch_l0(const L0Args &a0, hipStream_t st) {
     a.tiles_x = a.W / TW;
     a.tiles_y = a.H / TH;
     a.ntiles = a.tiles_x * a.tiles_y * a.N;
-    const int want = 256 * (MODE == M_UP ? SQ_L0_UP_OCC : SQ_L0_OCC);
+    const int want = 256 * (MODE == M_UP ? SQ_L0_UP_OCC : (NB == 2 ? 2 : SQ_L0_OCC));
     const int G = a.ntiles < want ? a.ntiles : want;
     const int per_image = a.tiles_x * a.tiles_y;
     a.gn = G / per_image;
@@ -594,7 +615,8 @@ int launch_l0(const L0Args &a0, hipStream_t st) {
 }  // namespace
 
 int sq_conv_l0_launch(int mode, const float *x, const float *w, const float *bias, float *y, int N, int H, int W,
-                      int act, const SqConvEpi &epi, hipStream_t st) {
+                      int cout, int act, const SqConvEpi &epi, hipStream_t st) {
+    if (cout != 16 && !(cout == 32 && mode == M_PLAIN && !epi.head_w && !epi.pooled)) return SQ_L0_NOT_MINE;
     if (!l0_enabled() || act != SQ_ACT_RELU || H % 16 != 0 || W % 16 != 0 || epi.x2) return SQ_L0_NOT_MINE;
     if (epi.head_w && epi.head_c != 2) return SQ_L0_NOT_MINE;
     if (epi.head_w && epi.pooled) return SQ_L0_NOT_MINE;
@@ -604,6 +626,7 @@ int sq_conv_l0_launch(int mode, const float *x, const float *w, const float *bia
     if (mode == M_PLAIN) {
         if (e == EPI_HEAD) return launch_l0<M_PLAIN, EPI_HEAD>(a, st);
         if (e == EPI_POOL) return launch_l0<M_PLAIN, EPI_POOL>(a, st);
+        if (cout == 32) return launch_l0<M_PLAIN, EPI_STORE, 0, 2>(a, st);
         return launch_l0<M_PLAIN, EPI_STORE>(a, st);
     }
     if (mode == M_FIRST) {

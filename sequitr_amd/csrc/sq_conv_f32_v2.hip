@@ -666,8 +666,8 @@ int sq_conv_mfma_v2(const float *x, const float *w, const float *bias, float *y,
                     int Cin, int Cout, int K, float wscale, int act, hipStream_t st) {
     SqConvEpi epi = {};
     epi.store_y = 1;
-    if (Cin == 16 && Cout == 16 && K == 3 && wscale == 1.0f) {
-        const int r = sq_conv_l0_launch(0, x, w, bias, y, N, H, W, act, epi, st);
+    if (Cin == 16 && (Cout == 16 || Cout == 32) && K == 3 && wscale == 1.0f) {
+        const int r = sq_conv_l0_launch(0, x, w, bias, y, N, H, W, Cout, act, epi, st);
         if (r != SQ_L0_NOT_MINE) return r;
     }
     if (Cin % 16 == 0)
@@ -714,7 +714,7 @@ extern "C" int sq_conv3x3_pool_fwd_f32(const float *x, const float *w, const flo
     epi.store_y = 1;
     epi.pooled = pooled;
     if (Cin == 16 && Cout == 16) {
-        const int r = sq_conv_l0_launch(0, x, w, bias, y, N, H, W, act, epi, reinterpret_cast<hipStream_t>(stream));
+        const int r = sq_conv_l0_launch(0, x, w, bias, y, N, H, W, 16, act, epi, reinterpret_cast<hipStream_t>(stream));
         if (r != SQ_L0_NOT_MINE) return r;
     }
     return dispatch_bn<3, 16>(x, w, bias, y, N, H, W, Cin, Cout, 1.0f, act, epi, reinterpret_cast<hipStream_t>(stream));
@@ -736,7 +736,7 @@ extern "C" int sq_conv3x3_head_fwd_f32(const float *x, const float *w, const flo
     epi.store_y = 0;
     epi.head_w = head_w; epi.head_b = head_b; epi.logits = logits; epi.mask = mask; epi.head_c = head_c;
     if (Cin == 16) {
-        const int r = sq_conv_l0_launch(0, x, w, bias, nullptr, N, H, W, act, epi, reinterpret_cast<hipStream_t>(stream));
+        const int r = sq_conv_l0_launch(0, x, w, bias, nullptr, N, H, W, 16, act, epi, reinterpret_cast<hipStream_t>(stream));
         if (r != SQ_L0_NOT_MINE) return r;
     }
     return launch_v2<16, 3, 16, false>(x, w, bias, nullptr, N, H, W, Cin, 16, 1.0f, act, epi,
@@ -760,7 +760,7 @@ extern "C" int sq_conv3x3_first_block_fwd_f32(const float *x, const float *w1, c
     epi.pooled = pooled;
     epi.first_w = w1; epi.first_b = b1;
     {
-        const int r = sq_conv_l0_launch(1, x, w2, b2, y, N, H, W, SQ_ACT_RELU, epi, reinterpret_cast<hipStream_t>(stream));
+        const int r = sq_conv_l0_launch(1, x, w2, b2, y, N, H, W, 16, SQ_ACT_RELU, epi, reinterpret_cast<hipStream_t>(stream));
         if (r != SQ_L0_NOT_MINE) return r;
     }
     return launch_v2<16, 3, 16, true>(x, w2, b2, y, N, H, W, 1, 16, 1.0f, SQ_ACT_RELU, epi,
@@ -786,7 +786,7 @@ extern "C" int sq_convT_conv3x3_fwd_f32(const float *x_low, const float *wt, con
     epi.store_y = 1;
     epi.up_x = x_low; epi.up_w = wt; epi.up_b = bt; epi.up_bridge = bridge;
     {
-        const int r = sq_conv_l0_launch(2, skip, w, bias, y, N, H, W, act, epi, reinterpret_cast<hipStream_t>(stream));
+        const int r = sq_conv_l0_launch(2, skip, w, bias, y, N, H, W, 16, act, epi, reinterpret_cast<hipStream_t>(stream));
         if (r != SQ_L0_NOT_MINE) return r;
     }
     return launch_v2<16, 3, 16, 2>(skip, w, bias, y, N, H, W, 16, 16, 1.0f, act, epi,

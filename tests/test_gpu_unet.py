@@ -83,6 +83,8 @@ def test_level0_kernel_family_bit_exact(shape):
     x = tiles(43, N, H, W, 16)
     r = co.conv2d(x, w, b, act="relu")
     assert_bit_exact(ops.conv2d(dev(x), dev(w), dev(b), act="relu").cpu().numpy(), r, "plain 16->16")
+    w32, b32 = rand_weights(51, (3, 3, 16, 32)), rand_weights(52, (32,), 0.1)
+    assert_bit_exact(ops.conv2d(dev(x), dev(w32), dev(b32), act="relu").cpu().numpy(), co.conv2d(x, w32, b32, act="relu"), "plain 16->32")
     y, p = ops.conv3x3_pool(dev(x), dev(w), dev(b))
     assert_bit_exact(y.cpu().numpy(), r, "conv+pool y")
     assert_bit_exact(p.cpu().numpy(), co.maxpool2x2(r), "conv+pool pooled")
