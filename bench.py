@@ -248,8 +248,8 @@ def pmc_mfma_busy():
         pmc_mfma_busy.source = os.path.relpath(fn, ROOT)
         with open(fn) as f:
             d = json.load(f)
-        return {k.replace("conv_mfma_f32_v2_kernel", "v2"): v["mfma_busy_frac"] for k, v in d.items()
-                if "mfma_busy_frac" in v and k.startswith("conv_mfma_f32_v2")}
+        return {k.replace("conv_mfma_f32_v2_kernel", "v2").replace("conv_l0_kernel", "l0"): v["mfma_busy_frac"]
+                for k, v in d.items() if "mfma_busy_frac" in v and k.startswith(("conv_mfma_f32_v2", "conv_l0_kernel"))}
     except Exception:
         return None
 
@@ -1428,8 +1428,9 @@ def main():
                                  "UNPINNED against the reference (its U-Net leaf ops are abstract, unet.py:326-343)"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv_mfma_f32_v2_kernel, all 17 launches of a step incl. the pool / head / first-block / "
-                          "convT-fused forms (3x3 implicit GEMM on v_mfma_f32_16x16x4_f32)",
+                "kernel": "the 3x3 implicit-GEMM family on v_mfma_f32_16x16x4_f32, all 17 launches of a step: "
+                          "conv_mfma_f32_v2_kernel (levels 1-4) and conv_l0_kernel (the 16-channel level-0 launches: first block + "
+                          "pool, convT-fused, 1x1-head-fused; the 16 -> 32 conv of level 1)",
                 "achieved": round(achieved, 3),
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
@@ -1437,7 +1438,7 @@ def main():
                 # HBM bytes PER STEP over the conv launches (PMC) with the algorithmic bytes per step (in + out of
                 # every conv launch) beside it; per-launch average kept under its own, labelled key
                 "traffic": (pmc_conv_traffic() or {}).get("per_step"),
-                "traffic_is": "HBM bytes per step (all conv_mfma launches of one 32-tile pass), rocprofv3 PMC",
+                "traffic_is": "HBM bytes per step (all conv_mfma / conv_l0 launches of one 32-tile pass), rocprofv3 PMC",
                 "algorithmic_bytes_per_step": (pmc_conv_traffic() or {}).get("algorithmic_per_step"),
                 "traffic_per_launch_avg": (pmc_conv_traffic() or {}).get("per_launch"),
                 "compulsory_bytes_per_step": float(x_all.shape[0]) * TILE * TILE * (4 + 8 + 1) + 4.0 * 1744994,

@@ -29,6 +29,9 @@
 #include "sq_common.h"
 #include "sq_conv_epi.h"
 
+#ifndef SQ_L0_SETPRIO
+#define SQ_L0_SETPRIO 1              // wave priority low while feeding the matrix pipe, high while staging / storing (A/B switch)
+#endif
 #ifndef SQ_L0_OCC
 #define SQ_L0_OCC 4                  // resident blocks per CU of the plain / FIRST forms (A/B switch)
 #endif
@@ -381,7 +384,9 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : (NB == 2 ? 2 : 
         float4 bq[2][3];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) bq[0][kx] = *reinterpret_cast<const float4 *>(xb + kx * PS);
+#if SQ_L0_SETPRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
         for (int h = 0; h < 6; ++h) {
             if (h + 1 < 6) {
@@ -410,7 +415,9 @@ __global__ __launch_bounds__(256, (MODE == M_UP ? SQ_L0_UP_OCC : (NB == 2 ? 2 : 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#if SQ_L0_SETPRIO
         __builtin_amdgcn_s_setprio(3);
+#endif
     };
 
     // ---- epilogues ---------------------------------------------------------------------------------------------------

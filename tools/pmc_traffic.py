@@ -8,8 +8,8 @@
 
 Both counters are in KiB; on gfx950 FETCH_SIZE counts half of a wide coalesced read, so
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  `--steps` = warm-up + timed steps of the profiled command
-(every launch of the run is averaged).  The summary covers every conv_mfma_f32_v2 instantiation
-(bench.py's roofline kernel)."""
+(every launch of the run is averaged).  The summary covers every conv_mfma_f32_v2 / conv_l0 instantiation
+(bench.py's roofline kernels)."""
 import argparse
 import collections
 import csv
@@ -42,7 +42,7 @@ def main():
     ap.add_argument("write_csv")
     ap.add_argument("--steps", type=int, required=True, help="bench steps + warm-up steps in the profiled run")
     ap.add_argument("--algorithmic-bytes-per-step", type=float, default=None)
-    ap.add_argument("--kernel-regex", default=r"conv_mfma_f32_v2_kernel")
+    ap.add_argument("--kernel-regex", default=r"conv_mfma_f32_v2_kernel|conv_l0_kernel")
     ap.add_argument("--command", default="")
     a = ap.parse_args()
     fe, wr = load(a.fetch_csv, "FETCH_SIZE"), load(a.write_csv, "WRITE_SIZE")
