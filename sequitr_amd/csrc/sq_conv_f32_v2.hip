@@ -22,6 +22,7 @@
 //     the kernel, in registers) and merges it into the halo image in LDS.  The up-scaled / merged level-0
 //     tensor (537 MB per 32-tile batch) is never written or re-read and the HBM-bound convT launch disappears.
 #include <stdlib.h>
+#include <type_traits>
 #include "sq_common.h"
 #include "sq_conv_epi.h"
 
@@ -392,9 +393,15 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
     //   v > 0 ? v : (relu ? +0 : v * slope),  slope = 1 (none) or 0.2 (leaky)
     const float slope = act == SQ_ACT_LEAKY ? 0.2f : 1.0f;
     const bool is_relu = act == SQ_ACT_RELU;
-    auto actf = [&](float v) {
-        const float neg = is_relu ? 0.0f : v * slope;
-        return v > 0.0f ? v : neg;
+    // FAST: ReLU on a tile that lies wholly inside the tensor -- one v_max per value and lane-part + tile-part store
+    // offsets instead of two selects per value and a bounds test per store (about 500 of a 64-channel tile's 800 VALU
+    // instructions; profiles/r04_l0_issue_model.txt on what those cost)
+    auto actk = [&](float v, auto fastc) {
+        if constexpr (decltype(fastc)::value) return __builtin_fmaxf(v, 0.0f);       // NaN -> 0, -0 -> +0, as v > 0 ? v : 0
+        else {
+            const float neg = is_relu ? 0.0f : v * slope;
+            return v > 0.0f ? v : neg;
+        }
     };
 
     // fused head operands, once per block: A[i = head output][k = channel] = head_w[channel][output]
@@ -424,7 +431,10 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         const int co = n0 + nb * 16 + 4 * kk;
         bvr[nb] = (bias && co < Cout) ? *reinterpret_cast<const float4 *>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    auto epilogue = [&](int tile) {
+    const int fast_lane = (((4 * wv) * W + li) * Cout + 4 * kk) * 4;    // the lane's part of a full tile's output offsets
+    auto epilogue = [&](int tile, auto fastc) {
+        constexpr bool FAST = decltype(fastc)::value;
+        auto actf = [&](float v) { return actk(v, fastc); };
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int gx = tx * TW + li;
 #pragma unroll
@@ -453,8 +463,13 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
                         *reinterpret_cast<__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned *>(&t),
                         yrsrc, off, 0, 0);
 #else
-                    const bool ok = gy < H && gx < W && co < Cout;
-                    const unsigned off = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 4) : OOB;
+                    unsigned off;
+                    if constexpr (FAST) {
+                        off = (unsigned)(fast_lane + nb * 64) + (unsigned)((((n * H + ty * TH + r) * W + tx * TW) * Cout + n0) * 4);
+                    } else {
+                        const bool ok = gy < H && gx < W && co < Cout;
+                        off = ok ? (unsigned)((((n * H + gy) * W + gx) * Cout + co) * 4) : OOB;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b128(
                         *reinterpret_cast<__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned *>(&o[r]),
                         yrsrc, off, 0, 0);
@@ -595,7 +610,18 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
                 up_conv(ntile);
             }
         }
-        if (chunk == nchunk - 1) epilogue(tile);
+        if (chunk == nchunk - 1) {
+            const int ftx = tile % tiles_x, fty = (tile / tiles_x) % tiles_y;
+            const bool fast = is_relu && fty * TH + TH <= H && ftx * TW + TW <= W && n0 + BN <= Cout;
+            // the second copy of the epilogue costs the <32,3,32> form 15 spilled registers: 64-channel blocks only
+            if constexpr (BN == 64 && MODE == 0) {
+                if (fast) epilogue(tile, std::integral_constant<bool, true>{});
+                else epilogue(tile, std::integral_constant<bool, false>{});
+            } else {
+                (void)fast;
+                epilogue(tile, std::integral_constant<bool, false>{});
+            }
+        }
         if (has_next) __syncthreads();
         tile = ntile;
         chunk = nchk;
