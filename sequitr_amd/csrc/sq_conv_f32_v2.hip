@@ -26,6 +26,9 @@
 #include "sq_common.h"
 #include "sq_conv_epi.h"
 
+#ifndef SQ_V2_INNER
+#define SQ_V2_INNER 1            // 64-channel blocks: SGPR tile offsets for interior halos and for the weight slab (A/B switch)
+#endif
 #ifndef SQ_TILE_INTERLEAVE
 #define SQ_TILE_INTERLEAVE 1    // block b takes tiles b, b+G, b+2G, ...; 0: a contiguous run per block (A/B switch, HISTORY.md 4a)
 #endif
@@ -184,6 +187,16 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
             const int base = (((n * H + y0) * W + x0) * Cs + (second ? cc - Cs : cc)) * 4;   // may be "negative": wraps back
             if constexpr (!UP) {
                 const __amdgpu_buffer_rsrc_t rs = second ? x2rsrc : xrsrc;      // wave-uniform select (4 s_cselect)
+                // a halo that lies wholly inside the image: the tile offset rides in the SGPR offset, the lane's part is
+                // loop-invariant -- no bounds arithmetic (64-channel blocks: 57 VALU instructions per item otherwise)
+                const bool inner = SQ_V2_INNER && BN == 64 && live && x0 >= 0 && y0 >= 0 && x0 + C::HALO_W <= W && y0 + C::HALO_H <= H;
+                if (inner) {
+#pragma unroll
+                    for (int sl = 0; sl < C::XSLOTS; ++sl) {
+                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, xrel[sl], base, 0);
+                        xr[sl] = *reinterpret_cast<const float4 *>(&v);
+                    }
+                } else
 #pragma unroll
                 for (int sl = 0; sl < C::XSLOTS; ++sl) {
                     const bool inb = live && (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
@@ -226,6 +239,13 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         }
         if (want_w) {
             const int wbase = cc * Cout * 4;
+            if (SQ_V2_INNER && BN == 64 && live) {              // out-of-range slots keep their out-of-range VGPR offset
+#pragma unroll
+                for (int sl = 0; sl < C::WSLOTS; ++sl) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wrel[sl], wbase, 0);
+                    wr[sl] = *reinterpret_cast<const float4 *>(&v);
+                }
+            } else
 #pragma unroll
             for (int sl = 0; sl < C::WSLOTS; ++sl) {
                 const unsigned off = (live && wrel[sl] != (int)OOB) ? (unsigned)(wbase + wrel[sl]) : OOB;
