@@ -167,8 +167,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
     // ---- issue the global loads of one work item (tile, chunk) into registers -------------
     // live == false: every lane's offset is out of range, nothing is fetched (the item past the last one -- issue()
     // and commit() run unconditionally every iteration, see the main loop)
-    auto issue = [&](int tile, int cc, bool want_w, bool live) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    auto issue = [&](int tx, int ty, int n, int cc, bool want_w, bool live) {
         if constexpr (FIRST) {
             // 20x20 single-channel patch around the tile (halo of the halo)
             const int x0 = tx * TW - 2, y0 = ty * TH - 2;
@@ -292,7 +291,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
                 if (idx < C::WITEMS) {
                     const int r = idx / (BN / 4), q4 = idx % (BN / 4);
                     float4 v = wr[sl];
-                    v.x *= wscale; v.y *= wscale; v.z *= wscale; v.w *= wscale;
+                    if (wscale != 1.0f) { v.x *= wscale; v.y *= wscale; v.z *= wscale; v.w *= wscale; }   // x * 1.0f == x
                     *reinterpret_cast<float4 *>(ws + r * C::BNS + ((q4 * 4) ^ ((r & 1) ? C::WSWZ : 0))) = v;
                 }
             }
@@ -316,8 +315,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         }
         b1v = *reinterpret_cast<const float4 *>(epi.first_b + 4 * kk);
     }
-    auto first_conv = [&](int tile) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+    auto first_conv = [&](int tx, int ty) {
         for (int blk = wv; blk < (C::HP + 15) / 16; blk += 4) {
             const int pix = blk * 16 + li;
             const int pc = pix < C::HP ? pix : C::HP - 1;
@@ -354,8 +352,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         for (int s8 = 0; s8 < 8; ++s8) aw[s8] = epi.up_w[(wv * 16 + li) * C::UP_CIN + 4 * s8 + kk];
         if (epi.up_b) upb = *reinterpret_cast<const float4 *>(epi.up_b + 4 * kk);
     }
-    auto up_conv = [&](int tile) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+    auto up_conv = [&](int tx, int ty) {
         const int pa = wv >> 1, pb = wv & 1;
         // halo row hy has parity (hy + 1) & 1 (global row 16 ty - 1 + hy): class rows are hy = 2 jy + ((pa + 1) & 1)
         const int oy = (pa + 1) & 1, ox = (pb + 1) & 1;
@@ -452,10 +449,9 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         bvr[nb] = (bias && co < Cout) ? *reinterpret_cast<const float4 *>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int fast_lane = (((4 * wv) * W + li) * Cout + 4 * kk) * 4;    // the lane's part of a full tile's output offsets
-    auto epilogue = [&](int tile, auto fastc) {
+    auto epilogue = [&](int tx, int ty, int n, auto fastc) {
         constexpr bool FAST = decltype(fastc)::value;
         auto actf = [&](float v) { return actk(v, fastc); };
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int gx = tx * TW + li;
 #pragma unroll
         for (int nb = 0; nb < NR; ++nb) {
@@ -553,7 +549,17 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         }
     };
 
-    issue(t_begin, 0, true, true);
+    // tile coordinates advance by carries (three divisions by run-time values per decode were ~80 scalar instructions per
+    // item in issue() alone); plain ints, not a struct (sq_conv_bf16.hip's experiment put structs on the stack)
+    const int per_image = tiles_x * tiles_y;
+    const int s_n = tstride / per_image, s_y = (tstride % per_image) / tiles_x, s_x = (tstride % per_image) % tiles_x;
+    int ctx = t_begin % tiles_x, cty = (t_begin / tiles_x) % tiles_y, cn = t_begin / per_image;   // the tile being multiplied
+    int ntx = ctx + s_x, nty = cty, nn = cn;                                                      // the next one of the walk
+    if (ntx >= tiles_x) { ntx -= tiles_x; nty += 1; }
+    nty += s_y;
+    if (nty >= tiles_y) { nty -= tiles_y; nn += 1; }
+    nn += s_n;
+    issue(ctx, cty, cn, 0, true, true);
     __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), stated outside commit()'s branches (see the main loop)
     commit(true);
 #pragma unroll
@@ -562,11 +568,11 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         for (int nb = 0; nb < NR; ++nb) acc[r][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     if constexpr (FIRST) {
-        first_conv(t_begin);
+        first_conv(ctx, cty);
         __syncthreads();
     }
     if constexpr (UP) {
-        up_conv(t_begin);
+        up_conv(ctx, cty);
         __syncthreads();
     }
 
@@ -576,7 +582,9 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         int ntile = tile, nchk = chunk + 1;
         if (nchk == nchunk) { nchk = 0; ntile = tile + tstride; }
         const bool has_next = it + 1 < nitems;
-        if (has_next) issue(ntile, nchk * KC, restage_w, true);
+        const bool same = ntile == tile;
+        const int itx = same ? ctx : ntx, ity = same ? cty : nty, itn = same ? cn : nn;     // the next ITEM's tile
+        if (has_next) issue(itx, ity, itn, nchk * KC, restage_w, true);
 
         // ---- MFMA phase: NSTEP steps; the ds_reads of step s+1 are issued BEFORE the MFMAs
         // of step s (sched_barrier fences stop hipcc sinking them back to just-in-time) ----------
@@ -623,26 +631,33 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
             commit(restage_w);
             if constexpr (FIRST) {
                 __syncthreads();        // the 20x20 patch is complete
-                first_conv(ntile);
+                first_conv(itx, ity);
             }
             if constexpr (UP) {
                 __syncthreads();        // skip halo and low-resolution patch are complete
-                up_conv(ntile);
+                up_conv(itx, ity);
             }
         }
         if (chunk == nchunk - 1) {
-            const int ftx = tile % tiles_x, fty = (tile / tiles_x) % tiles_y;
-            const bool fast = is_relu && fty * TH + TH <= H && ftx * TW + TW <= W && n0 + BN <= Cout;
+            const bool fast = is_relu && cty * TH + TH <= H && ctx * TW + TW <= W && n0 + BN <= Cout;
             // the second copy of the epilogue costs the <32,3,32> form 15 spilled registers: 64-channel blocks only
             if constexpr (BN == 64 && MODE == 0) {
-                if (fast) epilogue(tile, std::integral_constant<bool, true>{});
-                else epilogue(tile, std::integral_constant<bool, false>{});
+                if (fast) epilogue(ctx, cty, cn, std::integral_constant<bool, true>{});
+                else epilogue(ctx, cty, cn, std::integral_constant<bool, false>{});
             } else {
                 (void)fast;
-                epilogue(tile, std::integral_constant<bool, false>{});
+                epilogue(ctx, cty, cn, std::integral_constant<bool, false>{});
             }
         }
         if (has_next) __syncthreads();
+        if (ntile != tile) {                                     // the walk moves on by one tile stride
+            ctx = ntx; cty = nty; cn = nn;
+            ntx += s_x;
+            if (ntx >= tiles_x) { ntx -= tiles_x; nty += 1; }
+            nty += s_y;
+            if (nty >= tiles_y) { nty -= tiles_y; nn += 1; }
+            nn += s_n;
+        }
         tile = ntile;
         chunk = nchk;
     }
