@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
                 const __amdgpu_buffer_rsrc_t rs = second ? x2rsrc : xrsrc;      // wave-uniform select (4 s_cselect)
                 // a halo that lies wholly inside the image: the tile offset rides in the SGPR offset, the lane's part is
                 // loop-invariant -- no bounds arithmetic (64-channel blocks: 57 VALU instructions per item otherwise)
-                const bool inner = SQ_V2_INNER && BN == 64 && live && x0 >= 0 && y0 >= 0 && x0 + C::HALO_W <= W && y0 + C::HALO_H <= H;
+                const bool inner = SQ_V2_INNER && (BN == 64 || KC == 32) && live && x0 >= 0 && y0 >= 0 && x0 + C::HALO_W <= W && y0 + C::HALO_H <= H;
                 if (inner) {
 #pragma unroll
                     for (int sl = 0; sl < C::XSLOTS; ++sl) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         }
         if (want_w) {
             const int wbase = cc * Cout * 4;
-            if (SQ_V2_INNER && BN == 64 && live) {              // out-of-range slots keep their out-of-range VGPR offset
+            if (SQ_V2_INNER && (BN == 64 || KC == 32) && live) {   // out-of-range slots keep their out-of-range VGPR offset
 #pragma unroll
                 for (int sl = 0; sl < C::WSLOTS; ++sl) {
                     const auto v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wrel[sl], wbase, 0);
