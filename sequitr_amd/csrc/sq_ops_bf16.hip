@@ -487,13 +487,36 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const __bf16 *__rest
 #pragma unroll
         for (int o = 0; o < COUT; ++o) gw[c][o] = 0.f;
     const int64_t stride = (int64_t)gridDim.x * 256;
+    // the operands of a thread's NEXT pixel are requested before this pixel is worked on: the loop was load -> ~150 VALU ->
+    // store with nothing in flight meanwhile (3.6 TB/s of its bytes at level 0); same pixels, same order of the sums
+    bf16x8 xn[CIN / 8] = {};
+    float yn[COUT] = {}, wn = 0.f, gn[COUT] = {};
+    auto fetch = [&](int64_t q) {
+        if (q < npix) {
+#pragma unroll
+            for (int c8 = 0; c8 < CIN / 8; ++c8) xn[c8] = *reinterpret_cast<const bf16x8 *>(x + q * CIN + c8 * 8);
+            if constexpr (CE) {
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) yn[o] = (float)ce.yoh[q * COUT + o];
+                wn = ce.wgt[q];
+            } else {
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) gn[o] = dz[q * COUT + o];
+            }
+        }
+    };
+    fetch((int64_t)blockIdx.x * 256 + threadIdx.x);
     for (int64_t base = (int64_t)blockIdx.x * 256; base < npix; base += stride) {
         const int64_t p = base + threadIdx.x;
-        if (p < npix) {
-            float g[COUT];
-            bf16x8 xv[CIN / 8];
+        float g[COUT], ycur[COUT];
+        bf16x8 xv[CIN / 8];
 #pragma unroll
-            for (int c8 = 0; c8 < CIN / 8; ++c8) xv[c8] = *reinterpret_cast<const bf16x8 *>(x + p * CIN + c8 * 8);
+        for (int c8 = 0; c8 < CIN / 8; ++c8) xv[c8] = xn[c8];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) { ycur[o] = yn[o]; g[o] = gn[o]; }
+        const float wcur = wn;
+        fetch(p + stride);
+        if (p < npix) {
             if constexpr (CE) {
                 float acc[COUT], yc[COUT];
 #pragma unroll
@@ -508,16 +531,13 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const __bf16 *__rest
 #pragma unroll
                 for (int o = 0; o < COUT; ++o) {
                     acc[o] = acc[o] + (ce.bias ? ce.bias[o] : 0.f);
-                    yc[o] = (float)ce.yoh[p * COUT + o];
+                    yc[o] = ycur[o];
                 }
-                const float wp = ce.wgt[p];
+                const float wp = wcur;
                 tsum += (double)sq_wce_pixel<COUT>(acc, yc, COUT, wp, wp * ce.inv_npix, g);
                 const float up = ce.dloss[0];
 #pragma unroll
                 for (int o = 0; o < COUT; ++o) g[o] = g[o] * up;
-            } else {
-#pragma unroll
-                for (int o = 0; o < COUT; ++o) g[o] = dz[p * COUT + o];
             }
 #pragma unroll
             for (int o = 0; o < COUT; ++o) gb[o] += g[o];
