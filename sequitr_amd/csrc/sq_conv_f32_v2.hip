@@ -26,6 +26,9 @@
 #include "sq_common.h"
 #include "sq_conv_epi.h"
 
+#ifndef SQ_V2_FAST32
+#define SQ_V2_FAST32 1           // the ReLU / full-tile epilogue copy also in the <32,3,32> form (1 spilled register; A/B switch)
+#endif
 #ifndef SQ_V2_INNER
 #define SQ_V2_INNER 1            // 64-channel blocks: SGPR tile offsets for interior halos and for the weight slab (A/B switch)
 #endif
@@ -96,6 +99,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
     float *head_scratch = ws + C::WS_FLOATS + (FIRST ? C::IN_FLOATS : (UP ? C::UP_FLOATS : 0));   // only when epi.head_w
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __builtin_assume(tid < 256);                               // lets the `idx < ITEMS` guards of the full staging slots fold away
     const int li = lane & 15, kk = lane >> 4;
     const int n0 = blockIdx.y * BN;
     const int vb = (int)sq_xcd_remap(blockIdx.x, gridDim.x);
@@ -285,16 +289,22 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
             }
         }
         if (want_w) {
+            // x * 1.0f == x: the U-Net's layers skip the scaling (as a branch round the loop: inside it hipcc multiplies
+            // and then selects, six instructions per slot)
+            auto put = [&](auto scaledc) {
 #pragma unroll
-            for (int sl = 0; sl < C::WSLOTS; ++sl) {
-                const int idx = tid + sl * 256;
-                if (idx < C::WITEMS) {
-                    const int r = idx / (BN / 4), q4 = idx % (BN / 4);
-                    float4 v = wr[sl];
-                    if (wscale != 1.0f) { v.x *= wscale; v.y *= wscale; v.z *= wscale; v.w *= wscale; }   // x * 1.0f == x
-                    *reinterpret_cast<float4 *>(ws + r * C::BNS + ((q4 * 4) ^ ((r & 1) ? C::WSWZ : 0))) = v;
+                for (int sl = 0; sl < C::WSLOTS; ++sl) {
+                    const int idx = tid + sl * 256;
+                    if (idx < C::WITEMS) {
+                        const int r = idx / (BN / 4), q4 = idx % (BN / 4);
+                        float4 v = wr[sl];
+                        if constexpr (decltype(scaledc)::value) { v.x *= wscale; v.y *= wscale; v.z *= wscale; v.w *= wscale; }
+                        *reinterpret_cast<float4 *>(ws + r * C::BNS + ((q4 * 4) ^ ((r & 1) ? C::WSWZ : 0))) = v;
+                    }
                 }
-            }
+            };
+            if (wscale == 1.0f) put(std::integral_constant<bool, false>{});
+            else put(std::integral_constant<bool, true>{});
         }
     };
     // ---- FIRST: conv1 (3x3, 1 -> 16, bias, ReLU) of the 18x18 halo, straight into the halo image,
@@ -641,7 +651,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
         if (chunk == nchunk - 1) {
             const bool fast = is_relu && cty * TH + TH <= H && ctx * TW + TW <= W && n0 + BN <= Cout;
             // the second copy of the epilogue costs the <32,3,32> form 15 spilled registers: 64-channel blocks only
-            if constexpr (BN == 64 && MODE == 0) {
+            if constexpr ((BN == 64 || (SQ_V2_FAST32 && BN == 32 && KC == 32)) && MODE == 0) {
                 if (fast) epilogue(ctx, cty, cn, std::integral_constant<bool, true>{});
                 else epilogue(ctx, cty, cn, std::integral_constant<bool, false>{});
             } else {
