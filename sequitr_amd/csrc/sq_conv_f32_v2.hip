@@ -202,7 +202,15 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
                 } else
 #pragma unroll
                 for (int sl = 0; sl < C::XSLOTS; ++sl) {
-                    const bool inb = live && (unsigned)(y0 + xpy[sl]) < (unsigned)H && (unsigned)(x0 + xpx[sl]) < (unsigned)W &&
+                    int hpy = xpy[sl], hpx = xpx[sl];
+                    if constexpr (KC == 32) {                       // 11 slots: the halo coordinates are recomputed on the border tiles
+                        int tv = tid;                               // instead of living in 22 registers (opaque: not hoisted back out)
+                        asm volatile("" : "+v"(tv));
+                        const int hp = (tv + sl * 256) / C::QPP;
+                        hpy = hp / C::HALO_W;
+                        hpx = hp - hpy * C::HALO_W;
+                    }
+                    const bool inb = live && (unsigned)(y0 + hpy) < (unsigned)H && (unsigned)(x0 + hpx) < (unsigned)W &&
                                      xrel[sl] != (int)OOB;
                     const unsigned off = inb ? (unsigned)(base + xrel[sl]) : OOB;
                     const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
@@ -245,7 +253,9 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : Cfg2<BN, KS, KC>::OCC)) void 
             if (SQ_V2_INNER && (BN == 64 || KC == 32) && live) {   // out-of-range slots keep their out-of-range VGPR offset
 #pragma unroll
                 for (int sl = 0; sl < C::WSLOTS; ++sl) {
-                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wrel[sl], wbase, 0);
+                    // KC == 32: slot sl is tap sl (256 threads = 32 rows x 8 quads): one lane offset + a scalar per slot
+                    const auto v = KC == 32 ? __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wrel[0], wbase + sl * CinW * Cout * 4, 0)
+                                            : __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wrel[sl], wbase, 0);
                     wr[sl] = *reinterpret_cast<const float4 *>(&v);
                 }
             } else
