@@ -18,15 +18,18 @@
 #include <stdlib.h>
 #include "sq_common.h"
 
+#ifndef SQ_CT_WNI
+#define SQ_CT_WNI 2                 // default pixel-tile width / 32 (env SQ_CONVT_WNI overrides)
+#endif
 #ifndef SQ_CT_FRAG_DBUF
 #define SQ_CT_FRAG_DBUF 0
 #endif
 
 namespace {
 
-constexpr int BM = 128, BN = 128, KCH = 32;
+constexpr int BM = 128, KCH = 32;             // the pixel tile is 32 * WNI wide (template): 128 or 64
 constexpr int RS = 40;                          // floats per staged row: [half][kk][s] + 8 of padding
-constexpr int AS_FLOATS = BM * RS, XS_FLOATS2 = BN * RS;
+constexpr int AS_FLOATS = BM * RS;
 constexpr unsigned OOB = 0x80000000u;
 
 typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
@@ -38,14 +41,18 @@ struct CtArgs {
     int mtiles, ntiles;                         // row tiles (4 Cout / 128), pixel tiles
 };
 
-template <int BRIDGE>
-__global__ __launch_bounds__(256, 2) void convT2x2_v2_kernel(const CtArgs a) {
+// WNI: 16-pixel column blocks per wave.  4: 128 x 128 block tiles, 64 x 64 per wave (240 registers, two blocks per CU);
+// 2: 128 x 64 tiles, 64 x 32 per wave -- half the accumulators and bridge operands, three blocks per CU: a block's epilogue
+// (its share of the bridge + output traffic) then overlaps two other blocks' MFMAs instead of one
+template <int BRIDGE, int WNI>
+__global__ __launch_bounds__(256, (WNI == 4 ? 2 : 3)) void convT2x2_v2_kernel(const CtArgs a) {
+    constexpr int BN = 32 * WNI;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *as = smem;
     float *xs = smem + AS_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
-    const int wm = wv >> 1, wn = wv & 1;        // the wave's 64 x 64 quadrant
+    const int wm = wv >> 1, wn = wv & 1;        // the wave's 64 x (16 WNI) quadrant
     const int Cin = a.Cin, Cout = a.Cout, H = a.H, W = a.W;
     const int G = (int)gridDim.x;
     const int vb = (int)sq_xcd_remap(blockIdx.x, gridDim.x);
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void convT2x2_v2_kernel(const CtArgs a) {
     const int grel = (srow * Cin + sq * 4) * 4;                     // + 32 rows per slot
     float *cwa = as + srow * RS + (sq >> 2) * 16 + (sq & 3);        // channel 4 q + j -> [half q / 4][kk = j][s = q % 4]
     float *cwx = xs + srow * RS + (sq >> 2) * 16 + (sq & 3);
-    float4 ar[4], br[4];
+    float4 ar[4], br[WNI];
     auto issue = [&](int mt, int nt, int cc) {
         const int abase = (mt * BM * Cin + cc) * 4, xbase = (nt * BN * Cin + cc) * 4;
 #pragma unroll
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void convT2x2_v2_kernel(const CtArgs a) {
             ar[it] = *reinterpret_cast<const float4 *>(&v);
         }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {                            // pixels past P read as zeros (buffer range check)
+        for (int it = 0; it < WNI; ++it) {                          // pixels past P read as zeros (buffer range check)
             // the tile offset sits in the VGPR offset: that is the one the range check sees
             const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, grel + it * 32 * Cin * 4 + xbase, 0, 0);
             br[it] = *reinterpret_cast<const float4 *>(&v);
@@ -90,28 +97,31 @@ __global__ __launch_bounds__(256, 2) void convT2x2_v2_kernel(const CtArgs a) {
         for (int it = 0; it < 4; ++it) {
             float *d = cwa + it * 32 * RS;
             d[0] = ar[it].x; d[4] = ar[it].y; d[8] = ar[it].z; d[12] = ar[it].w;
+        }
+#pragma unroll
+        for (int it = 0; it < WNI; ++it) {
             float *e = cwx + it * 32 * RS;
             e[0] = br[it].x; e[4] = br[it].y; e[8] = br[it].z; e[12] = br[it].w;
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][WNI];
     const float *fa = as + (64 * wm + li) * RS + 4 * kk;
-    const float *fb = xs + (64 * wn + li) * RS + 4 * kk;
-    auto load_frags = [&](int half, float4 (&fa4)[4], float4 (&fb4)[4]) {
+    const float *fb = xs + (16 * WNI * wn + li) * RS + 4 * kk;
+    auto load_frags = [&](int half, float4 (&fa4)[4], float4 (&fb4)[WNI]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa4[i] = *reinterpret_cast<const float4 *>(fa + i * 16 * RS + half * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fb4[i] = *reinterpret_cast<const float4 *>(fb + i * 16 * RS + half * 16);
+        for (int i = 0; i < WNI; ++i) fb4[i] = *reinterpret_cast<const float4 *>(fb + i * 16 * RS + half * 16);
     };
-    auto mfma_half = [&](const float4 (&fa4)[4], const float4 (&fb4)[4], bool first) {
+    auto mfma_half = [&](const float4 (&fa4)[4], const float4 (&fb4)[WNI], bool first) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const float av = s == 0 ? fa4[mi].x : (s == 1 ? fa4[mi].y : (s == 2 ? fa4[mi].z : fa4[mi].w));
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
+                for (int ni = 0; ni < WNI; ++ni) {
                     const float bvv = s == 0 ? fb4[ni].x : (s == 1 ? fb4[ni].y : (s == 2 ? fb4[ni].z : fb4[ni].w));
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                         av, bvv, (first && s == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mi][ni], 0, 0, 0);
@@ -121,17 +131,17 @@ __global__ __launch_bounds__(256, 2) void convT2x2_v2_kernel(const CtArgs a) {
     };
 
     // ---- epilogue geometry: offset = pixel part [ni] + class part [mi] (bytes) ----------------------------------------
-    int pixoff[4], clsoff[4];
-    float4 bq[4], sk[4][4];
+    int pixoff[WNI], clsoff[4];
+    float4 bq[4], sk[4][WNI];
     auto geometry = [&](int mt, int nt) {
-        const int p0 = nt * BN + 64 * wn + li;
-        // ONE division pair per tile; the other three column blocks by carrying 16 pixels forward
+        const int p0 = nt * BN + 16 * WNI * wn + li;
+        // ONE division pair per tile; the other column blocks by carrying 16 pixels forward
         unsigned pu = (unsigned)(p0 < a.P ? p0 : 0), t = pu / (unsigned)W;
         int jj = (int)(pu - t * (unsigned)W);
         unsigned n32 = t / (unsigned)H;
         int ii = (int)(t - n32 * (unsigned)H);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < WNI; ++ni) {
             const int p = p0 + 16 * ni;
             pixoff[ni] = p < a.P ? (int)((((n32 * 2 * H + 2 * ii) * (2 * W)) + 2 * jj) * Cout * 4) : (int)OOB;
             jj += 16;
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void convT2x2_v2_kernel(const CtArgs a) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
+                for (int ni = 0; ni < WNI; ++ni) {
                     const unsigned off = pixoff[ni] == (int)OOB ? OOB : (unsigned)(pixoff[ni] + clsoff[mi]);
                     const auto v = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
                     sk[mi][ni] = *reinterpret_cast<const float4 *>(&v);
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void convT2x2_v2_kernel(const CtArgs a) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < WNI; ++ni) {
                 f32x4 v = acc[mi][ni];
                 if (a.bias) { v[0] += bq[mi].x; v[1] += bq[mi].y; v[2] += bq[mi].z; v[3] += bq[mi].w; }
                 if constexpr (BRIDGE == SQ_BRIDGE_ADD) { v[0] += sk[mi][ni].x; v[1] += sk[mi][ni].y; v[2] += sk[mi][ni].z; v[3] += sk[mi][ni].w; }
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void convT2x2_v2_kernel(const CtArgs a) {
         if (has_next) issue(ntile % a.mtiles, ntile / a.mtiles, nchk * KCH);
         {
 #if SQ_CT_FRAG_DBUF
-            float4 fa0[4], fb0[4], fa1[4], fb1[4];
+            float4 fa0[4], fb0[WNI], fa1[4], fb1[WNI];
             load_frags(0, fa0, fb0);
             load_frags(1, fa1, fb1);
             __builtin_amdgcn_s_setprio(0);
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void convT2x2_v2_kernel(const CtArgs a) {
 #else
             // one fragment set (32 registers), the second half's reads behind the first half's MFMAs: with the sixteen
             // bridge operands in flight the double-buffered form spills (267 registers wanted)
-            float4 fa0[4], fb0[4];
+            float4 fa0[4], fb0[WNI];
             load_frags(0, fa0, fb0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -229,11 +239,14 @@ __global__ __launch_bounds__(256, 2) void convT2x2_v2_kernel(const CtArgs a) {
     }
 }
 
-template <int BRIDGE>
-int launch_ct(const CtArgs &a, hipStream_t st) {
+template <int BRIDGE, int WNI>
+int launch_ct(const CtArgs &a0, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = convT2x2_v2_kernel<BRIDGE>;
-    constexpr int lds = (AS_FLOATS + XS_FLOATS2) * 4;
+    auto kern = convT2x2_v2_kernel<BRIDGE, WNI>;
+    constexpr int BN = 32 * WNI;
+    constexpr int lds = (AS_FLOATS + BN * RS) * 4;
+    CtArgs a = a0;
+    a.ntiles = (a.P + BN - 1) / BN;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             sq_set_error("convT2x2_v2: cannot reserve %d bytes of LDS", lds);
@@ -242,7 +255,8 @@ int launch_ct(const CtArgs &a, hipStream_t st) {
         attr_set = true;
     }
     const int total = a.mtiles * a.ntiles;
-    int G = total < 512 ? total : 512;
+    const int want = 256 * (WNI == 4 ? 2 : 3);
+    int G = total < want ? total : want;
     if (G > a.mtiles) G -= G % a.mtiles;                            // the row tiles of one pixel tile start together
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, a);
     return sq_check_launch("sq_convT2x2s2_nhwc_fwd_f32(v2)");
@@ -262,11 +276,19 @@ int sq_convT_v2_launch(const float *x, const float *w, const float *bias, const 
     a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.y = y;
     a.P = (int)P; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.mtiles = 4 * Cout / BM;
-    a.ntiles = (int)((P + BN - 1) / BN);
+    static const int wni = [] { const char *v = getenv("SQ_CONVT_WNI"); return v ? atoi(v) : SQ_CT_WNI; }();   // A/B switch: 4 or 2
+    if (wni == 4) {
+        switch (bridge) {
+            case SQ_BRIDGE_ADD: return launch_ct<SQ_BRIDGE_ADD, 4>(a, st);
+            case SQ_BRIDGE_MUL: return launch_ct<SQ_BRIDGE_MUL, 4>(a, st);
+            case SQ_BRIDGE_SUB: return launch_ct<SQ_BRIDGE_SUB, 4>(a, st);
+            default: return launch_ct<SQ_BRIDGE_NONE, 4>(a, st);
+        }
+    }
     switch (bridge) {
-        case SQ_BRIDGE_ADD: return launch_ct<SQ_BRIDGE_ADD>(a, st);
-        case SQ_BRIDGE_MUL: return launch_ct<SQ_BRIDGE_MUL>(a, st);
-        case SQ_BRIDGE_SUB: return launch_ct<SQ_BRIDGE_SUB>(a, st);
-        default: return launch_ct<SQ_BRIDGE_NONE>(a, st);
+        case SQ_BRIDGE_ADD: return launch_ct<SQ_BRIDGE_ADD, 2>(a, st);
+        case SQ_BRIDGE_MUL: return launch_ct<SQ_BRIDGE_MUL, 2>(a, st);
+        case SQ_BRIDGE_SUB: return launch_ct<SQ_BRIDGE_SUB, 2>(a, st);
+        default: return launch_ct<SQ_BRIDGE_NONE, 2>(a, st);
     }
 }
