@@ -3,8 +3,9 @@
 // c ascending: the chain of convT2x2_mfma_f32_kernel in sq_convt_loss.hip and of the oracle, bit for bit), + bias, then
 // the bridge with the skip tensor.  Rebuilt on what the level-0 kernels of this round showed (sq_conv_f32_l0.hip): what
 // a SIMD issues BESIDE its MFMAs is what it loses, and a streaming epilogue needs its loads in flight early.
-//   * persistent blocks walk (pixel tile, row tile) work; a block tile is 128 rows x 128 input pixels, a wave owns
-//     64 x 64 of it = 16 accumulators: 16 MFMAs per pair of operand fragments instead of 4;
+//   * persistent blocks walk (pixel tile, row tile) work; a block tile is 128 rows x 32 WNI input pixels (WNI = 1, 2, 4;
+//     a wave owns 64 rows x 16 WNI pixels): wide tiles issue more MFMAs per operand fragment and win stand-alone, narrow
+//     ones keep more blocks per CU and win inside the network's step (the default);
 //   * both operands are staged CHANNEL-TRANSPOSED ([row][16-channel half][kk][s] = channel 16 half + 4 s + kk, 40
 //     floats per row): one ds_read_b128 is a lane's operand for four k steps, conflict-free (10 li + kk covers the 16
 //     slots of a bank row in each of the instruction's lane groups) -- 16 LDS reads per 128 MFMAs instead of 160;
@@ -19,7 +20,7 @@
 #include "sq_common.h"
 
 #ifndef SQ_CT_WNI
-#define SQ_CT_WNI 2                 // default pixel-tile width / 32 (env SQ_CONVT_WNI overrides)
+#define SQ_CT_WNI 1                 // default pixel-tile width / 32 (env SQ_CONVT_WNI overrides; 1: 5.133, 2: 5.140, 4: 5.162 ms per inference step)
 #endif
 #ifndef SQ_CT_FRAG_DBUF
 #define SQ_CT_FRAG_DBUF 0
@@ -45,7 +46,7 @@ struct CtArgs {
 // 2: 128 x 64 tiles, 64 x 32 per wave -- half the accumulators and bridge operands, three blocks per CU: a block's epilogue
 // (its share of the bridge + output traffic) then overlaps two other blocks' MFMAs instead of one
 template <int BRIDGE, int WNI>
-__global__ __launch_bounds__(256, (WNI == 4 ? 2 : 3)) void convT2x2_v2_kernel(const CtArgs a) {
+__global__ __launch_bounds__(256, (WNI == 4 ? 2 : (WNI == 2 ? 3 : 4))) void convT2x2_v2_kernel(const CtArgs a) {
     constexpr int BN = 32 * WNI;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *as = smem;
@@ -255,7 +256,7 @@ int launch_ct(const CtArgs &a0, hipStream_t st) {
         attr_set = true;
     }
     const int total = a.mtiles * a.ntiles;
-    const int want = 256 * (WNI == 4 ? 2 : 3);
+    const int want = 256 * (WNI == 4 ? 2 : (WNI == 2 ? 3 : 4));
     int G = total < want ? total : want;
     if (G > a.mtiles) G -= G % a.mtiles;                            // the row tiles of one pixel tile start together
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, a);
@@ -283,6 +284,14 @@ int sq_convT_v2_launch(const float *x, const float *w, const float *bias, const 
             case SQ_BRIDGE_MUL: return launch_ct<SQ_BRIDGE_MUL, 4>(a, st);
             case SQ_BRIDGE_SUB: return launch_ct<SQ_BRIDGE_SUB, 4>(a, st);
             default: return launch_ct<SQ_BRIDGE_NONE, 4>(a, st);
+        }
+    }
+    if (wni == 1) {
+        switch (bridge) {
+            case SQ_BRIDGE_ADD: return launch_ct<SQ_BRIDGE_ADD, 1>(a, st);
+            case SQ_BRIDGE_MUL: return launch_ct<SQ_BRIDGE_MUL, 1>(a, st);
+            case SQ_BRIDGE_SUB: return launch_ct<SQ_BRIDGE_SUB, 1>(a, st);
+            default: return launch_ct<SQ_BRIDGE_NONE, 1>(a, st);
         }
     }
     switch (bridge) {
