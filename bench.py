@@ -328,12 +328,13 @@ def end_to_end_rate(net, x_dev, iters=5, dist=None, world=1):
     number shows whether the host can feed N cards at once."""
     from sequitr_amd.frontend import TileStreamer
     n = x_dev.shape[0]
-    k = max(2 * iters, 8)
+    k = max(2 * iters, 32)                                     # a 32-batch stream: pipeline fill, drain and the clock ramp of
+                                                               # its first batches are ~4 ms, 2 % of it (a 10-batch stream: 7 %)
     xh1 = x_dev.cpu()
     xh = xh1.repeat(k, 1, 1, 1).pin_memory()                   # k batches, pinned (allocated after set_device)
     st = TileStreamer(net, batch=n, want_logits=False)
     st.warm_up(tuple(x_dev.shape[1:]))
-    masks = np.empty((k * n,) + tuple(x_dev.shape[1:3]), np.uint8)
+    masks = np.zeros((k * n,) + tuple(x_dev.shape[1:3]), np.uint8)   # zeros: the pages are touched before the timed pass
 
     def sync_all():
         if dist is not None:

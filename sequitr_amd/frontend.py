@@ -9,6 +9,7 @@ Tiling (build-defined: the reference only ever crops fixed-size tiles, pipeline.
 length L, tiles of size T start at 0, T-2m, 2(T-2m), ... and the last one at L-T; every pixel is owned by the
 tile in which it lies at least `m` (margin) pixels from the tile border, except at the frame border.
 """
+import os
 import time
 
 import numpy as np
@@ -255,33 +256,64 @@ class TileStreamer(object):
     def _pick_streams(self):
         """Copy streams whose transfers really run UNDER the network's kernels.  HIP spreads its streams over a few
         hardware queues; a copy stream that lands on the compute stream's queue is executed in order with the kernels and
-        the pipeline falls back to the serial rate (measured on MI355X: the same three-stream loop ran at 5.45 or 6.1 ms
-        per batch depending on which streams a fresh torch.cuda.Stream() happened to be).  So: candidates are tried --
-        one batch of the network on the compute stream, an upload enqueued behind it on the candidate -- and a candidate
-        is kept when its copy finished well before the network did."""
-        dev, net = self.net.device, self.net
+        the pipeline falls back to the serial rate (measured on MI355X: the same three-stream loop runs at 5.7 .. 6.4 ms
+        per batch depending on which streams it got, 5.13 ms being the network alone).  A single upload enqueued behind
+        one network pass did not predict the steady state (round 4: pairs that passed that test ran the pipeline at the
+        serial rate), so every candidate PAIR -- default-priority and high-priority streams -- runs a short pipelined
+        loop of its own here, uploads, network and downloads as run() queues them, and the fastest pair is kept."""
+        dev, net, B = self.net.device, self.net, self.B
         main = torch.cuda.current_stream(dev)
-        good, tried = [], []
         self.dev_in[0].zero_()
-        for _ in range(12):
-            cand = torch.cuda.Stream(device=dev)
-            tried.append(cand)
-            e0, e1, ec = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            cand.wait_stream(main)
-            e0.record(main)
-            net.predict(self.dev_in[0])
-            e1.record(main)
-            with torch.cuda.stream(cand):
-                self.dev_in[1].copy_(self.pin_in[1], non_blocking=True)
-                ec.record(cand)
+        self.dev_in[1].zero_()
+
+        def probe(s_in, s_out, nb=6):
+            up = [torch.cuda.Event() for _ in range(2)]
+            used = [torch.cuda.Event() for _ in range(2)]
+            for e in up + used:
+                e.record(main)
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            held = [None, None]
+            for b in range(nb):
+                k = b & 1
+                with torch.cuda.stream(s_in):
+                    s_in.wait_event(used[k])
+                    self.dev_in[k].copy_(self.pin_in[k], non_blocking=True)
+                    up[k].record(s_in)
+                main.wait_event(up[k])
+                if b == 2:
+                    t0.record(main)
+                mask = net.predict(self.dev_in[k])
+                used[k].record(main)
+                done = torch.cuda.Event()
+                done.record(main)
+                held[k] = mask
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(done)
+                    self.pin_mask[k].copy_(mask, non_blocking=True)
+            t1.record(main)
             torch.cuda.synchronize(dev)
-            if e0.elapsed_time(ec) < 0.6 * e0.elapsed_time(e1):
-                good.append(cand)
-                if len(good) == 2:
-                    break
-        self.overlap_found = len(good)
-        pick = good + [c for c in tried if c not in good]
-        self.s_in, self.s_out = pick[0], pick[1]
+            return t0.elapsed_time(t1) / (nb - 2)
+
+        # the network alone, for the stopping rule (a pair that streams within 4 % of it hides its copies completely)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        net.predict(self.dev_in[0])
+        e0.record(main)
+        for _ in range(3):
+            net.predict(self.dev_in[0])
+        e1.record(main)
+        torch.cuda.synchronize(dev)
+        alone = e0.elapsed_time(e1) / 3
+        best, self.probe_ms = None, []
+        for prio in (0, -1, 0, -1, 0, -1, 0, -1):
+            pair = (torch.cuda.Stream(device=dev, priority=prio), torch.cuda.Stream(device=dev, priority=prio))
+            ms = probe(*pair)
+            self.probe_ms.append(round(ms, 3))
+            if best is None or ms < best[0]:
+                best = (ms, pair)
+            if ms <= 1.04 * alone:
+                break
+        self.s_in, self.s_out = best[1]
+        self.overlap_found = int(best[0] <= 1.04 * alone)       # 1: a pair was found whose copies hide completely
 
     def warm_up(self, tile_shape):
         """allocate the staging buffers and run one batch of zeros through the network (first-launch costs:
@@ -334,7 +366,7 @@ class TileStreamer(object):
             """host wait by polling: a worker never sits inside a blocking runtime call while the launching thread enqueues
             (events fire within a batch time; 100 us of sleep per poll costs nothing against 5 ms batches)"""
             while not ev.query():
-                time.sleep(1e-4)
+                time.sleep(float(os.environ.get("SQ_STREAM_POLL", "1e-4")))
 
         def count(b):
             return min(B, N - b * B)
