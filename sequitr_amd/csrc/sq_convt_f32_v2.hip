@@ -134,30 +134,48 @@ __global__ __launch_bounds__(256, (WNI == 4 ? 2 : (WNI == 2 ? 3 : 4))) void conv
     // ---- epilogue geometry: offset = pixel part [ni] + class part [mi] (bytes) ----------------------------------------
     int pixoff[WNI], clsoff[4];
     float4 bq[4], sk[4][WNI];
-    auto geometry = [&](int mt, int nt) {
-        const int p0 = nt * BN + 16 * WNI * wn + li;
-        // ONE division pair per tile; the other column blocks by carrying 16 pixels forward
-        unsigned pu = (unsigned)(p0 < a.P ? p0 : 0), t = pu / (unsigned)W;
-        int jj = (int)(pu - t * (unsigned)W);
-        unsigned n32 = t / (unsigned)H;
-        int ii = (int)(t - n32 * (unsigned)H);
+    // The row tile of a block never changes (the grid is a multiple of the row tiles per pixel tile), so the class part
+    // of the offsets and the bias quads are made ONCE; the pixel part advances from tile to tile by carries (the tile
+    // stride in pixels is a constant of the block): per tile this was six divisions and four bias loads for 64-512 MFMAs
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int rho = (vb % a.mtiles) * BM + 64 * wm + 16 * mi + 4 * kk;
+        const int ab = rho / Cout, o = rho - ab * Cout;
+        clsoff[mi] = (((ab >> 1) * 2 * W + (ab & 1)) * Cout + o) * 4;
+        bq[mi] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int step_px = (G / a.mtiles) * BN;                        // pixels from one tile of the walk to the next
+    const int s_j = step_px % W, s_i = (step_px / W) % H, s_n = step_px / (W * H);
+    int gp = (vb / a.mtiles) * BN + 16 * WNI * wn + li;             // the lane's first pixel of the current tile
+    int gj, gi, gn;
+    {
+        const unsigned pu = (unsigned)(gp < a.P ? gp : 0), t = pu / (unsigned)W;
+        gj = (int)(pu - t * (unsigned)W);
+        gn = (int)(t / (unsigned)H);
+        gi = (int)(t - (unsigned)gn * (unsigned)H);
+    }
+    auto geometry = [&]() {                                         // pixel offsets of the current tile
+        int jj = gj, ii = gi, n32 = gn;
 #pragma unroll
         for (int ni = 0; ni < WNI; ++ni) {
-            const int p = p0 + 16 * ni;
+            const int p = gp + 16 * ni;
             pixoff[ni] = p < a.P ? (int)((((n32 * 2 * H + 2 * ii) * (2 * W)) + 2 * jj) * Cout * 4) : (int)OOB;
-            jj += 16;
-            while (jj >= W) {
-                jj -= W;
-                if (++ii == H) { ii = 0; ++n32; }
+            if (ni + 1 < WNI) {
+                jj += 16;
+                while (jj >= W) {
+                    jj -= W;
+                    if (++ii == H) { ii = 0; ++n32; }
+                }
             }
         }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int rho = mt * BM + 64 * wm + 16 * mi + 4 * kk;
-            const int ab = rho / Cout, o = rho - ab * Cout;
-            clsoff[mi] = (((ab >> 1) * 2 * W + (ab & 1)) * Cout + o) * 4;
-            bq[mi] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    };
+    auto geometry_advance = [&]() {                                 // ... and on to the next tile of the walk
+        gp += step_px;
+        gj += s_j;
+        if (gj >= W) { gj -= W; gi += 1; }
+        gi += s_i;
+        if (gi >= H) { gi -= H; gn += 1; }
+        gn += s_n;
     };
     auto issue_skip = [&]() {
         if constexpr (BRIDGE != SQ_BRIDGE_NONE) {
@@ -198,7 +216,7 @@ __global__ __launch_bounds__(256, (WNI == 4 ? 2 : (WNI == 2 ? 3 : 4))) void conv
         const bool has_next = it + 1 < nitems;
         const bool last = chunk == nchunk - 1;
         if (last) {                                                 // the bridge operands, in flight under this chunk's MFMAs
-            geometry(tile % a.mtiles, tile / a.mtiles);
+            geometry();
             issue_skip();
         }
         if (has_next) issue(ntile % a.mtiles, ntile / a.mtiles, nchk * KCH);
@@ -233,7 +251,7 @@ __global__ __launch_bounds__(256, (WNI == 4 ? 2 : (WNI == 2 ? 3 : 4))) void conv
             __syncthreads();                                        // every wave is done reading this item's images
             commit();
         }
-        if (last) epilogue();
+        if (last) { epilogue(); geometry_advance(); }
         if (has_next) __syncthreads();
         tile = ntile;
         chunk = nchk;
